@@ -1,0 +1,11 @@
+"""MI355X-native flat-sky CMB lensing field engine (host-side mirror of the CMBLensing.jl operator surface).
+
+The compute path is the hand-written HIP library `libcmblens_hip.so` (csrc/, C ABI in include/cmblens.h).
+This package is plumbing: it loads the library with ctypes, holds device memory in torch tensors, and mirrors
+the reference's names (ProjLambert, LenseFlow, BaseDataSet, argmaxf_logpdf, ...) for the path in scope.
+There is NO CPU fallback: without the built library or without a GPU every compute call raises.
+"""
+from .lib import load_library, library_path, CmblError, build            # noqa: F401
+from .engine import (ProjLambert, LenseFlow, BaseDataSet, Field, MAP, FOURIER, HARMONIC,   # noqa: F401
+                     FLOW_FWD, FLOW_INV, FLOW_ADJ, FLOW_INVADJ)
+from .sim import (Cls, load_sim, noise_cls, beam_cls, lowpass, cl_to_2d, HarmOp, border_mask)   # noqa: F401

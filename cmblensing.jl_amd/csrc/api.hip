@@ -1,0 +1,274 @@
+// C ABI of libcmblens_hip.so (see include/cmblens.h).  Single translation unit: all kernels are templates.
+#include "engine.hpp"
+#include "../../include/cmblens.h"
+
+namespace cmbl { thread_local std::string g_last_error; }
+using namespace cmbl;
+
+struct cmbl_ctx { std::unique_ptr<CtxBase> p; };
+struct cmbl_flow { cmbl_ctx* ctx; std::unique_ptr<Flow<float>> f32; std::unique_ptr<Flow<double>> f64; };
+struct cmbl_dataset { cmbl_ctx* ctx; std::unique_ptr<Dataset<float>> f32; std::unique_ptr<Dataset<double>> f64; };
+
+template <typename F>
+static int guard(F&& f) {
+  try { f(); return CMBL_OK; }
+  catch (const Error& e) { g_last_error = e.msg; return e.code; }
+  catch (const std::exception& e) { g_last_error = e.what(); return CMBL_ERR_ARG; }
+  catch (...) { g_last_error = "unknown error"; return CMBL_ERR_ARG; }
+}
+#define NOTNULL(p) CMBL_REQUIRE((p) != nullptr, ERR_ARG, "null pointer argument: " #p)
+#define BASIS_OK(b) CMBL_REQUIRE((b) >= 0 && (b) <= 2, ERR_ARG, "bad basis: " #b)
+#define POLB_OK(P, B) CMBL_REQUIRE((P) >= 1 && (P) <= 3 && (B) >= 1, ERR_SHAPE, "npol must be 1..3 and nbatch >= 1")
+
+template <typename T> static Ctx<T>* C(cmbl_ctx* c) { return static_cast<Ctx<T>*>(c->p.get()); }
+#define BY_DTYPE(ctx, expr32, expr64) do { if ((ctx)->p->dtype == CMBL_F32) { expr32; } else { expr64; } } while (0)
+
+template <typename T> static void do_convert(cmbl_ctx* ctx, int bi, const void* in, int bo, void* out, int P, int B) {
+  Ctx<T>* c = C<T>(ctx);
+  const long sl = (long)P * B;
+  c->tmpA.ensure(sizeof(cx<T>) * sl * c->plane());
+  cx<T>* F = c->tmpA.template as<cx<T>>();
+  // carry the data in the basis of whichever side is a Fourier basis; map<->map is a copy
+  if (bi == B_MAP && bo == B_MAP) { CMBL_HIP(hipMemcpyAsync(out, in, sizeof(T) * sl * c->npix(), hipMemcpyDeviceToDevice, c->stream)); return; }
+  const int carry = (bi == B_MAP) ? (bo == B_HARMONIC ? B_HARMONIC : B_FOURIER) : bi;
+  c->to_F(bi, in, F, carry, P, B);
+  c->from_F(F, carry, bo, out, P, B);
+}
+template <typename T>
+static void do_diag(cmbl_ctx* ctx, int kind, int bd, const void* diag, int nplanes, bool transpose, int bi, const void* in, int bo, void* out, int P, int B) {
+  Ctx<T>* c = C<T>(ctx);
+  const long sl = (long)P * B;
+  c->tmpA.ensure(sizeof(cx<T>) * sl * c->plane());
+  c->tmpB.ensure(sizeof(T) * nplanes * c->plane());
+  cx<T>* F = c->tmpA.template as<cx<T>>();
+  T* dF = c->tmpB.template as<T>();
+  c->ref2F_real((const T*)diag, dF, nplanes);
+  const T* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < nplanes; ++k) d[k] = dF + (size_t)k * c->plane();
+  c->to_F(bi, in, F, bd, P, B);                       // B(f): convert to the operator's basis (src/specialops.jl:9)
+  c->harm(F, F, P, B, kind, d, transpose, false, false);
+  c->from_F(F, bd, bo, out, P, B);
+}
+template <typename T> static void do_dot(cmbl_ctx* ctx, int basis, const void* a, const void* b, int P, int B, double* out) {
+  Ctx<T>* c = C<T>(ctx);
+  if (basis == B_MAP) { c->dot_map((const T*)a, (const T*)b, P, B, out); return; }
+  // Fourier-type bases: the weighted sum is invariant under the internal permutation, but lam depends on ky, so
+  // bring both operands to F layout (rotation QU<->EB is orthogonal entry by entry, any Fourier basis works as is)
+  const long sl = (long)P * B;
+  c->tmpA.ensure(sizeof(cx<T>) * 2 * sl * c->plane());
+  cx<T>* Fa = c->tmpA.template as<cx<T>>(); cx<T>* Fb = Fa + sl * c->plane();
+  c->ref2F((const cx<T>*)a, Fa, sl); c->ref2F((const cx<T>*)b, Fb, sl);
+  c->dot_F(Fa, Fb, P, B, out);
+}
+template <typename T> static void do_logdet(cmbl_ctx* ctx, const void* d, int nplanes, double* out) {
+  Ctx<T>* c = C<T>(ctx);
+  c->tmpB.ensure(sizeof(T) * nplanes * c->plane());
+  c->ref2F_real((const T*)d, c->tmpB.template as<T>(), nplanes);
+  c->logdet_F(c->tmpB.template as<T>(), nplanes, out);
+}
+template <typename T>
+static void do_gradf(Dataset<T>& ds, Flow<T>& L, const void* f, const void* d, int zero_d, void* out, int B) {
+  Ctx<T>* c = ds.c;
+  const long n = ds.fsize(B);
+  ds.cvt.ensure(sizeof(cx<T>) * 3 * n);
+  cx<T>* fF = ds.cvt.template as<cx<T>>(); cx<T>* dF = fF + n; cx<T>* oF = dF + n;
+  c->ref2F((const cx<T>*)f, fF, (long)ds.P * B);
+  const cx<T>* dd = nullptr;
+  if (!zero_d) {
+    if (d) { c->ref2F((const cx<T>*)d, dF, (long)ds.P * B); dd = dF; }
+    else { CMBL_REQUIRE(ds.Bd == B, ERR_SHAPE, "dataset data batch size differs from nbatch"); dd = ds.d_h.template as<cx<T>>(); }
+  }
+  ds.gradientf(L, fF, dd, oF, B);
+  c->F2ref(oF, (cx<T>*)out, (long)ds.P * B);
+}
+template <typename T>
+static void do_cg(Dataset<T>& ds, Flow<T>& L, const void* d, const void* fstart, double tol, int maxit, void* f_out, double* hist, int* nit, int B) {
+  Ctx<T>* c = ds.c;
+  const long n = ds.fsize(B);
+  ds.cvt.ensure(sizeof(cx<T>) * 3 * n);
+  cx<T>* dF = ds.cvt.template as<cx<T>>(); cx<T>* sF = dF + n; cx<T>* oF = sF + n;
+  const cx<T>* dd;
+  if (d) { c->ref2F((const cx<T>*)d, dF, (long)ds.P * B); dd = dF; }
+  else { CMBL_REQUIRE(ds.Bd == B, ERR_SHAPE, "dataset data batch size differs from nbatch"); dd = ds.d_h.template as<cx<T>>(); }
+  const cx<T>* fs = nullptr;
+  if (fstart) { c->ref2F((const cx<T>*)fstart, sF, (long)ds.P * B); fs = sF; }
+  *nit = ds.wiener_cg(L, dd, fs, tol, maxit, oF, hist, B);
+  c->F2ref(oF, (cx<T>*)f_out, (long)ds.P * B);
+  CMBL_HIP(hipStreamSynchronize(c->stream));
+}
+template <typename T>
+static void do_lpm(Dataset<T>& ds, Flow<T>& L, const void* fo, const void* phio, double* lp, void* gfo, void* gphio, int B, int quirk) {
+  Ctx<T>* c = ds.c;
+  const long pl = c->plane();
+  ds.cvt.ensure(sizeof(cx<T>) * 2 * B * pl);
+  cx<T>* pF = ds.cvt.template as<cx<T>>(); cx<T>* gF = pF + (long)B * pl;
+  c->ref2F((const cx<T>*)phio, pF, B);
+  ds.logpdf_mixed(L, (const T*)fo, pF, lp, (T*)gfo, gfo ? gF : nullptr, B, quirk != 0);
+  if (gfo) c->F2ref(gF, (cx<T>*)gphio, B);
+  CMBL_HIP(hipStreamSynchronize(c->stream));
+}
+
+extern "C" {
+
+const char* cmbl_last_error(void) { return g_last_error.c_str(); }
+int cmbl_version(void) { return 100; }
+
+int cmbl_ctx_create(int Ny, int Nx, double theta, int dtype, int device, void* stream, cmbl_ctx** out) {
+  return guard([&] {
+    NOTNULL(out);
+    CMBL_REQUIRE(dtype == CMBL_F32 || dtype == CMBL_F64, ERR_ARG, "dtype must be CMBL_F32 or CMBL_F64");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) fail(ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    CMBL_REQUIRE(device >= 0 && device < ndev, ERR_ARG, "device index out of range");
+    auto h = std::make_unique<cmbl_ctx>();
+    if (dtype == CMBL_F32) h->p = std::make_unique<Ctx<float>>(Ny, Nx, theta, device, stream);
+    else h->p = std::make_unique<Ctx<double>>(Ny, Nx, theta, device, stream);
+    *out = h.release();
+  });
+}
+int cmbl_ctx_destroy(cmbl_ctx* ctx) { return guard([&] { delete ctx; }); }
+int cmbl_ctx_synchronize(cmbl_ctx* ctx) { return guard([&] { NOTNULL(ctx); CMBL_HIP(hipStreamSynchronize(ctx->p->stream)); }); }
+
+int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out, size_t n) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(out);
+    const CtxBase& c = *ctx->p;
+    const std::vector<double>* v = which == 0 ? &c.h_lx : which == 1 ? &c.h_ly : which == 2 ? &c.h_lam : which == 3 ? &c.h_sin2
+                                 : which == 4 ? &c.h_cos2 : which == 5 ? &c.h_lmag : nullptr;
+    CMBL_REQUIRE(v != nullptr, ERR_ARG, "bad geometry selector");
+    CMBL_REQUIRE(n == v->size(), ERR_SHAPE, "geometry output has the wrong length");
+    std::memcpy(out, v->data(), n * sizeof(double));
+  });
+}
+
+
+int cmbl_convert(cmbl_ctx* ctx, int bi, const void* in, int bo, void* out, int P, int B) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(in); NOTNULL(out); BASIS_OK(bi); BASIS_OK(bo); POLB_OK(P, B);
+    BY_DTYPE(ctx, do_convert<float>(ctx, bi, in, bo, out, P, B), do_convert<double>(ctx, bi, in, bo, out, P, B));
+  });
+}
+int cmbl_rfft(cmbl_ctx* ctx, const void* map, void* fourier, int P, int B) { return cmbl_convert(ctx, CMBL_MAP, map, CMBL_FOURIER, fourier, P, B); }
+int cmbl_irfft(cmbl_ctx* ctx, const void* fourier, void* map, int P, int B) { return cmbl_convert(ctx, CMBL_FOURIER, fourier, CMBL_MAP, map, P, B); }
+
+
+int cmbl_diag_apply(cmbl_ctx* ctx, int kind, int bd, const void* diag, int bi, const void* in, int bo, void* out, int P, int B) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(diag); NOTNULL(in); NOTNULL(out); BASIS_OK(bi); BASIS_OK(bo); POLB_OK(P, B);
+    CMBL_REQUIRE(kind == CMBL_DIAG_MUL || kind == CMBL_DIAG_DIV_NAN2ZERO, ERR_ARG, "kind must be CMBL_DIAG_MUL or CMBL_DIAG_DIV_NAN2ZERO");
+    CMBL_REQUIRE(bd == CMBL_FOURIER || bd == CMBL_HARMONIC, ERR_ARG, "operator must be diagonal in FOURIER or HARMONIC");
+    BY_DTYPE(ctx, do_diag<float>(ctx, kind, bd, diag, P, false, bi, in, bo, out, P, B), do_diag<double>(ctx, kind, bd, diag, P, false, bi, in, bo, out, P, B));
+  });
+}
+int cmbl_blockdiag_ieb_apply(cmbl_ctx* ctx, const void* te_bb, int transpose, int bi, const void* in, int bo, void* out, int B) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(te_bb); NOTNULL(in); NOTNULL(out); BASIS_OK(bi); BASIS_OK(bo); POLB_OK(3, B);
+    BY_DTYPE(ctx, do_diag<float>(ctx, 2, B_HARMONIC, te_bb, 5, transpose != 0, bi, in, bo, out, 3, B),
+             do_diag<double>(ctx, 2, B_HARMONIC, te_bb, 5, transpose != 0, bi, in, bo, out, 3, B));
+  });
+}
+
+int cmbl_dot(cmbl_ctx* ctx, int basis, const void* a, const void* b, int P, int B, double* out) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(a); NOTNULL(b); NOTNULL(out); BASIS_OK(basis); POLB_OK(P, B);
+    BY_DTYPE(ctx, do_dot<float>(ctx, basis, a, b, P, B, out), do_dot<double>(ctx, basis, a, b, P, B, out));
+  });
+}
+int cmbl_logdet(cmbl_ctx* ctx, const void* d, int nplanes, double* out) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(d); NOTNULL(out); CMBL_REQUIRE(nplanes >= 1, ERR_ARG, "nplanes >= 1");
+    BY_DTYPE(ctx, do_logdet<float>(ctx, d, nplanes, out), do_logdet<double>(ctx, d, nplanes, out));
+  });
+}
+
+// ---- LenseFlow -------------------------------------------------------------------------------------
+int cmbl_lenseflow_create(cmbl_ctx* ctx, int nsteps, cmbl_flow** out) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(out);
+    auto h = std::make_unique<cmbl_flow>();
+    h->ctx = ctx;
+    BY_DTYPE(ctx, h->f32 = std::make_unique<Flow<float>>(C<float>(ctx), nsteps), h->f64 = std::make_unique<Flow<double>>(C<double>(ctx), nsteps));
+    *out = h.release();
+  });
+}
+int cmbl_lenseflow_destroy(cmbl_flow* L) { return guard([&] { delete L; }); }
+int cmbl_lenseflow_set_phi(cmbl_flow* L, int basis, const void* phi, int nb) {
+  return guard([&] {
+    NOTNULL(L); NOTNULL(phi); BASIS_OK(basis); CMBL_REQUIRE(nb >= 1, ERR_SHAPE, "nbatch_phi >= 1");
+    BY_DTYPE(L->ctx, L->f32->set_phi(basis, phi, nb), L->f64->set_phi(basis, phi, nb));
+  });
+}
+int cmbl_lenseflow_apply(cmbl_flow* L, int mode, int bi, const void* in, int bo, void* out, int P, int B) {
+  return guard([&] {
+    NOTNULL(L); NOTNULL(in); NOTNULL(out); BASIS_OK(bi); BASIS_OK(bo); POLB_OK(P, B);
+    CMBL_REQUIRE(mode >= 0 && mode <= 3, ERR_ARG, "bad flow mode");
+    BY_DTYPE(L->ctx, L->f32->apply(mode, bi, in, bo, out, P, B), L->f64->apply(mode, bi, in, bo, out, P, B));
+  });
+}
+int cmbl_lenseflow_grad(cmbl_flow* L, int mode, const void* f_end, int bdel, const void* delta, void* dphi, int bdf, void* df,
+                        void* f_start, int P, int B, int quirk) {
+  return guard([&] {
+    NOTNULL(L); NOTNULL(f_end); NOTNULL(delta); NOTNULL(dphi); NOTNULL(df); BASIS_OK(bdel); BASIS_OK(bdf); POLB_OK(P, B);
+    CMBL_REQUIRE(mode == CMBL_FLOW_FWD || mode == CMBL_FLOW_INV, ERR_ARG, "grad mode must be CMBL_FLOW_FWD or CMBL_FLOW_INV");
+    BY_DTYPE(L->ctx, L->f32->grad(mode, f_end, bdel, delta, dphi, bdf, df, f_start, P, B, quirk != 0),
+             L->f64->grad(mode, f_end, bdel, delta, dphi, bdf, df, f_start, P, B, quirk != 0));
+  });
+}
+
+// ---- dataset ---------------------------------------------------------------------------------------
+int cmbl_dataset_create(cmbl_ctx* ctx, int npol, cmbl_dataset** out) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(out);
+    auto h = std::make_unique<cmbl_dataset>();
+    h->ctx = ctx;
+    BY_DTYPE(ctx, h->f32 = std::make_unique<Dataset<float>>(C<float>(ctx), npol), h->f64 = std::make_unique<Dataset<double>>(C<double>(ctx), npol));
+    *out = h.release();
+  });
+}
+int cmbl_dataset_destroy(cmbl_dataset* ds) { return guard([&] { delete ds; }); }
+int cmbl_dataset_set_op(cmbl_dataset* ds, int which, const void* planes, int nplanes) {
+  return guard([&] { NOTNULL(ds); NOTNULL(planes); BY_DTYPE(ds->ctx, ds->f32->set_op(which, planes, nplanes), ds->f64->set_op(which, planes, nplanes)); });
+}
+int cmbl_dataset_set_data(cmbl_dataset* ds, const void* d, int B) {
+  return guard([&] { NOTNULL(ds); NOTNULL(d); CMBL_REQUIRE(B >= 1, ERR_SHAPE, "nbatch >= 1"); BY_DTYPE(ds->ctx, ds->f32->set_data(d, B), ds->f64->set_data(d, B)); });
+}
+int cmbl_dataset_set_logdet(cmbl_dataset* ds, double v) {
+  return guard([&] { NOTNULL(ds); BY_DTYPE(ds->ctx, ds->f32->logdet_sum = v, ds->f64->logdet_sum = v); });
+}
+
+int cmbl_gradientf_logpdf(cmbl_dataset* ds, cmbl_flow* L, const void* f, const void* d, int zero_d, void* out, int B) {
+  return guard([&] {
+    NOTNULL(ds); NOTNULL(L); NOTNULL(f); NOTNULL(out); CMBL_REQUIRE(B >= 1, ERR_SHAPE, "nbatch >= 1");
+    CMBL_REQUIRE(ds->ctx == L->ctx, ERR_ARG, "dataset and flow belong to different contexts");
+    BY_DTYPE(ds->ctx, do_gradf<float>(*ds->f32, *L->f32, f, d, zero_d, out, B), do_gradf<double>(*ds->f64, *L->f64, f, d, zero_d, out, B));
+  });
+}
+
+int cmbl_wiener_cg(cmbl_dataset* ds, cmbl_flow* L, const void* d, const void* fstart, double tol, int maxit, void* f_out,
+                   double* hist, int* nit, int B) {
+  return guard([&] {
+    NOTNULL(ds); NOTNULL(L); NOTNULL(f_out); NOTNULL(hist); NOTNULL(nit);
+    CMBL_REQUIRE(B >= 1 && maxit >= 1, ERR_ARG, "nbatch >= 1 and maxit >= 1");
+    CMBL_REQUIRE(ds->ctx == L->ctx, ERR_ARG, "dataset and flow belong to different contexts");
+    BY_DTYPE(ds->ctx, do_cg<float>(*ds->f32, *L->f32, d, fstart, tol, maxit, f_out, hist, nit, B),
+             do_cg<double>(*ds->f64, *L->f64, d, fstart, tol, maxit, f_out, hist, nit, B));
+  });
+}
+
+int cmbl_logpdf_mixed(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void* phio, double* lp, int B) {
+  return guard([&] {
+    NOTNULL(ds); NOTNULL(L); NOTNULL(fo); NOTNULL(phio); NOTNULL(lp); CMBL_REQUIRE(B >= 1, ERR_SHAPE, "nbatch >= 1");
+    CMBL_REQUIRE(ds->ctx == L->ctx, ERR_ARG, "dataset and flow belong to different contexts");
+    BY_DTYPE(ds->ctx, do_lpm<float>(*ds->f32, *L->f32, fo, phio, lp, nullptr, nullptr, B, 0), do_lpm<double>(*ds->f64, *L->f64, fo, phio, lp, nullptr, nullptr, B, 0));
+  });
+}
+int cmbl_grad_logpdf_mixed(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void* phio, double* lp, void* gfo, void* gphio, int B, int quirk) {
+  return guard([&] {
+    NOTNULL(ds); NOTNULL(L); NOTNULL(fo); NOTNULL(phio); NOTNULL(lp); NOTNULL(gfo); NOTNULL(gphio); CMBL_REQUIRE(B >= 1, ERR_SHAPE, "nbatch >= 1");
+    CMBL_REQUIRE(ds->ctx == L->ctx, ERR_ARG, "dataset and flow belong to different contexts");
+    BY_DTYPE(ds->ctx, do_lpm<float>(*ds->f32, *L->f32, fo, phio, lp, gfo, gphio, B, quirk), do_lpm<double>(*ds->f64, *L->f64, fo, phio, lp, gfo, gphio, B, quirk));
+  });
+}
+
+}  // extern "C"

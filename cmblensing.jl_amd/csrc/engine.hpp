@@ -1,0 +1,666 @@
+// Host-side engine: context (geometry, twiddles, launch geometry), layout/basis conversions, the LenseFlow
+// operator and the data-model / Wiener-filter / posterior drivers.  Everything below the C ABI (api.hip).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <memory>
+#include "kernels_fft.hpp"
+#include "kernels_pointwise.hpp"
+#include "kernels_flow.hpp"
+
+namespace cmbl {
+
+enum Basis { B_MAP = 0, B_FOURIER = 1, B_HARMONIC = 2 };
+enum FlowMode { F_FWD = 0, F_INV = 1, F_ADJ = 2, F_INVADJ = 3 };
+
+inline void raise_lds_limit(const void* fn, size_t bytes) {
+  static std::map<const void*, size_t> done;
+  if (bytes <= 48 * 1024) return;
+  auto it = done.find(fn);
+  if (it != done.end() && it->second >= bytes) return;
+  CMBL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done[fn] = bytes;
+}
+#define CMBL_LAUNCH(kernel, grid, lds, stream, ...)                                   \
+  do {                                                                                \
+    raise_lds_limit(reinterpret_cast<const void*>(kernel), (lds));                    \
+    hipLaunchKernelGGL(kernel, grid, dim3(NT), (lds), (stream), __VA_ARGS__);         \
+    CMBL_HIP(hipGetLastError());                                                      \
+  } while (0)
+
+struct CtxBase {
+  int Ny = 0, Nx = 0, Nyh = 0, M = 0, lgM = 0, lgNx = 0, dtype = 0, device = 0;
+  double theta = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::vector<double> h_lx, h_ly, h_lam, h_sin2, h_cos2, h_lmag;   // reference layout ([x][ky] planes)
+  virtual ~CtxBase() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+  long plane() const { return (long)Nyh * Nx; }
+  long npix() const { return (long)Ny * Nx; }
+};
+
+template <typename T>
+struct Ctx : CtxBase {
+  DevBuf twY, twX, lx_r, ly, lam, cos2F, sin2F, red_part, red_out;
+  DevBuf tmpA, tmpB;                       // conversion scratch (mixed/F complex)
+  static constexpr int RED_BLOCKS = 256;
+
+  Ctx(int Ny_, int Nx_, double theta_, int device_, void* stream_) {
+    Ny = Ny_; Nx = Nx_; theta = theta_; device = device_; dtype = sizeof(T) == 4 ? 0 : 1;
+    CMBL_REQUIRE(ispow2(Ny) && ispow2(Nx) && Ny >= 32 && Nx >= 32 && Ny <= 4096 && Nx <= 4096, ERR_SHAPE,
+                 "Ny and Nx must be powers of two in [32, 4096]");
+    CMBL_REQUIRE(theta > 0, ERR_ARG, "theta_pix must be positive");
+    Nyh = Ny / 2 + 1; M = Ny / 2; lgM = ilog2(M); lgNx = ilog2(Nx);
+    CMBL_HIP(hipSetDevice(device));
+    // NULL is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns when the caller has not
+    // switched streams): ordered against every other blocking stream, so caller-side copies and our kernels serialise.
+    stream = (hipStream_t)stream_; own_stream = false;
+    build_geometry();
+  }
+
+  // src/proj_lambert.jl:58-71 (computed in T like the reference, tables uploaded in the internal layouts)
+  void build_geometry() {
+    const T dx = (T)(theta / 60.0 * M_PI / 180.0);
+    const T dlx = (T)(2.0 * M_PI / (double)((T)Nx * dx));
+    const T dly = (T)(2.0 * M_PI / (double)((T)Ny * dx));
+    std::vector<T> lx(Nx), lyv(Nyh), lamv(Nyh, (T)2);
+    for (int i = 0; i < Nx; ++i) { int k = i < (Nx + 1) / 2 ? i : i - Nx; lx[i] = (T)k * dlx; }      // ifftshift(-N÷2:(N-1)÷2)
+    for (int i = 0; i < Nyh; ++i) { int k = i < (Ny + 1) / 2 ? i : i - Ny; lyv[i] = (T)k * dly; }     // last entry negative
+    lamv[0] = 1; lamv[Nyh - 1] = 1;                                                                    // even Ny (util_fft.jl:137-143)
+    std::vector<T> s2((size_t)Nx * Nyh), c2((size_t)Nx * Nyh), lm((size_t)Nx * Nyh);
+    for (int x = 0; x < Nx; ++x)
+      for (int k = 0; k < Nyh; ++k) {
+        const T ph = std::atan2(lyv[k], lx[x]);
+        s2[(size_t)x * Nyh + k] = std::sin(2 * ph);
+        c2[(size_t)x * Nyh + k] = std::cos(2 * ph);
+        lm[(size_t)x * Nyh + k] = std::sqrt(lx[x] * lx[x] + lyv[k] * lyv[k]);
+      }
+    // sin2ϕ[end, end:-1:(Nx÷2+2)] .= sin2ϕ[end, 2:Nx÷2]  (1-based; proj_lambert.jl:69-71)
+    for (int i = 0; i < Nx / 2 - 1; ++i) s2[(size_t)(Nx - 1 - i) * Nyh + (Nyh - 1)] = s2[(size_t)(1 + i) * Nyh + (Nyh - 1)];
+    h_lx.assign(lx.begin(), lx.end()); h_ly.assign(lyv.begin(), lyv.end()); h_lam.assign(lamv.begin(), lamv.end());
+    h_sin2.assign(s2.begin(), s2.end()); h_cos2.assign(c2.begin(), c2.end()); h_lmag.assign(lm.begin(), lm.end());
+    // internal tables
+    std::vector<T> lxr(Nx);
+    for (int i = 0; i < Nx; ++i) { unsigned r = 0; for (int b = 0; b < lgNx; ++b) r |= ((i >> b) & 1u) << (lgNx - 1 - b); lxr[i] = lx[r]; }
+    std::vector<T> s2F((size_t)Nx * Nyh), c2F((size_t)Nx * Nyh);
+    for (int k = 0; k < Nyh; ++k)
+      for (int i = 0; i < Nx; ++i) {
+        unsigned r = 0; for (int b = 0; b < lgNx; ++b) r |= ((i >> b) & 1u) << (lgNx - 1 - b);
+        s2F[(size_t)k * Nx + i] = s2[(size_t)r * Nyh + k];
+        c2F[(size_t)k * Nx + i] = c2[(size_t)r * Nyh + k];
+      }
+    std::vector<cx<T>> ty(M), tx(Nx / 2);
+    for (int k = 0; k < M; ++k) { double a = -2.0 * M_PI * k / Ny; ty[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
+    for (int k = 0; k < Nx / 2; ++k) { double a = -2.0 * M_PI * k / Nx; tx[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
+    upload(twY, ty); upload(twX, tx); upload(lx_r, lxr); upload(ly, lyv); upload(lam, lamv); upload(cos2F, c2F); upload(sin2F, s2F);
+    red_part.ensure(sizeof(double) * RED_BLOCKS * 64);
+    red_out.ensure(sizeof(double) * 64);
+  }
+  template <typename V> void upload(DevBuf& b, const std::vector<V>& v) {
+    b.ensure(v.size() * sizeof(V));
+    CMBL_HIP(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice, stream));
+    CMBL_HIP(hipStreamSynchronize(stream));
+  }
+
+  // ---- launch geometry -----------------------------------------------------------------------
+  // column kernels: C columns per workgroup.  Fused kernels need C*M == R*NT with R in {1,..,32}.
+  int pickC(long slices, bool fused) const {
+    int C = sizeof(T) == 4 ? 8 : 4;
+    while (C > 4 && (long)(Nx / C) * slices < 512) C >>= 1;            // keep >= 2 workgroups per CU when possible
+    if (fused) {
+      while ((long)C * M < NT) C <<= 1;                                 // R >= 1
+      while ((long)C * M > 32L * NT && C > 1) C >>= 1;                  // R <= 32
+    }
+    while (C > Nx) C >>= 1;
+    const size_t lds = ((size_t)M + (size_t)C * (M + 1)) * sizeof(cx<T>);
+    CMBL_REQUIRE(lds <= 160 * 1024, ERR_SHAPE, "column tile does not fit LDS");
+    return C;
+  }
+  size_t ldsY(int C) const { return ((size_t)M + (size_t)C * (M + 1)) * sizeof(cx<T>); }
+  int pickRX(int nbuf) const {
+    const int RX = std::max(1, (int)(4096 / ((long)nbuf * Nx)));
+    CMBL_REQUIRE(ldsX(RX, nbuf) <= 160 * 1024, ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
+    return RX;
+  }
+  size_t ldsX(int RX, int nbuf) const { return ((size_t)Nx / 2 + (size_t)nbuf * RX * Nx) * sizeof(cx<T>); }
+
+  // ---- layout / transform primitives (all on `stream`) -----------------------------------------
+  void ref2F(const cx<T>* in, cx<T>* out, long slices) {
+    CMBL_LAUNCH((k_ref2F<cx<T>>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
+  }
+  void F2ref(const cx<T>* in, cx<T>* out, long slices) {
+    CMBL_LAUNCH((k_F2ref<cx<T>>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
+  }
+  void ref2F_real(const T* in, T* out, long slices) {
+    CMBL_LAUNCH((k_ref2F<T>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
+  }
+  void y_r2c(const T* map, cx<T>* mixed, long slices) {
+    const int C = pickC(slices, false);
+    CMBL_LAUNCH((k_y_r2c<T>), dim3(Nx / C, (unsigned)slices), ldsY(C), stream, map, mixed, twY.as<cx<T>>(), Nx, lgM, C, ilog2(C));
+  }
+  void y_c2r(const cx<T>* mixed, T* map, long slices) {
+    const int C = pickC(slices, false);
+    CMBL_LAUNCH((k_y_c2r<T>), dim3(Nx / C, (unsigned)slices), ldsY(C), stream, mixed, map, twY.as<cx<T>>(), Nx, lgM, C, ilog2(C),
+                (T)(1.0 / Ny));
+  }
+  template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices) {
+    const long rows = slices * Nyh;
+    const int RX = pickRX(1);
+    CMBL_LAUNCH((k_x_fft<T, MODE>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), stream, in, out, twX.as<cx<T>>(),
+                lx_r.as<T>(), lgNx, rows, RX);
+  }
+  // map -> F  (m_rfft, src/util_fft.jl:20)
+  void rfft2_F(const T* map, cx<T>* F, long slices) { y_r2c(map, F, slices); x_pass<0>(F, F, slices); }
+  // F -> map  (m_irfft, src/util_fft.jl:21-25); `scratch` (slices*plane) receives the x-inverse unless F may be clobbered
+  void irfft2_F(const cx<T>* F, T* map, long slices, cx<T>* scratch) { x_pass<1>(F, scratch, slices); y_c2r(scratch, map, slices); }
+
+  // harmonic-operator application (see k_harm_apply)
+  void harm(const cx<T>* in, cx<T>* out, int P, int B, int kind, const T* const* d, bool transpose, bool in_qu, bool out_qu,
+            const cx<T>* z = nullptr, T alpha = 0, T beta = 1) {
+    HarmOpArgs<T> a{};
+    a.in = in; a.out = out; a.z = z; a.cos2 = cos2F.as<T>(); a.sin2 = sin2F.as<T>();
+    for (int k = 0; k < 5; ++k) a.d[k] = d ? d[k] : nullptr;
+    a.kind = kind; a.in_qu = in_qu; a.out_qu = out_qu; a.transpose = transpose; a.alpha = alpha; a.beta = beta;
+    a.plane = plane(); a.B = B;
+    const dim3 grid((unsigned)((plane() + NT - 1) / NT));
+    if (P == 1) CMBL_LAUNCH((k_harm_apply<T, 1>), grid, 0, stream, a);
+    else if (P == 2) CMBL_LAUNCH((k_harm_apply<T, 2>), grid, 0, stream, a);
+    else CMBL_LAUNCH((k_harm_apply<T, 3>), grid, 0, stream, a);
+  }
+
+  // out = a*x + c*y with per-batch scalars (n = reals per batch slot)
+  void lincomb(T* out, const T* x, const T* y, const double* a, const double* c, long n, int B) {
+    for (int b0 = 0; b0 < B; b0 += MAXB) {
+      const int nb = std::min(MAXB, B - b0);
+      BScal<T> sa{}, sc{};
+      for (int i = 0; i < nb; ++i) { sa.v[i] = (T)a[b0 + i]; sc.v[i] = c ? (T)c[b0 + i] : (T)0; }
+      const unsigned gx = (unsigned)std::min<long>((n + NT - 1) / NT, 2048);
+      CMBL_LAUNCH((k_lincomb<T>), dim3(gx, nb), 0, stream, out, x, y, sa, sc, n, b0);
+    }
+  }
+  void lincomb1(T* out, const T* x, const T* y, double a, double c, long n, int B) {
+    std::vector<double> va(B, a), vc(B, c);
+    lincomb(out, x, y, va.data(), vc.data(), n, B);
+  }
+  void mask_mul(T* out, const T* in, const T* m, long slices) {
+    const unsigned gx = (unsigned)std::min<long>((npix() + NT - 1) / NT, 2048);
+    CMBL_LAUNCH((k_mask_mul<T>), dim3(gx, (unsigned)slices), 0, stream, out, in, m, npix());
+  }
+
+  // per-batch reductions -> host doubles (synchronises the stream)
+  void finish_reduce(int B, double scale, double* out_host) {
+    CMBL_LAUNCH(k_reduce_final, dim3(B), 0, stream, red_part.as<double>(), red_out.as<double>(), RED_BLOCKS, scale);
+    CMBL_HIP(hipMemcpyAsync(out_host, red_out.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream));
+    CMBL_HIP(hipStreamSynchronize(stream));
+  }
+  void dot_F(const cx<T>* a, const cx<T>* b, int P, int B, double* out_host) {
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    CMBL_LAUNCH((k_dot_F<T>), dim3(RED_BLOCKS, B), 0, stream, a, b, lam.as<T>(), red_part.as<double>(), (long)P * plane(), lgNx, Nyh);
+    finish_reduce(B, 1.0 / ((double)Ny * Nx), out_host);
+  }
+  void dot_map(const T* a, const T* b, int P, int B, double* out_host) {
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    CMBL_LAUNCH((k_dot_map<T>), dim3(RED_BLOCKS, B), 0, stream, a, b, red_part.as<double>(), (long)P * npix());
+    finish_reduce(B, 1.0, out_host);
+  }
+  void logdet_F(const T* d, int nplanes, double* out_host) {
+    CMBL_LAUNCH((k_logdet_F<T>), dim3(RED_BLOCKS, 1), 0, stream, d, lam.as<T>(), red_part.as<double>(), (long)nplanes * plane(), lgNx, Nyh);
+    finish_reduce(1, 1.0, out_host);
+  }
+
+  // ---- basis conversion between reference-layout arrays and the internal F layout ----------------
+  // to F: out_F is (P*B*plane) complex in `want` (B_FOURIER = QU Fourier, B_HARMONIC = EB Fourier)
+  void to_F(int basis_in, const void* in, cx<T>* out_F, int want, int P, int B) {
+    const long slices = (long)P * B;
+    if (basis_in == B_MAP) rfft2_F((const T*)in, out_F, slices);
+    else ref2F((const cx<T>*)in, out_F, slices);
+    const bool have_h = (basis_in == B_HARMONIC), want_h = (want == B_HARMONIC);
+    if (P >= 2 && have_h != want_h) harm(out_F, out_F, P, B, 0, nullptr, false, !have_h, !want_h);
+  }
+  // from F (in `have` basis) to a reference-layout array; clobbers in_F
+  void from_F(cx<T>* in_F, int have, int basis_out, void* out, int P, int B) {
+    const long slices = (long)P * B;
+    const bool have_h = (have == B_HARMONIC), want_h = (basis_out == B_HARMONIC);
+    if (P >= 2 && have_h != want_h) harm(in_F, in_F, P, B, 0, nullptr, false, !have_h, !want_h);
+    if (basis_out == B_MAP) { x_pass<1>(in_F, in_F, slices); y_c2r(in_F, (T*)out, slices); }
+    else F2ref(in_F, (cx<T>*)out, slices);
+  }
+};
+
+// =================================================================================================
+// LenseFlow operator  (src/lenseflow.jl, src/flowops.jl)
+template <typename T>
+struct Flow {
+  Ctx<T>* c;
+  int n;                                  // RK4 steps (src/lenseflow.jl:29 default 7)
+  int Bphi = 0;
+  DevBuf phimaps;                         // [5][Bphi][Nx][Ny] : gx, gy, Hxx, Hyx, Hyy
+  DevBuf phiF, gh;                        // scratch for precompute
+  DevBuf A, A2, Gx, y0, acc;              // forward flow state          (slices)
+  DevBuf H, Wx, Wy, Y0, Yacc;             // adjoint flow state          (slices)
+  DevBuf w1p, w2p, Z0, Z1, Z2, P0, Pacc;  // delta flow extras
+  DevBuf cvt;                             // boundary conversion scratch
+
+  Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) { CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range"); }
+
+  PhiMaps<T> ph() const {
+    const size_t s = (size_t)Bphi * c->npix();
+    const T* b = phimaps.as<T>();
+    return PhiMaps<T>{b, b + s, b + 2 * s, b + 3 * s, b + 4 * s, Bphi};
+  }
+
+  // precompute! (src/lenseflow.jl:131-142): gradhess(phi) -> five maps; p(t), M^-1(t) are formed on the fly
+  void set_phi_F(const cx<T>* phi_F, int nb) {
+    Bphi = nb;
+    const long pl = c->plane();
+    gh.ensure(sizeof(cx<T>) * 5 * nb * pl);
+    phimaps.ensure(sizeof(T) * 5 * nb * c->npix());
+    // multipliers: out[comp][b][plane]
+    CMBL_LAUNCH((k_gradhess_mult<T>), dim3((unsigned)((pl + NT - 1) / NT)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
+                c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
+    c->template x_pass<1>(gh.as<cx<T>>(), gh.as<cx<T>>(), 5L * nb);
+    c->y_c2r(gh.as<cx<T>>(), phimaps.as<T>(), 5L * nb);
+  }
+  void set_phi(int basis, const void* phi, int nb) {
+    CMBL_REQUIRE(basis == B_MAP || basis == B_FOURIER || basis == B_HARMONIC, ERR_ARG, "bad basis");
+    phiF.ensure(sizeof(cx<T>) * nb * c->plane());
+    c->to_F(basis, phi, phiF.as<cx<T>>(), B_FOURIER, 1, nb);
+    set_phi_F(phiF.as<cx<T>>(), nb);
+  }
+
+  RKCoef<T> coef(int step, int stage, double t0, double h, bool last) const {
+    // stage times t, t+h/2, t+h/2, t+h on the 2n+1 grid (src/numerical_algorithms.jl:15-19, src/lenseflow.jl:78)
+    const double ts = t0 + step * h + (stage == 1 ? 0 : (stage == 4 ? h : h / 2));
+    const int kidx = (int)std::lround(ts * 2 * n);
+    RKCoef<T> r;
+    r.t = (T)kidx / (T)(2 * n);
+    r.cnext = (T)(stage <= 2 ? h / 2 : h);
+    r.h6 = (T)(h / 6);
+    r.stage = stage; r.last = last ? 1 : 0;
+    return r;
+  }
+
+  template <int R> void launch_fwd_y(const FlowYArgs<T>& a, long slices, int C) {
+    CMBL_LAUNCH((k_flow_y_fwd<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
+  }
+  template <int R> void launch_adj_y(const AdjYArgs<T>& a, long slices, int C) {
+    CMBL_LAUNCH((k_adj_y<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
+  }
+  template <int R> void launch_delta_y(const DeltaYArgs<T>& a, long slices, int C) {
+    CMBL_LAUNCH((k_delta_y<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
+  }
+  template <int R> void launch_dphi_y(const DphiYArgs<T>& a, long B, int C) {
+    CMBL_LAUNCH((k_dphi_y<T, R>), dim3(c->Nx / C, (unsigned)B), c->ldsY(C), c->stream, a);
+  }
+#define CMBL_DISPATCH_R(R, fn, ...)                                                      \
+  switch (R) {                                                                          \
+    case 1: fn<1>(__VA_ARGS__); break;  case 2: fn<2>(__VA_ARGS__); break;                \
+    case 4: fn<4>(__VA_ARGS__); break;  case 8: fn<8>(__VA_ARGS__); break;                \
+    case 16: fn<16>(__VA_ARGS__); break; case 32: fn<32>(__VA_ARGS__); break;             \
+    default: fail(ERR_SHAPE, "unsupported tile shape");                                  \
+  }
+
+  void check_ready(int B) const {
+    CMBL_REQUIRE(Bphi >= 1, ERR_STATE, "cmbl_lenseflow_set_phi has not been called");
+    CMBL_REQUIRE(Bphi == 1 || Bphi == B, ERR_SHAPE, "nbatch of phi must be 1 or equal to nbatch of f");
+  }
+
+  // L*f (inverse=false) or L\f (inverse=true) on maps; out may alias in
+  void flow_map(const T* in, T* out, int P, int B, bool inverse) {
+    check_ready(B);
+    const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    A.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
+    acc.ensure(sizeof(T) * slices * np);
+    T* y = out;
+    if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
+    cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
+    c->y_r2c(y, a_cur, slices);
+    const int C = c->pickC(slices, true), R = C * c->M / NT;
+    const double t0 = inverse ? 1.0 : 0.0, h = (inverse ? -1.0 : 1.0) / n;
+    for (int step = 0; step < n; ++step)
+      for (int stage = 1; stage <= 4; ++stage) {
+        c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);
+        FlowYArgs<T> a{};
+        a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = y; a.acc = acc.as<T>(); a.ph = ph();
+        a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
+        a.Nx = c->Nx; a.lgM = c->lgM; a.C = C; a.lgC = ilog2(C); a.P = P;
+        a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
+        CMBL_DISPATCH_R(R, launch_fwd_y, a, slices, C);
+        std::swap(a_cur, a_nxt);
+      }
+  }
+
+  // L'*g (inverse=false, t 1->0) or L'\g (inverse=true, t 0->1); F layout, QU-Fourier basis; out may alias in
+  void flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse) {
+    check_ready(B);
+    const long slices = (long)P * B, pl = c->plane();
+    H.ensure(sizeof(cx<T>) * slices * pl); Wx.ensure(sizeof(cx<T>) * slices * pl); Wy.ensure(sizeof(cx<T>) * slices * pl);
+    Yacc.ensure(sizeof(cx<T>) * slices * pl);
+    if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
+    c->template x_pass<1>(out, H.as<cx<T>>(), slices);
+    const int C = c->pickC(slices, true), R = C * c->M / NT;
+    const int RX = c->pickRX(2);
+    const long rows = slices * c->Nyh;
+    const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
+    for (int step = 0; step < n; ++step)
+      for (int stage = 1; stage <= 4; ++stage) {
+        const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
+        AdjYArgs<T> a{};
+        a.H = H.as<cx<T>>(); a.Wx = Wx.as<cx<T>>(); a.Wy = Wy.as<cx<T>>(); a.ph = ph();
+        a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
+        a.Nx = c->Nx; a.lgM = c->lgM; a.C = C; a.lgC = ilog2(C); a.P = P; a.t = rk.t;
+        CMBL_DISPATCH_R(R, launch_adj_y, a, slices, C);
+        AdjXArgs<T> x{};
+        x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = out; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
+        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.lgNx = c->lgNx; x.RX = RX; x.rows = rows; x.rk = rk;
+        CMBL_LAUNCH((k_adj_x<T>), dim3((unsigned)((rows + RX - 1) / RX)), c->ldsX(RX, 2), c->stream, x);
+      }
+  }
+
+  // delta flow (src/flowops.jl:48,63): state (f [map], df [F, QU-Fourier], dphi [F, S0]); all updated in place.
+  // forward_primal=true : pullback of L*f  -> integrate t 1->0;  false: pullback of L\f -> t 0->1.
+  void flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
+    check_ready(B);
+    const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    A.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
+    acc.ensure(sizeof(T) * slices * np);
+    H.ensure(sizeof(cx<T>) * slices * pl); Wx.ensure(sizeof(cx<T>) * slices * pl); Wy.ensure(sizeof(cx<T>) * slices * pl);
+    Yacc.ensure(sizeof(cx<T>) * slices * pl);
+    w1p.ensure(sizeof(T) * slices * np); w2p.ensure(sizeof(T) * slices * np);
+    Z0.ensure(sizeof(cx<T>) * B * pl); Z1.ensure(sizeof(cx<T>) * B * pl); Z2.ensure(sizeof(cx<T>) * B * pl);
+    Pacc.ensure(sizeof(cx<T>) * B * pl);
+    CMBL_HIP(hipMemsetAsync(dphi, 0, sizeof(cx<T>) * B * pl, c->stream));
+    cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
+    c->y_r2c(f, a_cur, slices);
+    c->template x_pass<1>(df, H.as<cx<T>>(), slices);
+    const int C = c->pickC(slices, true), R = C * c->M / NT;
+    const int Cp = c->pickC(B, true), Rp = Cp * c->M / NT;
+    const int RX2 = c->pickRX(2), RX3 = c->pickRX(3);
+    const long rows = slices * c->Nyh, rowsp = (long)B * c->Nyh;
+    const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
+    for (int step = 0; step < n; ++step)
+      for (int stage = 1; stage <= 4; ++stage) {
+        const bool last = step == n - 1 && stage == 4;
+        const RKCoef<T> rk = coef(step, stage, t0, h, last);
+        c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);
+        DeltaYArgs<T> d{};
+        FlowYArgs<T>& a = d.f;
+        a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = f; a.acc = acc.as<T>(); a.ph = ph();
+        a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
+        a.Nx = c->Nx; a.lgM = c->lgM; a.C = C; a.lgC = ilog2(C); a.P = P; a.rk = rk;
+        d.H = H.as<cx<T>>(); d.Wx = Wx.as<cx<T>>(); d.Wy = Wy.as<cx<T>>(); d.w1p = w1p.as<T>(); d.w2p = w2p.as<T>();
+        CMBL_DISPATCH_R(R, launch_delta_y, d, slices, C);
+        std::swap(a_cur, a_nxt);
+        // delta-f row pass (RK update of df + next H)
+        AdjXArgs<T> x{};
+        x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
+        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.lgNx = c->lgNx; x.RX = RX2; x.rows = rows; x.rk = rk;
+        CMBL_LAUNCH((k_adj_x<T>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
+        // delta-phi
+        DphiYArgs<T> py{};
+        py.w1p = w1p.as<T>(); py.w2p = w2p.as<T>(); py.Z0 = Z0.as<cx<T>>(); py.Z1 = Z1.as<cx<T>>(); py.Z2 = Z2.as<cx<T>>();
+        py.ph = ph(); py.twY = a.twY; py.ly = a.ly; py.Nx = c->Nx; py.lgM = c->lgM; py.C = Cp; py.lgC = ilog2(Cp); py.P = P;
+        py.alias_quirk = alias_quirk ? 1 : 0; py.t = rk.t;
+        CMBL_DISPATCH_R(Rp, launch_dphi_y, py, B, Cp);
+        DphiXArgs<T> px{};
+        px.Z0 = Z0.as<cx<T>>(); px.Z1 = Z1.as<cx<T>>(); px.Z2 = Z2.as<cx<T>>(); px.Y0 = dphi; px.acc = Pacc.as<cx<T>>();
+        px.twX = x.twX; px.lx_r = x.lx_r; px.lgNx = c->lgNx; px.RX = RX3; px.rows = rowsp; px.rk = rk;
+        CMBL_LAUNCH((k_dphi_x<T>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), c->stream, px);
+      }
+  }
+
+  // ---- boundary-level entry points ---------------------------------------------------------------
+  void apply(int mode, int basis_in, const void* in, int basis_out, void* out, int P, int B) {
+    const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    if (mode == F_FWD || mode == F_INV) {
+      y0.ensure(sizeof(T) * slices * np);
+      T* y = (basis_out == B_MAP) ? (T*)out : y0.as<T>();
+      if (basis_in == B_MAP) flow_map((const T*)in, y, P, B, mode == F_INV);
+      else {
+        cvt.ensure(sizeof(cx<T>) * slices * pl);
+        c->ref2F((const cx<T>*)in, cvt.as<cx<T>>(), slices);
+        c->from_F(cvt.as<cx<T>>(), basis_in, B_MAP, y, P, B);
+        flow_map(y, y, P, B, mode == F_INV);
+      }
+      if (basis_out != B_MAP) {
+        cvt.ensure(sizeof(cx<T>) * slices * pl);
+        c->to_F(B_MAP, y, cvt.as<cx<T>>(), basis_out, P, B);
+        c->F2ref(cvt.as<cx<T>>(), (cx<T>*)out, slices);
+      }
+    } else {
+      Y0.ensure(sizeof(cx<T>) * slices * pl);
+      c->to_F(basis_in, in, Y0.as<cx<T>>(), B_FOURIER, P, B);
+      flow_adj_F(Y0.as<cx<T>>(), Y0.as<cx<T>>(), P, B, mode == F_INVADJ);
+      c->from_F(Y0.as<cx<T>>(), B_FOURIER, basis_out, out, P, B);
+    }
+  }
+
+  void grad(int mode, const void* f_end, int basis_delta, const void* delta, void* dphi_out, int basis_df, void* df_out,
+            void* f_start_out, int P, int B, bool quirk) {
+    const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    y0.ensure(sizeof(T) * slices * np); Y0.ensure(sizeof(cx<T>) * slices * pl); P0.ensure(sizeof(cx<T>) * B * pl);
+    T* f = f_start_out ? (T*)f_start_out : y0.as<T>();
+    CMBL_HIP(hipMemcpyAsync(f, f_end, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
+    c->to_F(basis_delta, delta, Y0.as<cx<T>>(), B_FOURIER, P, B);
+    flow_delta(f, Y0.as<cx<T>>(), P0.as<cx<T>>(), P, B, mode == F_FWD, quirk);
+    c->from_F(Y0.as<cx<T>>(), B_FOURIER, basis_df, df_out, P, B);
+    c->F2ref(P0.as<cx<T>>(), (cx<T>*)dphi_out, B);
+  }
+};
+
+// =================================================================================================
+// Data model, Wiener filter, posterior   (src/dataset.jl, src/maximization.jl, src/numerical_algorithms.jl)
+enum OpId { OP_CF_INV = 0, OP_CN_INV, OP_B, OP_MF, OP_D, OP_D_INV, OP_PRECOND_INV, OP_CPHI_INV, OP_G_INV, OP_MPIX, OP_COUNT };
+
+template <typename T>
+struct Dataset {
+  Ctx<T>* c;
+  int P;
+  struct Op { DevBuf buf; int nplanes = 0; const T* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int kind = 0; };
+  Op ops[OP_COUNT];
+  DevBuf d_h; int Bd = 0;                  // data, F layout harmonic
+  double logdet_sum = 0;
+  // scratch
+  DevBuf t1, t2, t3, mp, mp2, xs, rs, zs, ps, aps, best, bb, phiF, gphi, dphi1, dphi2, fh, fhat, ftil, cvt;
+
+  Dataset(Ctx<T>* ctx, int npol) : c(ctx), P(npol) { CMBL_REQUIRE(npol >= 1 && npol <= 3, ERR_ARG, "npol must be 1, 2 or 3"); }
+
+  void set_op(int which, const void* planes, int nplanes) {
+    CMBL_REQUIRE(which >= 0 && which < OP_COUNT, ERR_ARG, "bad operator id");
+    Op& o = ops[which];
+    if (which == OP_MPIX) {
+      CMBL_REQUIRE(nplanes == 1, ERR_ARG, "pixel mask is one map");
+      o.buf.ensure(sizeof(T) * c->npix());
+      CMBL_HIP(hipMemcpyAsync(o.buf.p, planes, sizeof(T) * c->npix(), hipMemcpyDeviceToDevice, c->stream));
+      o.nplanes = 1; o.d[0] = o.buf.template as<T>(); o.kind = 1;
+      return;
+    }
+    const bool s0 = (which == OP_CPHI_INV || which == OP_G_INV);
+    CMBL_REQUIRE(s0 ? nplanes == 1 : (nplanes == P || (P == 3 && nplanes == 5)), ERR_SHAPE, "wrong number of planes for this operator");
+    o.buf.ensure(sizeof(T) * nplanes * c->plane());
+    c->ref2F_real((const T*)planes, o.buf.template as<T>(), nplanes);
+    o.nplanes = nplanes; o.kind = (nplanes == 5) ? 2 : 1;
+    for (int k = 0; k < 5; ++k) o.d[k] = k < nplanes ? o.buf.template as<T>() + (size_t)k * c->plane() : nullptr;
+  }
+  const Op& op(int which) const {
+    CMBL_REQUIRE(ops[which].nplanes > 0, ERR_STATE, "a required dataset operator has not been set");
+    return ops[which];
+  }
+  bool has(int which) const { return ops[which].nplanes > 0; }
+  void apply(int which, const cx<T>* in, cx<T>* out, int B, bool transpose = false, bool in_qu = false, bool out_qu = false,
+             const cx<T>* z = nullptr, T alpha = 0, T beta = 1, int Pp = -1) {
+    const Op& o = op(which);
+    c->harm(in, out, Pp < 0 ? P : Pp, B, o.kind, o.d, transpose, in_qu, out_qu, z, alpha, beta);
+  }
+  void set_data(const void* d_ref, int B) {
+    d_h.ensure(sizeof(cx<T>) * (long)P * B * c->plane());
+    c->ref2F((const cx<T>*)d_ref, d_h.template as<cx<T>>(), (long)P * B);
+    Bd = B;
+  }
+  long fsize(int B) const { return (long)P * B * c->plane(); }
+
+  // x (harmonic F) -> M x = Mf * (Mpix * x) ; transpose: Mpix' * (Mf' * x)   (src/dataset.jl:279-285)
+  void apply_M(cx<T>* x, int B, bool transpose) {
+    const long sl = (long)P * B;
+    if (!has(OP_MPIX)) { apply(OP_MF, x, x, B, transpose); return; }
+    mp.ensure(sizeof(T) * sl * c->npix());
+    if (!transpose) {
+      c->harm(x, x, P, B, 0, nullptr, false, false, true);                 // -> QU Fourier
+      c->template x_pass<1>(x, x, sl); c->y_c2r(x, mp.template as<T>(), sl);
+      c->mask_mul(mp.template as<T>(), mp.template as<T>(), ops[OP_MPIX].d[0], sl);
+      c->rfft2_F(mp.template as<T>(), x, sl);
+      apply(OP_MF, x, x, B, false, true, false);
+    } else {
+      apply(OP_MF, x, x, B, true, false, true);
+      c->template x_pass<1>(x, x, sl); c->y_c2r(x, mp.template as<T>(), sl);
+      c->mask_mul(mp.template as<T>(), mp.template as<T>(), ops[OP_MPIX].d[0], sl);
+      c->rfft2_F(mp.template as<T>(), x, sl);
+      c->harm(x, x, P, B, 0, nullptr, false, true, false);
+    }
+  }
+
+  // mu = M B L f : harmonic F in (f may be nullptr == 0) -> harmonic F out (t2); uses mp2 for maps
+  void mean(Flow<T>& L, const cx<T>* f_h, cx<T>* out, int B) {
+    const long sl = (long)P * B;
+    mp2.ensure(sizeof(T) * sl * c->npix());
+    c->harm(f_h, out, P, B, 0, nullptr, false, false, true);
+    c->template x_pass<1>(out, out, sl); c->y_c2r(out, mp2.template as<T>(), sl);
+    L.flow_map(mp2.template as<T>(), mp2.template as<T>(), P, B, false);
+    c->rfft2_F(mp2.template as<T>(), out, sl);
+    apply(OP_B, out, out, B, false, true, false);
+    apply_M(out, B, false);
+  }
+
+  // gradientf_logpdf (src/dataset.jl:76-80): L'B'M'Cn^-1 (d - M B L f) - Cf^-1 f.  f_h == nullptr means f = 0;
+  // d_h == nullptr means d = 0.  All harmonic F layout.  out must not alias f_h.
+  void gradientf(Flow<T>& L, const cx<T>* f_h, const cx<T>* dd, cx<T>* out, int B) {
+    const long n = fsize(B);
+    t2.ensure(sizeof(cx<T>) * n);
+    cx<T>* r = t2.template as<cx<T>>();
+    if (f_h) {
+      mean(L, f_h, r, B);
+      if (dd) c->lincomb1((T*)r, (const T*)dd, (const T*)r, 1.0, -1.0, 2 * n / B, B);
+      else c->lincomb1((T*)r, (const T*)r, nullptr, -1.0, 0.0, 2 * n / B, B);
+    } else {
+      CMBL_REQUIRE(dd != nullptr, ERR_ARG, "gradientf with f = 0 and d = 0 is identically zero");
+      CMBL_HIP(hipMemcpyAsync(r, dd, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    apply(OP_CN_INV, r, r, B);
+    apply_M(r, B, true);
+    apply(OP_B, r, r, B, true, false, true);                               // -> QU Fourier
+    L.flow_adj_F(r, r, P, B, false);
+    if (f_h) {
+      c->harm(r, r, P, B, 0, nullptr, false, true, false);                 // -> harmonic
+      apply(OP_CF_INV, f_h, out, B, false, false, false, r, (T)1, (T)-1);  // out = r - Cf^-1 f
+    } else {
+      c->harm(r, out, P, B, 0, nullptr, false, true, false);
+    }
+  }
+
+  // conjugate_gradient (src/numerical_algorithms.jl:73-134) driving argmaxf_logpdf (src/maximization.jl:17-42).
+  // a0 = gradientf(f=0,d=0) is identically zero for this linear model (all operators finite), so it is not evaluated.
+  int wiener_cg(Flow<T>& L, const cx<T>* dd, const cx<T>* fstart, double tol, int maxit, cx<T>* f_out, double* hist, int B) {
+    const long n = fsize(B), nr = 2 * n / B;
+    xs.ensure(sizeof(cx<T>) * n); rs.ensure(sizeof(cx<T>) * n); zs.ensure(sizeof(cx<T>) * n); ps.ensure(sizeof(cx<T>) * n);
+    aps.ensure(sizeof(cx<T>) * n); best.ensure(sizeof(cx<T>) * n); bb.ensure(sizeof(cx<T>) * n);
+    cx<T>*x = xs.template as<cx<T>>(), *r = rs.template as<cx<T>>(), *z = zs.template as<cx<T>>(), *p = ps.template as<cx<T>>();
+    cx<T>*Ap = aps.template as<cx<T>>(), *bx = best.template as<cx<T>>(), *b = bb.template as<cx<T>>();
+    std::vector<double> res(B), res2(B), pAp(B), bestres(B), al(B), be(B), one(B, 1.0), mone(B, -1.0);
+    // b = -gradientf(f=0, d) = -L'B'M'Cn^-1 d
+    gradientf(L, nullptr, dd, b, B);
+    c->lincomb((T*)b, (T*)b, nullptr, mone.data(), nullptr, nr, B);
+    if (fstart) {
+      CMBL_HIP(hipMemcpyAsync(x, fstart, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+      gradientf(L, x, nullptr, Ap, B);                                      // A x
+      c->lincomb((T*)r, (T*)b, (T*)Ap, one.data(), mone.data(), nr, B);     // r = b - A x
+    } else {
+      CMBL_HIP(hipMemsetAsync(x, 0, sizeof(cx<T>) * n, c->stream));
+      CMBL_HIP(hipMemcpyAsync(r, b, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    apply(OP_PRECOND_INV, r, z, B);
+    CMBL_HIP(hipMemcpyAsync(p, z, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+    c->dot_F(r, z, P, B, res.data());
+    for (int i = 0; i < B; ++i) CMBL_REQUIRE(!std::isnan(res[i]), ERR_NAN, "NaN residual in conjugate gradient");
+    bestres = res;
+    CMBL_HIP(hipMemcpyAsync(bx, x, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+    int nh = 0;
+    for (int i = 0; i < B; ++i) hist[(size_t)nh * B + i] = res[i];
+    ++nh;
+    for (int it = 2; it <= maxit; ++it) {
+      gradientf(L, p, nullptr, Ap, B);
+      c->dot_F(p, Ap, P, B, pAp.data());
+      for (int i = 0; i < B; ++i) { al[i] = res[i] / pAp[i]; be[i] = -al[i]; }
+      c->lincomb((T*)x, (T*)x, (T*)p, one.data(), al.data(), nr, B);
+      c->lincomb((T*)r, (T*)r, (T*)Ap, one.data(), be.data(), nr, B);
+      apply(OP_PRECOND_INV, r, z, B);
+      c->dot_F(r, z, P, B, res2.data());
+      for (int i = 0; i < B; ++i) { CMBL_REQUIRE(!std::isnan(res2[i]), ERR_NAN, "NaN residual in conjugate gradient"); be[i] = res2[i] / res[i]; }
+      c->lincomb((T*)p, (T*)z, (T*)p, one.data(), be.data(), nr, B);
+      res = res2;
+      bool better = true, done = true;
+      for (int i = 0; i < B; ++i) { better = better && (res[i] < bestres[i]); done = done && (res[i] < tol); }
+      if (better) { bestres = res; CMBL_HIP(hipMemcpyAsync(bx, x, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream)); }
+      for (int i = 0; i < B; ++i) hist[(size_t)nh * B + i] = res[i];
+      ++nh;
+      if (done) break;
+    }
+    CMBL_HIP(hipMemcpyAsync(f_out, bx, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+    return nh;
+  }
+
+  // logpdf(Mixed(ds); f°, phi°) and optionally its gradient.  fo: map (reference layout == internal), phio: F layout S0.
+  // gfo (map) / gphio (F) may be nullptr for value only.
+  void logpdf_mixed(Flow<T>& L, const T* fo, const cx<T>* phio_F, double* lp, T* gfo, cx<T>* gphio_F, int B, bool quirk) {
+    CMBL_REQUIRE(Bd == B, ERR_SHAPE, "dataset data batch size differs from nbatch");
+    const long sl = (long)P * B, n = fsize(B), np = c->npix(), pl = c->plane();
+    phiF.ensure(sizeof(cx<T>) * B * pl); fhat.ensure(sizeof(T) * sl * np); ftil.ensure(sizeof(T) * sl * np);
+    fh.ensure(sizeof(cx<T>) * n); t1.ensure(sizeof(cx<T>) * n); t3.ensure(sizeof(cx<T>) * n);
+    gphi.ensure(sizeof(cx<T>) * B * pl); dphi1.ensure(sizeof(cx<T>) * B * pl); dphi2.ensure(sizeof(cx<T>) * B * pl);
+    cx<T>*phi = phiF.template as<cx<T>>(), *f_h = fh.template as<cx<T>>(), *z = t1.template as<cx<T>>(), *w = t3.template as<cx<T>>();
+    // phi = G \ phi°
+    apply(OP_G_INV, phio_F, phi, B, false, false, false, nullptr, 0, 1, 1);
+    L.set_phi_F(phi, B);
+    // fhat = L \ f° ; f = D \ fhat
+    L.flow_map(fo, fhat.template as<T>(), P, B, true);
+    c->rfft2_F(fhat.template as<T>(), f_h, sl);
+    apply(OP_D_INV, f_h, f_h, B, false, true, false);
+    // z = M B L f - d
+    mean(L, f_h, z, B);                                                   // leaves f~ = L f in mp2
+    CMBL_HIP(hipMemcpyAsync(ftil.p, mp2.p, sizeof(T) * sl * np, hipMemcpyDeviceToDevice, c->stream));
+    c->lincomb1((T*)z, (const T*)z, (const T*)d_h.p, 1.0, -1.0, 2 * n / B, B);
+    // quadratic forms
+    std::vector<double> q1(B), q2(B), q3(B);
+    apply(OP_CN_INV, z, w, B);                c->dot_F(z, w, P, B, q3.data());          // w = Cn^-1 z  (kept)
+    cx<T>* cfif = t2.template as<cx<T>>(); t2.ensure(sizeof(cx<T>) * n); cfif = t2.template as<cx<T>>();
+    apply(OP_CF_INV, f_h, cfif, B);           c->dot_F(f_h, cfif, P, B, q1.data());
+    cx<T>* cpip = gphi.template as<cx<T>>();
+    apply(OP_CPHI_INV, phi, cpip, B, false, false, false, nullptr, 0, 1, 1);
+    c->dot_F(phi, cpip, 1, B, q2.data());
+    for (int i = 0; i < B; ++i) {
+      lp[i] = -0.5 * (q1[i] + q2[i] + q3[i] + logdet_sum);
+      CMBL_REQUIRE(!std::isnan(lp[i]), ERR_NAN, "logpdf is NaN");
+    }
+    if (!gfo) return;
+    // d/df~ = -B'M'Cn^-1 z  -> QU Fourier
+    apply_M(w, B, true);
+    apply(OP_B, w, w, B, true, false, true, nullptr, 0, (T)-1);
+    // pullback through f~ = L f : delta flow t 1->0 from (f~, w, 0)
+    L.flow_delta(ftil.template as<T>(), w, dphi1.template as<cx<T>>(), P, B, true, quirk);
+    // g_f = df1 - Cf^-1 f   (harmonic) ; then d/dfhat = D' \ g_f  -> QU Fourier
+    c->harm(w, w, P, B, 0, nullptr, false, true, false);
+    c->lincomb1((T*)w, (const T*)w, (const T*)cfif, 1.0, -1.0, 2 * n / B, B);
+    apply(OP_D_INV, w, w, B, true, false, true);
+    // pullback through fhat = L \ f° : delta flow t 0->1 from (fhat, w, 0)
+    L.flow_delta(fhat.template as<T>(), w, dphi2.template as<cx<T>>(), P, B, false, quirk);
+    // d/df° in f°'s basis (QU map)
+    c->template x_pass<1>(w, w, sl); c->y_c2r(w, gfo, sl);
+    // g_phi = dphi1 + dphi2 - Cphi^-1 phi ; d/dphi° = G' \ g_phi
+    cx<T>* g = dphi1.template as<cx<T>>();
+    c->lincomb1((T*)g, (const T*)g, (const T*)dphi2.p, 1.0, 1.0, 2 * pl, B);
+    c->lincomb1((T*)g, (const T*)g, (const T*)cpip, 1.0, -1.0, 2 * pl, B);
+    apply(OP_G_INV, g, gphio_F, B, true, false, false, nullptr, 0, 1, 1);
+  }
+};
+
+}  // namespace cmbl

@@ -1,0 +1,167 @@
+// Pointwise kernels on the internal layouts: harmonic-basis operators (Cl / mask / beam / TE block applies
+// fused with the QU<->EB rotation), linear combinations with per-batch scalars, per-batch reductions.
+#pragma once
+#include "common.hpp"
+
+namespace cmbl {
+
+constexpr int MAXB = 16;                       // per-batch scalars are passed by value in chunks of MAXB
+template <typename T> struct BScal { T v[MAXB]; };
+
+// ---------------------------------------------------------------------------------------------
+// Harmonic operator application in F layout (src/specialops.jl:9-10,80-83; src/proj_lambert.jl:253-271).
+//   out = alpha * z + beta * R_out( Op( R_in(in) ) )
+// R_in : QU->EB rotation if in_qu (E=-Qc-Us, B=Qs-Uc), R_out: EB->QU if out_qu (Q=-Ec+Bs, U=-Es-Bc).
+// Op   : kind 0 identity; kind 1 diagonal multiply d[p]; kind 2 IEB block (a b; c d) on (I,E), e on B  (P==3);
+//        kind 3 diagonal "\" : nan2zero(in / d[p])   (src/specialops.jl:10)
+// transpose swaps b<->c.  Operator arrays are real, F layout [ky][xr], shared by all batch slots.
+template <typename T> struct HarmOpArgs {
+  const cx<T>* in; cx<T>* out; const cx<T>* z;
+  const T* cos2; const T* sin2;
+  const T* d[5];
+  int kind, in_qu, out_qu, transpose;
+  T alpha, beta;
+  long plane;                                  // Nyh*Nx
+  int B;
+};
+
+template <typename T> __device__ __forceinline__ T nan2zero(T v) { return isfinite(v) ? v : T(0); }
+
+template <typename T, int P>
+__global__ __launch_bounds__(NT) void k_harm_apply(HarmOpArgs<T> a) {
+  const long i = (long)blockIdx.x * NT + threadIdx.x;
+  if (i >= a.plane) return;
+  T c = 0, s = 0;
+  if (P >= 2 && (a.in_qu || a.out_qu)) { c = a.cos2[i]; s = a.sin2[i]; }
+  T d[5];
+  const int nd = (a.kind == 2) ? 5 : ((a.kind == 1 || a.kind == 3) ? P : 0);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) d[k] = (k < nd) ? a.d[k][i] : T(0);
+  if (a.kind == 2 && a.transpose) { T t = d[1]; d[1] = d[2]; d[2] = t; }
+  for (int b = 0; b < a.B; ++b) {
+    const long base = (long)b * P * a.plane + i;
+    cx<T> v[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) v[p] = a.in[base + p * a.plane];
+    if (P >= 2 && a.in_qu) {
+      cx<T> Q = v[P - 2], U = v[P - 1];
+      v[P - 2] = mk<T>(-Q.x * c - U.x * s, -Q.y * c - U.y * s);
+      v[P - 1] = mk<T>(Q.x * s - U.x * c, Q.y * s - U.y * c);
+    }
+    if (a.kind == 1) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) v[p] = d[p] * v[p];
+    } else if (a.kind == 3) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) v[p] = mk<T>(nan2zero(v[p].x / d[p]), nan2zero(v[p].y / d[p]));
+    } else if (a.kind == 2 && P == 3) {
+      cx<T> I = v[0], E = v[1];
+      v[0] = d[0] * I + d[1] * E;
+      v[1] = d[2] * I + d[3] * E;
+      v[2] = d[4] * v[2];
+    }
+    if (P >= 2 && a.out_qu) {
+      cx<T> E = v[P - 2], Bm = v[P - 1];
+      v[P - 2] = mk<T>(-E.x * c + Bm.x * s, -E.y * c + Bm.y * s);
+      v[P - 1] = mk<T>(-E.x * s - Bm.x * c, -E.y * s - Bm.y * c);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      cx<T> r = a.beta * v[p];
+      if (a.z) r = r + a.alpha * a.z[base + p * a.plane];
+      a.out[base + p * a.plane] = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[b][i] = a[b]*x[b][i] + c[b]*y[b][i]   on real views (complex arrays are passed as 2n reals).  grid (blocks, nb)
+template <typename T>
+__global__ __launch_bounds__(NT) void k_lincomb(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ y,
+                                                BScal<T> a, BScal<T> c, long n, int b0) {
+  const int b = blockIdx.y;
+  const T av = a.v[b], cv = c.v[b];
+  const long off = (long)(b0 + b) * n;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    T r = av * x[off + i];
+    if (y) r += cv * y[off + i];
+    out[off + i] = r;
+  }
+}
+
+// out[b][p][i] = m[i] * in[b][p][i]  (pixel mask, src/dataset.jl:281)   grid (blocks, slices)
+template <typename T>
+__global__ __launch_bounds__(NT) void k_mask_mul(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ m, long n) {
+  const long off = (long)blockIdx.y * n;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[off + i] = m[i] * in[off + i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reductions, deterministic two-pass (fixed partition, fixed tree), accumulated in double.
+template <int DUMMY = 0>
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double red[NT / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) { for (int w = 0; w < NT / 64; ++w) r += red[w]; }
+  __syncthreads();
+  return r;
+}
+
+// Fourier dot in F layout: sum lam[ky] * Re(conj(a) b)   (src/proj_lambert.jl:322-325); n = P*Nyh*Nx per batch
+template <typename T>
+__global__ __launch_bounds__(NT) void k_dot_F(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
+                                              const T* __restrict__ lam, double* __restrict__ part,
+                                              long n, int lgNx, int Nyh) {
+  const int bt = blockIdx.y;
+  const long off = (long)bt * n;
+  double acc = 0;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int ky = (int)((i >> lgNx) % Nyh);
+    cx<T> u = a[off + i], v = b[off + i];
+    acc += (double)lam[ky] * ((double)u.x * (double)v.x + (double)u.y * (double)v.y);
+  }
+  double r = block_sum(acc);
+  if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = r;
+}
+
+// Map dot: sum a*b  (src/proj_lambert.jl:318-321)
+template <typename T>
+__global__ __launch_bounds__(NT) void k_dot_map(const T* __restrict__ a, const T* __restrict__ b, double* __restrict__ part, long n) {
+  const int bt = blockIdx.y;
+  const long off = (long)bt * n;
+  double acc = 0;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT)
+    acc += (double)a[off + i] * (double)b[off + i];
+  double r = block_sum(acc);
+  if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = r;
+}
+
+// logdet of a real diagonal in F layout: sum lam * log|d|, non-finite -> 0  (src/proj_lambert.jl:331-336)
+template <typename T>
+__global__ __launch_bounds__(NT) void k_logdet_F(const T* __restrict__ d, const T* __restrict__ lam, double* __restrict__ part,
+                                                 long n, int lgNx, int Nyh) {
+  const int bt = blockIdx.y;
+  const long off = (long)bt * n;
+  double acc = 0;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int ky = (int)((i >> lgNx) % Nyh);
+    double v = log(fabs((double)d[off + i])) * (double)lam[ky];
+    acc += isfinite(v) ? v : 0.0;
+  }
+  double r = block_sum(acc);
+  if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(NT) void k_reduce_final(const double* __restrict__ part, double* __restrict__ out, int nblk, double scale) {
+  const int bt = blockIdx.x;
+  double acc = 0;
+  for (int i = threadIdx.x; i < nblk; i += NT) acc += part[(long)bt * nblk + i];
+  double r = block_sum(acc);
+  if (threadIdx.x == 0) out[bt] = r * scale;
+}
+
+}  // namespace cmbl

@@ -1,0 +1,342 @@
+"""Host-side mirror of the reference operator surface for the hot path, on top of the C ABI.
+
+Names follow CMBLensing.jl: `ProjLambert` (src/proj_lambert.jl:48-75), `LenseFlow` / cached flow with
+`L*f`, `L\\f`, `L'*f`, `L'\\f` and the pullbacks (src/lenseflow.jl, src/flowops.jl), `BaseDataSet` with
+`gradientf_logpdf`, `argmaxf_logpdf`, `logpdf(Mixed(ds))` and its gradient (src/dataset.jl,
+src/maximization.jl).  Device memory is held in torch tensors (plumbing only); every computation is a call
+into libcmblens_hip.so.  Tensor layouts are the reference's: map (B,P,Nx,Ny) real == Julia (Ny,Nx,P,B);
+Fourier (B,P,Nx,Ny//2+1) complex.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .lib import load_library, check
+
+MAP, FOURIER, HARMONIC = 0, 1, 2
+FLOW_FWD, FLOW_INV, FLOW_ADJ, FLOW_INVADJ = 0, 1, 2, 3
+DIAG_MUL, DIAG_DIV_NAN2ZERO = 1, 3
+(OP_CF_INV, OP_CN_INV, OP_B, OP_MF, OP_D, OP_D_INV, OP_PRECOND_INV, OP_CPHI_INV, OP_G_INV, OP_MPIX) = range(10)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class ProjLambert:
+    """Context: geometry + FFT tables + stream.  `T` is torch.float32 or torch.float64."""
+
+    def __init__(self, Ny, Nx, theta_pix=1.0, T=torch.float32, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("cmblensing_jl_amd needs a HIP device (no CPU fallback)")
+        self.lib = load_library()
+        self.Ny, self.Nx, self.Nyh, self.theta_pix = int(Ny), int(Nx), int(Ny) // 2 + 1, float(theta_pix)
+        self.T = T
+        self.CT = torch.complex64 if T == torch.float32 else torch.complex128
+        self.device = torch.device("cuda", device)
+        self._h = ctypes.c_void_p()
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.cmbl_ctx_create(self.Ny, self.Nx, self.theta_pix, 0 if T == torch.float32 else 1,
+                                       device, ctypes.c_void_p(stream), ctypes.byref(self._h)))
+        self._geom = {}
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.cmbl_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # geometry (host numpy, float64 copies of the T-precision values the kernels use)
+    def _g(self, which, shape):
+        if which not in self._geom:
+            n = int(np.prod(shape))
+            out = np.empty(n, dtype=np.float64)
+            check(self.lib.cmbl_ctx_geometry_host(self._h, which, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n))
+            self._geom[which] = out.reshape(shape)
+        return self._geom[which]
+
+    lx = property(lambda s: s._g(0, (s.Nx,)))
+    ly = property(lambda s: s._g(1, (s.Nyh,)))
+    lam = property(lambda s: s._g(2, (s.Nyh,)))
+    sin2phi = property(lambda s: s._g(3, (s.Nx, s.Nyh)))
+    cos2phi = property(lambda s: s._g(4, (s.Nx, s.Nyh)))
+    lmag = property(lambda s: s._g(5, (s.Nx, s.Nyh)))
+
+    @property
+    def Opix(self):
+        return np.deg2rad(self.theta_pix / 60) ** 2
+
+    @property
+    def nyquist(self):
+        return np.pi / np.deg2rad(self.theta_pix / 60)
+
+    @property
+    def lmax(self):
+        return int(round(np.ceil(np.sqrt(2) * self.nyquist) + 1))       # src/dataset.jl:232
+
+    def synchronize(self):
+        check(self.lib.cmbl_ctx_synchronize(self._h))
+
+    # ---- tensors
+    def empty(self, basis, P, B):
+        if basis == MAP:
+            return torch.empty((B, P, self.Nx, self.Ny), dtype=self.T, device=self.device)
+        return torch.empty((B, P, self.Nx, self.Nyh), dtype=self.CT, device=self.device)
+
+    def tensor(self, a, basis=None):
+        """numpy / torch -> contiguous device tensor of the context's precision"""
+        t = torch.as_tensor(a)
+        dt = self.CT if t.is_complex() else self.T
+        return t.to(device=self.device, dtype=dt).contiguous()
+
+    def _check(self, t, basis):
+        B, P = t.shape[0], t.shape[1]
+        want = (B, P, self.Nx, self.Ny if basis == MAP else self.Nyh)
+        if tuple(t.shape) != want or t.dtype != (self.T if basis == MAP else self.CT) or not t.is_contiguous() or t.device != self.device:
+            raise ValueError(f"field tensor has shape/dtype/device {tuple(t.shape)}/{t.dtype}/{t.device}, expected {want}")
+        return P, B
+
+    # ---- basis conversion (src/proj_lambert.jl:245-300)
+    def convert(self, t, basis_in, basis_out):
+        P, B = self._check(t, basis_in)
+        out = self.empty(basis_out, P, B)
+        check(self.lib.cmbl_convert(self._h, basis_in, _ptr(t), basis_out, _ptr(out), P, B))
+        return out
+
+    def rfft(self, m):
+        return self.convert(m, MAP, FOURIER)
+
+    def irfft(self, f):
+        return self.convert(f, FOURIER, MAP)
+
+    # ---- DiagOp * / \ (src/specialops.jl:9-10)
+    def diag_apply(self, diag, t, basis_diag, basis_in, basis_out=None, kind=DIAG_MUL):
+        P, B = self._check(t, basis_in)
+        basis_out = basis_in if basis_out is None else basis_out
+        d = self.tensor(diag)
+        out = self.empty(basis_out, P, B)
+        if d.shape[0] == 5 and P == 3:
+            check(self.lib.cmbl_blockdiag_ieb_apply(self._h, _ptr(d), 0, basis_in, _ptr(t), basis_out, _ptr(out), B))
+        else:
+            assert tuple(d.shape) == (P, self.Nx, self.Nyh), d.shape
+            check(self.lib.cmbl_diag_apply(self._h, kind, basis_diag, _ptr(d), basis_in, _ptr(t), basis_out, _ptr(out), P, B))
+        return out
+
+    # ---- reductions (src/proj_lambert.jl:318-342)
+    def dot(self, a, b, basis):
+        P, B = self._check(a, basis)
+        self._check(b, basis)
+        out = (ctypes.c_double * B)()
+        check(self.lib.cmbl_dot(self._h, basis, _ptr(a), _ptr(b), P, B, out))
+        return np.array(out[:])
+
+    def logdet(self, diag):
+        d = self.tensor(diag)
+        d = d.reshape(-1, self.Nx, self.Nyh)
+        out = (ctypes.c_double * 1)()
+        check(self.lib.cmbl_logdet(self._h, _ptr(d), d.shape[0], out))
+        return out[0]
+
+
+class Field:
+    """A field tensor tagged with its basis (tiny stand-in for BaseField{B,...}, src/base_fields.jl:14-21)."""
+
+    def __init__(self, proj, arr, basis):
+        self.proj, self.arr, self.basis = proj, arr, basis
+
+    def to(self, basis):
+        return self if basis == self.basis else Field(self.proj, self.proj.convert(self.arr, self.basis, basis), basis)
+
+    def dot(self, other):
+        o = other.to(self.basis)
+        return self.proj.dot(self.arr, o.arr, self.basis)
+
+    def __add__(self, o):
+        return Field(self.proj, self.arr + o.to(self.basis).arr, self.basis)
+
+    def __sub__(self, o):
+        return Field(self.proj, self.arr - o.to(self.basis).arr, self.basis)
+
+    def __rmul__(self, s):
+        return Field(self.proj, self.arr * s, self.basis)
+
+
+class _Adjoint:
+    def __init__(self, L):
+        self.L = L
+
+    def __mul__(self, g):            # L' * g
+        return self.L._apply(FLOW_ADJ, g)
+
+    def ldiv(self, g):               # L' \ g
+        return self.L._apply(FLOW_INVADJ, g)
+
+
+class LenseFlow:
+    """`LenseFlow(ϕ, n)` / `CachedLenseFlow` (src/lenseflow.jl:19-60): `L(ϕ)` re-caches only when ϕ is a
+    different object (src/lenseflow.jl:123-129)."""
+
+    def __init__(self, proj, nsteps=7):
+        self.proj, self.nsteps = proj, int(nsteps)
+        self.lib = proj.lib
+        self._h = ctypes.c_void_p()
+        check(self.lib.cmbl_lenseflow_create(proj._h, self.nsteps, ctypes.byref(self._h)))
+        self._phi = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.cmbl_lenseflow_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def __call__(self, phi):
+        """phi: Field (MAP or FOURIER, P=1)."""
+        if self._phi is not phi:
+            P, B = self.proj._check(phi.arr, phi.basis)
+            assert P == 1
+            check(self.lib.cmbl_lenseflow_set_phi(self._h, phi.basis, _ptr(phi.arr), B))
+            self._phi = phi
+        return self
+
+    def invalidate(self):
+        self._phi = None
+
+    @property
+    def phi(self):                                   # getϕ (src/lenseflow.jl:69-70)
+        return self._phi
+
+    def _apply(self, mode, f, basis_out=None):
+        P, B = self.proj._check(f.arr, f.basis)
+        if basis_out is None:
+            basis_out = MAP if mode in (FLOW_FWD, FLOW_INV) else FOURIER      # Ł / Ð of the result (src/flowops.jl:11-14)
+        out = self.proj.empty(basis_out, P, B)
+        check(self.lib.cmbl_lenseflow_apply(self._h, mode, f.basis, _ptr(f.arr), basis_out, _ptr(out), P, B))
+        return Field(self.proj, out, basis_out)
+
+    def __mul__(self, f):            # L * f
+        return self._apply(FLOW_FWD, f)
+
+    def ldiv(self, f):               # L \ f
+        return self._apply(FLOW_INV, f)
+
+    @property
+    def adjoint(self):
+        return _Adjoint(self)
+
+    def gradient(self, mode, f_end, delta, alias_quirk=False, basis_df=None):
+        """Pullback of `L*f` (mode=FLOW_FWD) or `L\\f` (FLOW_INV) (src/flowops.jl:40-68).
+        f_end: primal OUTPUT (map Field); delta: cotangent.  Returns (δϕ [FOURIER], δf, f_start)."""
+        P, B = self.proj._check(f_end.arr, MAP)
+        self.proj._check(delta.arr, delta.basis)
+        basis_df = delta.basis if basis_df is None else basis_df
+        dphi = self.proj.empty(FOURIER, 1, B)
+        df = self.proj.empty(basis_df, P, B)
+        fstart = self.proj.empty(MAP, P, B)
+        check(self.lib.cmbl_lenseflow_grad(self._h, mode, _ptr(f_end.arr), delta.basis, _ptr(delta.arr), _ptr(dphi),
+                                           basis_df, _ptr(df), _ptr(fstart), P, B, 1 if alias_quirk else 0))
+        return Field(self.proj, dphi, FOURIER), Field(self.proj, df, basis_df), Field(self.proj, fstart, MAP)
+
+
+class BaseDataSet:
+    """`BaseDataSet` at fiducial θ (src/dataset.jl:37-57) with the operators resident on the device.
+
+    ops: dict name -> real planes (numpy/torch, reference layout):
+        'Cf_inv','Cn_inv','B','Mf','D','D_inv','precond_inv' : (P or 5, Nx, Nyh)   harmonic basis
+        'Cphi_inv','G_inv' : (1, Nx, Nyh) ;  'Mpix' : (Nx, Ny) optional
+    d: harmonic-basis data (B,P,Nx,Nyh); logdet_sum: logdet Cf + logdet Cϕ + logdet Cn.
+    """
+    _ids = dict(Cf_inv=OP_CF_INV, Cn_inv=OP_CN_INV, B=OP_B, Mf=OP_MF, D=OP_D, D_inv=OP_D_INV,
+                precond_inv=OP_PRECOND_INV, Cphi_inv=OP_CPHI_INV, G_inv=OP_G_INV, Mpix=OP_MPIX)
+
+    def __init__(self, proj, P, ops, d=None, logdet_sum=0.0, nsteps=7):
+        self.proj, self.P, self.lib = proj, int(P), proj.lib
+        self._h = ctypes.c_void_p()
+        check(self.lib.cmbl_dataset_create(proj._h, self.P, ctypes.byref(self._h)))
+        self.L = LenseFlow(proj, nsteps)
+        self.ops = {}
+        for k, v in ops.items():
+            if v is None:
+                continue
+            t = proj.tensor(v)
+            t = t.reshape(1, *t.shape) if t.dim() == 2 else t
+            self.ops[k] = t
+            check(self.lib.cmbl_dataset_set_op(self._h, self._ids[k], _ptr(t), t.shape[0]))
+        self.d = None
+        if d is not None:
+            self.set_data(d)
+        check(self.lib.cmbl_dataset_set_logdet(self._h, float(logdet_sum)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.cmbl_dataset_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_data(self, d):
+        d = d if isinstance(d, Field) else Field(self.proj, self.proj.tensor(d), HARMONIC)
+        d = d.to(HARMONIC)
+        self.d = d
+        check(self.lib.cmbl_dataset_set_data(self._h, _ptr(d.arr), d.arr.shape[0]))
+
+    def gradientf_logpdf(self, f, phi, d=None, zero_d=False):
+        """src/dataset.jl:76-80"""
+        f = f.to(HARMONIC)
+        L = self.L(phi)
+        B = f.arr.shape[0]
+        out = self.proj.empty(HARMONIC, self.P, B)
+        dd = None if d is None else d.to(HARMONIC).arr
+        check(self.lib.cmbl_gradientf_logpdf(self._h, L._h, _ptr(f.arr), _ptr(dd), 1 if zero_d else 0, _ptr(out), B))
+        return Field(self.proj, out, HARMONIC)
+
+    def argmaxf_logpdf(self, phi, d=None, fstart=None, tol=1e-1, nsteps=500):
+        """Wiener filter (src/maximization.jl:17-42): returns (f [HARMONIC], history [(i, res_per_batch)])."""
+        L = self.L(phi)
+        dd = self.d if d is None else d.to(HARMONIC)
+        B = dd.arr.shape[0]
+        out = self.proj.empty(HARMONIC, self.P, B)
+        hist = (ctypes.c_double * (nsteps * B))()
+        nit = ctypes.c_int(0)
+        fs = None if fstart is None else fstart.to(HARMONIC).arr
+        check(self.lib.cmbl_wiener_cg(self._h, L._h, _ptr(dd.arr), _ptr(fs), float(tol), int(nsteps), _ptr(out),
+                                      hist, ctypes.byref(nit), B))
+        h = np.array(hist[: nit.value * B]).reshape(nit.value, B)
+        return Field(self.proj, out, HARMONIC), [(i + 1, h[i]) for i in range(nit.value)]
+
+    def logpdf_mixed(self, fo, phio):
+        """logpdf(Mixed(ds); f°, ϕ°) (src/dataset.jl:84-87)"""
+        fo, phio = fo.to(MAP), phio.to(FOURIER)
+        B = fo.arr.shape[0]
+        lp = (ctypes.c_double * B)()
+        self.L.invalidate()
+        check(self.lib.cmbl_logpdf_mixed(self._h, self.L._h, _ptr(fo.arr), _ptr(phio.arr), lp, B))
+        return np.array(lp[:])
+
+    def gradient_logpdf_mixed(self, fo, phio, alias_quirk=False):
+        """(logpdf, ∇f° [MAP], ∇ϕ° [FOURIER]) — the "∇lnP" step (test/runbenchmarks.jl:120)."""
+        fo, phio = fo.to(MAP), phio.to(FOURIER)
+        B = fo.arr.shape[0]
+        lp = (ctypes.c_double * B)()
+        gfo = self.proj.empty(MAP, self.P, B)
+        gpo = self.proj.empty(FOURIER, 1, B)
+        self.L.invalidate()
+        check(self.lib.cmbl_grad_logpdf_mixed(self._h, self.L._h, _ptr(fo.arr), _ptr(phio.arr), lp, _ptr(gfo), _ptr(gpo),
+                                              B, 1 if alias_quirk else 0))
+        return np.array(lp[:]), Field(self.proj, gfo, MAP), Field(self.proj, gpo, FOURIER)
+
+    def mix(self, f, phi):
+        """f° = L(ϕ)·D·f, ϕ° = G·ϕ (src/dataset.jl:96-101)"""
+        f = f.to(HARMONIC)
+        Df = Field(self.proj, self.proj.diag_apply(self.ops["D"], f.arr, HARMONIC, HARMONIC), HARMONIC)
+        fo = self.L(phi) * Df
+        G = 1.0 / self.ops["G_inv"]
+        G = torch.where(torch.isfinite(G), G, torch.zeros_like(G))
+        phio = Field(self.proj, self.proj.diag_apply(G, phi.to(FOURIER).arr, FOURIER, FOURIER), FOURIER)
+        return fo, phio

@@ -1,0 +1,98 @@
+"""ctypes loader for libcmblens_hip.so and the in-tree build recipe."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/cmblens.h declares (tests/test_boundary.py checks the .so exports exactly these)
+SYMBOLS = [
+    "cmbl_last_error", "cmbl_version", "cmbl_ctx_create", "cmbl_ctx_destroy", "cmbl_ctx_synchronize",
+    "cmbl_ctx_geometry_host", "cmbl_rfft", "cmbl_irfft", "cmbl_convert", "cmbl_diag_apply",
+    "cmbl_blockdiag_ieb_apply", "cmbl_dot", "cmbl_logdet", "cmbl_lenseflow_create", "cmbl_lenseflow_destroy",
+    "cmbl_lenseflow_set_phi", "cmbl_lenseflow_apply", "cmbl_lenseflow_grad", "cmbl_dataset_create",
+    "cmbl_dataset_destroy", "cmbl_dataset_set_op", "cmbl_dataset_set_data", "cmbl_dataset_set_logdet",
+    "cmbl_gradientf_logpdf", "cmbl_wiener_cg", "cmbl_logpdf_mixed", "cmbl_grad_logpdf_mixed",
+]
+
+
+class CmblError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcmblens_hip error {code}: {msg}")
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "libcmblens_hip.so")
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU.  In-tree output: cmblensing.jl_amd/libcmblens_hip.so"""
+    src = os.path.join(_HERE, "csrc", "api.hip")
+    out = library_path()
+    deps = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    deps.append(os.path.join(_HERE, "..", "include", "cmblens.h"))
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def load_library():
+    """Load the HIP library; fails loudly when it has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    pd = ctypes.POINTER(ctypes.c_double)
+    lib.cmbl_last_error.restype = ctypes.c_char_p
+    lib.cmbl_last_error.argtypes = []
+    lib.cmbl_version.restype = ci
+    sig = {
+        "cmbl_ctx_create": [ci, ci, cd, ci, ci, vp, ctypes.POINTER(vp)],
+        "cmbl_ctx_destroy": [vp],
+        "cmbl_ctx_synchronize": [vp],
+        "cmbl_ctx_geometry_host": [vp, ci, pd, ctypes.c_size_t],
+        "cmbl_rfft": [vp, vp, vp, ci, ci],
+        "cmbl_irfft": [vp, vp, vp, ci, ci],
+        "cmbl_convert": [vp, ci, vp, ci, vp, ci, ci],
+        "cmbl_diag_apply": [vp, ci, ci, vp, ci, vp, ci, vp, ci, ci],
+        "cmbl_blockdiag_ieb_apply": [vp, vp, ci, ci, vp, ci, vp, ci],
+        "cmbl_dot": [vp, ci, vp, vp, ci, ci, pd],
+        "cmbl_logdet": [vp, vp, ci, pd],
+        "cmbl_lenseflow_create": [vp, ci, ctypes.POINTER(vp)],
+        "cmbl_lenseflow_destroy": [vp],
+        "cmbl_lenseflow_set_phi": [vp, ci, vp, ci],
+        "cmbl_lenseflow_apply": [vp, ci, ci, vp, ci, vp, ci, ci],
+        "cmbl_lenseflow_grad": [vp, ci, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci],
+        "cmbl_dataset_create": [vp, ci, ctypes.POINTER(vp)],
+        "cmbl_dataset_destroy": [vp],
+        "cmbl_dataset_set_op": [vp, ci, vp, ci],
+        "cmbl_dataset_set_data": [vp, vp, ci],
+        "cmbl_dataset_set_logdet": [vp, cd],
+        "cmbl_gradientf_logpdf": [vp, vp, vp, vp, ci, vp, ci],
+        "cmbl_wiener_cg": [vp, vp, vp, vp, cd, ci, vp, pd, ctypes.POINTER(ci), ci],
+        "cmbl_logpdf_mixed": [vp, vp, vp, vp, pd, ci],
+        "cmbl_grad_logpdf_mixed": [vp, vp, vp, vp, pd, vp, vp, ci, ci],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ci
+    _LIB = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise CmblError(code, load_library().cmbl_last_error().decode("utf-8", "replace"))

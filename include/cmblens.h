@@ -1,0 +1,140 @@
+/* libcmblens_hip.so -- C ABI of the MI355X-native flat-sky lensing field engine.
+ *
+ * Drop-in boundary for the LenseFlow / Wiener-filter hot path of marius311/CMBLensing.jl
+ * (reference @ v0.10.1; citations are `file:line` under /root/reference).  The reference has no
+ * FFI for this path -- its "plugin" surface is the array storage type `A` of `BaseField{B,M,T,A}`
+ * (src/base_fields.jl:14) plus the operator slot `ds.L` (src/dataset.jl:55).  Each entry point
+ * below replaces the reference method(s) it cites; INTEGRATION.md shows the Julia `ccall` glue.
+ *
+ * Conventions
+ *   - every function returns 0 (CMBL_OK) or a CMBL_ERR_* code; cmbl_last_error() gives the text
+ *     (thread-local).  Nothing throws across the ABI.
+ *   - all field pointers are DEVICE pointers (HIP) unless the name ends in `_host`.
+ *   - array layouts are the reference's (src/proj_cartesian.jl:13-36, column-major, Ny fastest):
+ *       map     : real    (Ny, Nx, npol, nbatch)
+ *       fourier : complex (Ny/2+1, Nx, npol, nbatch)   interleaved (re,im)
+ *     npol = 1 (I), 2 (QU), 3 (IQU).  Operators diagonal in l are real (Ny/2+1, Nx) planes.
+ *   - dtype: CMBL_F32 or CMBL_F64 (the whole context works in one precision).
+ *   - Ny, Nx must be powers of two in [32, 4096] (the reference accepts any size through FFTW;
+ *     other sizes return CMBL_ERR_SHAPE).
+ *   - a handle is used by one host thread at a time; different contexts are independent.
+ *   - calls are asynchronous on the context's stream unless they return host values.
+ */
+#ifndef CMBLENS_H
+#define CMBLENS_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmbl_ctx cmbl_ctx;
+typedef struct cmbl_flow cmbl_flow;
+typedef struct cmbl_dataset cmbl_dataset;
+
+enum { CMBL_OK = 0, CMBL_ERR_ARG = 1, CMBL_ERR_SHAPE = 2, CMBL_ERR_HIP = 3, CMBL_ERR_NAN = 4,
+       CMBL_ERR_STATE = 5, CMBL_ERR_ALLOC = 6 };
+enum { CMBL_F32 = 0, CMBL_F64 = 1 };
+
+/* bases (src/generic.jl:42-98): MAP = Map/QUMap/IQUMap (LenseBasis), FOURIER = Fourier/QUFourier/
+ * IQUFourier (DerivBasis), HARMONIC = Fourier/EBFourier/IEBFourier (basis covariances are diagonal in) */
+enum { CMBL_MAP = 0, CMBL_FOURIER = 1, CMBL_HARMONIC = 2 };
+
+/* LenseFlow operator modes (src/flowops.jl:11-14) */
+enum { CMBL_FLOW_FWD = 0,     /* L * f   : velocity,  t 0->1 */
+       CMBL_FLOW_INV = 1,     /* L \ f   : velocity,  t 1->0 */
+       CMBL_FLOW_ADJ = 2,     /* L' * f  : velocityH, t 1->0 */
+       CMBL_FLOW_INVADJ = 3   /* L' \ f  : velocityH, t 0->1 */ };
+
+/* diagonal operator application kinds (src/specialops.jl:9-10) */
+enum { CMBL_DIAG_MUL = 1, CMBL_DIAG_DIV_NAN2ZERO = 3 };
+
+const char* cmbl_last_error(void);
+int cmbl_version(void);
+
+/* ---- context: replaces the memoized ProjLambert + FFT plans
+ *      (src/proj_lambert.jl:48-75, src/util_fft.jl:32-39).  `stream` is a hipStream_t the caller owns
+ *      (e.g. torch's current stream); NULL is the legacy default stream. */
+int cmbl_ctx_create(int Ny, int Nx, double theta_pix_arcmin, int dtype, int device, void* stream, cmbl_ctx** out);
+int cmbl_ctx_destroy(cmbl_ctx* ctx);
+int cmbl_ctx_synchronize(cmbl_ctx* ctx);
+/* geometry queries, host output, double: which = 0 lx[Nx], 1 ly[Ny/2+1], 2 lambda_rfft[Ny/2+1],
+ * 3 sin2phi[(Ny/2+1)*Nx], 4 cos2phi[...], 5 lmag[...]  (planes in the reference layout) */
+int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n);
+
+/* ---- basis transforms: m_rfft / m_irfft and the Basis conversion lattice
+ *      (src/util_fft.jl:20-31, src/proj_lambert.jl:245-300) */
+int cmbl_rfft(cmbl_ctx* ctx, const void* map, void* fourier, int npol, int nbatch);
+int cmbl_irfft(cmbl_ctx* ctx, const void* fourier, void* map, int npol, int nbatch);
+int cmbl_convert(cmbl_ctx* ctx, int basis_in, const void* in, int basis_out, void* out, int npol, int nbatch);
+
+/* ---- diagonal operators: DiagOp `*` and `\` with automatic basis conversion, BlockDiagIEB
+ *      (src/specialops.jl:9-10, 61-118; src/field_vectors.jl:64-66).
+ *      diag: real (Ny/2+1, Nx, npol) planes, diagonal in `basis_diag` (FOURIER or HARMONIC). */
+int cmbl_diag_apply(cmbl_ctx* ctx, int kind, int basis_diag, const void* diag,
+                    int basis_in, const void* in, int basis_out, void* out, int npol, int nbatch);
+/* te_bb: 5 real planes (TT, TE, ET, EE, BB): (i,e) = [TT TE; ET EE](I,E), b = BB*B */
+int cmbl_blockdiag_ieb_apply(cmbl_ctx* ctx, const void* te_bb, int transpose,
+                             int basis_in, const void* in, int basis_out, void* out, int nbatch);
+
+/* ---- per-batch reductions: dot, logdet (src/proj_lambert.jl:318-342) */
+int cmbl_dot(cmbl_ctx* ctx, int basis, const void* a, const void* b, int npol, int nbatch, double* out_host);
+int cmbl_logdet(cmbl_ctx* ctx, const void* diag_fourier, int nplanes, double* out_host);
+
+/* ---- LenseFlow: LenseFlow / CachedLenseFlow, precompute!!, the four flow operators and the two
+ *      Zygote pullbacks (src/lenseflow.jl:19-214, src/flowops.jl:11-14, 40-68) */
+int cmbl_lenseflow_create(cmbl_ctx* ctx, int nsteps, cmbl_flow** out);
+int cmbl_lenseflow_destroy(cmbl_flow* L);
+/* precompute!(L): phi in `basis` (MAP or FOURIER), (.., 1, nbatch_phi) */
+int cmbl_lenseflow_set_phi(cmbl_flow* L, int basis, const void* phi, int nbatch_phi);
+int cmbl_lenseflow_apply(cmbl_flow* L, int mode, int basis_in, const void* in, int basis_out, void* out,
+                         int npol, int nbatch);
+/* pullback of  mode=FWD: ftilde = L*f   (delta flow t 1->0 from (ftilde, delta, 0))
+ *              mode=INV: f = L\ftilde   (delta flow t 0->1 from (f, delta, 0)).
+ * f_end: the OUTPUT of the primal op (MAP basis); delta: cotangent in basis_delta.
+ * outputs: dphi (FOURIER, (Ny/2+1,Nx,1,nbatch)), df (basis_df), f_start (MAP; may be NULL).
+ * alias_quirk != 0 reproduces the reference's in-place aliasing (src/lenseflow.jl:198-200 with
+ * src/field_vectors.jl:48-49); 0 gives the mathematically consistent gradient. */
+int cmbl_lenseflow_grad(cmbl_flow* L, int mode, const void* f_end, int basis_delta, const void* delta,
+                        void* dphi_out, int basis_df, void* df_out, void* f_start_out,
+                        int npol, int nbatch, int alias_quirk);
+
+/* ---- data model, Wiener filter and posterior (src/dataset.jl:37-137, src/maximization.jl:17-42,
+ *      src/numerical_algorithms.jl:73-134).  Operators are set as real planes in the reference
+ *      layout; *_INV operators are the caller's pinv() of the reference operators. */
+enum { CMBL_OP_CF_INV = 0,     /* pinv(Cf)                                   harmonic, npol planes (5 for IQU) */
+       CMBL_OP_CN_INV = 1,     /* pinv(Cn)                                                                      */
+       CMBL_OP_B = 2,          /* beam / transfer function                                                      */
+       CMBL_OP_MF = 3,         /* Fourier-space mask                                                            */
+       CMBL_OP_D = 4,          /* mixing matrix D                                                               */
+       CMBL_OP_D_INV = 5,      /* operator applied for `D \ f` (pinv(D), or D itself with DIV semantics)        */
+       CMBL_OP_PRECOND_INV = 6,/* pinv(Cf^-1 + B'M'Cn^-1 M B)  (src/dataset.jl:129-132)                          */
+       CMBL_OP_CPHI_INV = 7,   /* pinv(Cphi), 1 plane                                                           */
+       CMBL_OP_G_INV = 8,      /* pinv(G), 1 plane                                                              */
+       CMBL_OP_MPIX = 9,       /* pixel mask, real (Ny,Nx) map; optional                                        */
+       CMBL_OP_COUNT = 10 };
+int cmbl_dataset_create(cmbl_ctx* ctx, int npol, cmbl_dataset** out);
+int cmbl_dataset_destroy(cmbl_dataset* ds);
+int cmbl_dataset_set_op(cmbl_dataset* ds, int which, const void* planes, int nplanes);
+int cmbl_dataset_set_data(cmbl_dataset* ds, const void* d_harmonic, int nbatch);
+/* sum of the three logdet terms of logpdf (logdet Cf + logdet Cphi + logdet Cn), per batch identical */
+int cmbl_dataset_set_logdet(cmbl_dataset* ds, double logdet_sum);
+
+/* gradientf_logpdf (src/dataset.jl:76-80): f, out HARMONIC; d = NULL uses ds.d; use_zero_d != 0 uses d = 0 */
+int cmbl_gradientf_logpdf(cmbl_dataset* ds, cmbl_flow* L, const void* f, const void* d, int use_zero_d,
+                          void* out, int nbatch);
+/* argmaxf_logpdf (src/maximization.jl:17-42) by conjugate_gradient (src/numerical_algorithms.jl:73-134):
+ * fstart may be NULL; res_hist_host has room for maxit*nbatch doubles; *nit_host = history length. */
+int cmbl_wiener_cg(cmbl_dataset* ds, cmbl_flow* L, const void* d, const void* fstart, double tol, int maxit,
+                   void* f_out, double* res_hist_host, int* nit_host, int nbatch);
+/* logpdf(Mixed(ds); f°, phi°) and its gradient (src/dataset.jl:84-117, src/maximization.jl:178):
+ * fo MAP, phio FOURIER; gfo MAP, gphio FOURIER.  L's phi is overwritten with G \ phi°. */
+int cmbl_logpdf_mixed(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void* phio, double* lp_host, int nbatch);
+int cmbl_grad_logpdf_mixed(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void* phio, double* lp_host,
+                           void* gfo, void* gphio, int nbatch, int alias_quirk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

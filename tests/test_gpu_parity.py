@@ -1,0 +1,266 @@
+"""GPU parity: every C-ABI entry point of libcmblens_hip.so against the NumPy oracle on identical inputs.
+
+Tolerances (relative L2 per field, vs the oracle run in the SAME precision class noted):
+    fp64: 1e-10 single transforms / pointwise, 1e-9 flows and gradients (vs float64 oracle)
+    fp32: 2e-6 transforms, 5e-5 flows, 2e-4 gradient flows            (vs float64 oracle on the fp32-rounded inputs)
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as O                                   # the checker (tests only)
+from oracle.lenseflow import LenseFlow as OLenseFlow
+
+
+def _pkg():
+    import cmblensing_jl_amd as C
+    return C
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+
+
+DT = {"f32": (torch.float32, np.float32), "f64": (torch.float64, np.float64)}
+TOL = {"f32": dict(fft=2e-6, flow=5e-5, grad=3e-4, cg=2e-3), "f64": dict(fft=1e-12, flow=1e-10, grad=1e-9, cg=1e-7)}
+
+
+@pytest.fixture(scope="module")
+def camb():
+    return O.load_camb()
+
+
+def sims(camb, Ny, Nx, P, B=1, theta=2.0):
+    """float64 CMB-like inputs: f (map), g (map), phi (map)"""
+    proj = O.Proj(Ny, Nx, theta, np.float64)
+    cl = camb["unlensed_total"]
+    Cphi = O.cl_to_2d(cl["pp"], proj)
+    if P == 1:
+        C = O.cl_to_2d(cl["TT"], proj)[None]
+    elif P == 2:
+        C = np.stack([O.cl_to_2d(cl["EE"], proj), O.cl_to_2d(cl["BB"], proj) + 0.05 * O.cl_to_2d(cl["EE"], proj)])
+    else:
+        C = np.stack([O.cl_to_2d(cl["TT"], proj), O.cl_to_2d(cl["EE"], proj), 0.05 * O.cl_to_2d(cl["EE"], proj)])
+    simf = lambda seed: O.from_harm(proj, np.sqrt(C) * O.rfft2(O.white_noise(seed, (B, P, Nx, Ny), np.float64)))
+    simp = lambda seed, b=B: O.irfft2(np.sqrt(Cphi) * O.rfft2(O.white_noise(seed, (b, 1, Nx, Ny), np.float64)), Ny)
+    return proj, simf, simp
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("Ny,Nx", [(64, 128), (128, 64), (256, 256), (32, 32)])
+def test_geometry_and_basis_transforms(prec, Ny, Nx):
+    C = _pkg()
+    tT, nT = DT[prec]
+    p = C.ProjLambert(Ny, Nx, 3.0, tT)
+    op = O.Proj(Ny, Nx, 3.0, nT)
+    np.testing.assert_allclose(p.lx, op.lx, rtol=1e-6)
+    np.testing.assert_allclose(p.ly, op.ly, rtol=1e-6)
+    np.testing.assert_allclose(p.lam, op.lam)
+    np.testing.assert_allclose(p.sin2phi, op.sin2phi, atol=2e-6)
+    np.testing.assert_allclose(p.cos2phi, op.cos2phi, atol=2e-6)
+    rng = np.random.default_rng(4)
+    for P, B in [(1, 1), (2, 2), (3, 1)]:
+        m = rng.standard_normal((B, P, Nx, Ny)).astype(nT)
+        fl = p.rfft(p.tensor(m))
+        ref = O.rfft2(m.astype(np.float64))
+        assert rel(fl.cpu().numpy(), ref) < TOL[prec]["fft"], ("rfft", P, B)
+        back = p.irfft(fl)
+        assert rel(back.cpu().numpy(), m) < TOL[prec]["fft"], ("irfft∘rfft", P, B)
+        # irfft of NON-Hermitian input must follow FFTW/pocketfft semantics (Im of ky=0,Nyq after the x pass dropped)
+        junk = (rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape))
+        out = p.irfft(p.tensor(junk))
+        assert rel(out.cpu().numpy(), O.irfft2(junk, Ny)) < TOL[prec]["fft"], ("irfft non-hermitian", P, B)
+        # the whole basis lattice (src/proj_lambert.jl:245-300)
+        oproj = O.Proj(Ny, Nx, 3.0, np.float64)
+        h = p.convert(p.tensor(m), C.MAP, C.HARMONIC)
+        assert rel(h.cpu().numpy(), O.to_harm(oproj, m.astype(np.float64))) < 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32")
+        q = p.convert(h, C.HARMONIC, C.FOURIER)
+        assert rel(q.cpu().numpy(), ref) < 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32")
+        mm = p.convert(h, C.HARMONIC, C.MAP)
+        assert rel(mm.cpu().numpy(), m) < 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32")
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_reductions_and_diag_ops(prec):
+    C = _pkg()
+    tT, nT = DT[prec]
+    Ny, Nx = 128, 64
+    p = C.ProjLambert(Ny, Nx, 2.0, tT)
+    op = O.Proj(Ny, Nx, 2.0, np.float64)
+    rng = np.random.default_rng(1)
+    tol = 1e-5 if prec == "f32" else 1e-12
+    for P, B in [(1, 2), (2, 3), (3, 1)]:
+        a = rng.standard_normal((B, P, Nx, Ny)).astype(nT)
+        b = rng.standard_normal((B, P, Nx, Ny)).astype(nT)
+        np.testing.assert_allclose(p.dot(p.tensor(a), p.tensor(b), C.MAP), O.dot_map(a.astype(float), b.astype(float)), rtol=tol, atol=tol * a.size ** 0.5)
+        al, bl = O.rfft2(a.astype(float)), O.rfft2(b.astype(float))
+        got = p.dot(p.tensor(al), p.tensor(bl), C.FOURIER)
+        np.testing.assert_allclose(got, O.dot_fourier(op, al, bl), rtol=10 * tol, atol=tol * a.size ** 0.5)
+        np.testing.assert_allclose(got, O.dot_map(a.astype(float), b.astype(float)), rtol=10 * tol, atol=10 * tol * a.size ** 0.5)   # Parseval
+        # DiagOp * and \ in the harmonic basis applied to a map, result as map (src/specialops.jl:9-10)
+        d = (rng.random((P, Nx, Ny // 2 + 1)) + 0.5).astype(nT)
+        d[0, 0, 0] = 0                                       # exercises nan2zero
+        fh = O.to_harm(op, a.astype(float))
+        want = O.from_harm(op, d.astype(float) * fh)
+        got = p.diag_apply(d, p.tensor(a), C.HARMONIC, C.MAP, C.MAP)
+        assert rel(got.cpu().numpy(), want) < (5e-6 if prec == "f32" else 1e-12)
+        want = O.from_harm(op, O.diag_div(d.astype(float), fh))
+        got = p.diag_apply(d, p.tensor(a), C.HARMONIC, C.MAP, C.MAP, kind=3)
+        assert rel(got.cpu().numpy(), want) < (5e-6 if prec == "f32" else 1e-12)
+        ld = p.logdet(d)
+        np.testing.assert_allclose(ld, O.logdet_fourier(op, d.astype(float)[None])[0], rtol=1e-6 if prec == "f32" else 1e-12)
+    # BlockDiagIEB (src/specialops.jl:80-83)
+    te = (rng.random((5, Nx, Ny // 2 + 1)) + 0.5).astype(nT)
+    a = rng.standard_normal((2, 3, Nx, Ny)).astype(nT)
+    H = O.HarmOp(3, te=tuple(te[:4].astype(float)), bb=te[4].astype(float))
+    want = H(O.to_harm(op, a.astype(float)))
+    got = p.diag_apply(te, p.tensor(a), C.HARMONIC, C.MAP, C.HARMONIC)
+    assert rel(got.cpu().numpy(), want) < (5e-6 if prec == "f32" else 1e-12)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(128, 128, 1, 1, 1), (64, 128, 2, 1, 1), (128, 64, 3, 1, 1), (64, 64, 2, 3, 3),
+                                            (64, 64, 2, 2, 1), (256, 256, 2, 1, 1)])
+def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi):
+    C = _pkg()
+    tT, nT = DT[prec]
+    oproj, simf, simp = sims(camb, Ny, Nx, P, B)
+    f = simf(1).astype(nT).astype(np.float64)
+    g = simf(11).astype(nT).astype(np.float64)
+    phi = simp(2, Bphi).astype(nT).astype(np.float64)
+    OL = OLenseFlow(oproj, phi, 7)
+    p = C.ProjLambert(Ny, Nx, 2.0, tT)
+    L = C.LenseFlow(p, 7)(C.Field(p, p.tensor(phi), C.MAP))
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    tol = TOL[prec]["flow"]
+    out = (L * F(f, C.MAP)).arr.cpu().numpy()
+    assert rel(out, OL.apply(f)) < tol, "L*f"
+    out = L.ldiv(F(f, C.MAP)).arr.cpu().numpy()
+    assert rel(out, OL.inv(f)) < tol, "L\\f"
+    gl = O.rfft2(g)
+    out = (L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy()
+    assert rel(out, OL.adj(gl)) < tol, "L'*g"
+    out = L.adjoint.ldiv(F(gl, C.FOURIER)).arr.cpu().numpy()
+    assert rel(out, OL.invadj(gl)) < tol, "L'\\g"
+    # basis plumbing: harmonic in, map out == explicit conversion
+    fh = O.to_harm(oproj, f)
+    out = L._apply(C.FLOW_FWD, F(fh, C.HARMONIC), C.HARMONIC).arr.cpu().numpy()
+    assert rel(out, O.to_harm(oproj, OL.apply(f))) < 2 * tol
+    # adjoint identity on the device itself (test/runtests.jl:556,570)
+    lhs = p.dot(p.tensor(f), (L * F(g, C.MAP)).arr, C.MAP)
+    rhs = (L.adjoint * F(O.rfft2(f), C.FOURIER)).dot(F(gl, C.FOURIER))
+    np.testing.assert_allclose(lhs, rhs, rtol=2e-4 if prec == "f32" else 1e-10)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(128, 128, 1, 1, 1), (64, 128, 2, 1, 1), (128, 64, 3, 1, 1), (64, 64, 2, 2, 2), (64, 64, 2, 2, 1)])
+@pytest.mark.parametrize("mode", ["fwd", "inv"])
+def test_lenseflow_gradient(camb, prec, Ny, Nx, P, B, Bphi, mode):
+    C = _pkg()
+    tT, nT = DT[prec]
+    oproj, simf, simp = sims(camb, Ny, Nx, P, B)
+    f = simf(1).astype(nT).astype(np.float64)
+    phi = simp(2, Bphi).astype(nT).astype(np.float64)
+    OL = OLenseFlow(oproj, phi, 7)
+    fe = OL.apply(f) if mode == "fwd" else OL.inv(f)
+    fe = fe.astype(nT).astype(np.float64)
+    delta = O.rfft2(simf(7)).astype(np.complex64 if prec == "f32" else np.complex128).astype(np.complex128)
+    p = C.ProjLambert(Ny, Nx, 2.0, tT)
+    L = C.LenseFlow(p, 7)(C.Field(p, p.tensor(phi), C.MAP))
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    for quirk in (False, True):
+        f0, df, dp = (OL.grad_apply if mode == "fwd" else OL.grad_inv)(fe, delta, alias_quirk=quirk)
+        gdp, gdf, gf0 = L.gradient(C.FLOW_FWD if mode == "fwd" else C.FLOW_INV, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=quirk)
+        assert rel(gf0.arr.cpu().numpy(), f0) < TOL[prec]["flow"], ("f", quirk)
+        assert rel(gdf.arr.cpu().numpy(), df) < TOL[prec]["flow"], ("df", quirk)
+        assert rel(gdp.arr.cpu().numpy(), dp) < TOL[prec]["grad"], ("dphi", quirk)
+    # the two variants must differ (the flag is live)
+    a = L.gradient(C.FLOW_FWD, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=False)[0].arr
+    b = L.gradient(C.FLOW_FWD, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=True)[0].arr
+    assert rel(a.cpu().numpy(), b.cpu().numpy()) > 1e-6
+
+
+def _dataset_pair(prec, pol, Nside, theta=3.0, mask=True, beam=3.0, B=1):
+    """identical dataset on both sides: oracle (float64) and device (precision `prec`)"""
+    C = _pkg()
+    tT, nT = DT[prec]
+    pm = dict(pad_deg=0.4, apod_deg=0.4) if mask else None
+    so = O.load_sim(theta, Nside, pol, np.float64, beam_fwhm=beam, pixel_mask=pm, Nbatch=B)
+    camb = so["cls"]
+    cls = {g: {k: C.Cls(v.ell, v.cl) for k, v in camb[g].items()} for g in ("unlensed_scalar", "tensor", "total")}
+    sd = C.load_sim(theta, Nside, pol, cls, T=tT, beam_fwhm=beam, pixel_mask=pm, Nbatch=B, Nphi=so["ds"].Nphi * 2)
+    return C, so, sd
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("pol,Nside,mask", [("I", (64, 64), True), ("P", (64, 128), True), ("IP", (128, 64), True), ("P", (64, 64), False)])
+def test_dataset_gradientf_and_wiener(prec, pol, Nside, mask):
+    C, so, sd = _dataset_pair(prec, pol, Nside, mask=mask)
+    ods, ds, p = so["ds"], sd["ds"], sd["proj"]
+    tol = TOL[prec]
+    # the simulated fields agree (same PCG64 seeds, same operators)
+    assert rel(sd["f"].arr.cpu().numpy(), so["f"]) < tol["fft"] * 10 + 1e-6 * (prec == "f32")
+    assert rel(sd["phi"].arr.cpu().numpy(), so["phi"]) < tol["fft"] * 10 + 1e-6 * (prec == "f32")
+    assert rel(sd["d"].arr.cpu().numpy(), so["d"]) < tol["flow"]
+    # run both sides from the ORACLE's fields so that only the operator under test differs
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    f, phi, d = so["f"], so["phi"], so["d"]
+    ds.set_data(F(d, C.HARMONIC))
+    OL = ods.L(phi)
+    want = ods.gradientf_logpdf(f, OL, d)
+    got = ds.gradientf_logpdf(F(f, C.HARMONIC), F(phi, C.FOURIER))
+    assert rel(got.arr.cpu().numpy(), want) < tol["flow"] * 4, "gradientf_logpdf"
+    # Wiener filter: same tolerance-based stop; compare solution and history loosely, tight solve tightly
+    fw_o, h_o = ods.argmaxf_logpdf(phi, tol=1e-1, nsteps=500)
+    fw_g, h_g = ds.argmaxf_logpdf(F(phi, C.FOURIER), tol=1e-1, nsteps=500)
+    assert abs(len(h_g) - len(h_o)) <= 1, (len(h_g), len(h_o))
+    n = min(len(h_g), len(h_o)) - 1
+    np.testing.assert_allclose(h_g[0][1], h_o[0][1], rtol=1e-3 if prec == "f32" else 1e-8)
+    np.testing.assert_allclose(h_g[n // 2][1], h_o[n // 2][1], rtol=5e-2 if prec == "f32" else 1e-5)
+    assert rel(fw_g.arr.cpu().numpy(), fw_o) < (5e-3 if prec == "f32" else 1e-6)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("pol,Nside", [("I", (64, 64)), ("P", (64, 128)), ("IP", (128, 64))])
+def test_logpdf_mixed_and_gradient(prec, pol, Nside):
+    C, so, sd = _dataset_pair(prec, pol, Nside)
+    ods, ds, p = so["ds"], sd["ds"], sd["proj"]
+    oproj = so["proj"]
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    ds.set_data(F(so["d"], C.HARMONIC))
+    # a non-trivial G exercises the ϕ re-parametrisation on both sides
+    G = np.sqrt(1 + 2 * ods.Nphi * O.pinv(ods.Cphi))
+    ods.G = G
+    ds.ops["G_inv"] = p.tensor(O.pinv(G)[None])
+    import ctypes
+    from cmblensing_jl_amd.lib import check
+    check(ds.lib.cmbl_dataset_set_op(ds._h, 8, ctypes.c_void_p(ds.ops["G_inv"].data_ptr()), 1))
+    fo, po = ods.mix(so["f"], so["phi"])
+    gfo_d, gpo_d = ds.mix(F(so["f"], C.HARMONIC), F(so["phi"], C.FOURIER))
+    assert rel(gfo_d.arr.cpu().numpy(), fo) < TOL[prec]["flow"] * 2
+    assert rel(gpo_d.arr.cpu().numpy(), po) < TOL[prec]["fft"] * 10 + 1e-6
+    lp_o = ods.logpdf_mixed(fo, po)
+    lp_g = ds.logpdf_mixed(F(fo, C.MAP), F(po, C.FOURIER))
+    np.testing.assert_allclose(lp_g, lp_o, rtol=2e-5 if prec == "f32" else 1e-10)
+    for quirk in (False, True):
+        lp2, gf, gp = ods.grad_logpdf_mixed(fo, po, alias_quirk=quirk)
+        lp3, gf_g, gp_g = ds.gradient_logpdf_mixed(F(fo, C.MAP), F(po, C.FOURIER), alias_quirk=quirk)
+        np.testing.assert_allclose(lp3, lp2, rtol=2e-5 if prec == "f32" else 1e-10)
+        assert rel(gf_g.arr.cpu().numpy(), gf) < TOL[prec]["grad"], ("grad f°", quirk)
+        assert rel(gp_g.arr.cpu().numpy(), gp) < TOL[prec]["grad"] * 3, ("grad ϕ°", quirk)
+
+
+def test_errors_are_status_codes():
+    C = _pkg()
+    with pytest.raises(C.CmblError) as e:
+        C.ProjLambert(100, 64, 1.0)
+    assert e.value.code == 2                       # CMBL_ERR_SHAPE
+    p = C.ProjLambert(64, 64, 1.0)
+    L = C.LenseFlow(p, 7)
+    f = C.Field(p, p.tensor(np.zeros((1, 1, 64, 64))), C.MAP)
+    with pytest.raises(C.CmblError) as e:
+        L * f                                       # set_phi not called
+    assert e.value.code == 5                       # CMBL_ERR_STATE
