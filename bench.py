@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LenseFlow + ∇logP steps/sec on a 1024² QU flat-sky map (BASELINE.json `metric`).
+
+One "step" = one evaluation of ∇_(f°,ϕ°) logpdf(Mixed(ds)) (the reference's "∇lnP" row,
+test/runbenchmarks.jl:120): precompute(ϕ) + 1 inverse flow + 1 forward flow + 2 δ-flows +
+the Fourier-diagonal / mask / reduction work, LenseFlow n = 7 RK4 steps, fp32, inputs resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nside 1024] [--pol P] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, every rank runs its own independent posterior chain state (weak scaling, no
+data-path collective); RCCL (`nccl` backend) only gathers the per-chain scalars, as SURVEY.md §8(e) prescribes.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def synthetic_cls():
+    """Spectra of the reference's own data fixture (decoded dat/default_camb_Cls.jld2 -> tests/golden/camb_cls.npz)."""
+    import cmblensing_jl_amd as C
+    z = np.load(os.path.join(ROOT, "tests", "golden", "camb_cls.npz"))
+    ell = z["ell"]
+    out = {}
+    for g in ("unlensed_scalar", "tensor", "total"):
+        out[g] = {k: C.Cls(ell, z[f"{g}_{k}"]) for k in ("TT", "EE", "BB", "TE")}
+        out[g]["pp"] = C.Cls(ell, z["phiphi"])
+    return out
+
+
+def algorithmic_bytes(N, P, B, Bphi, n, s):
+    """SURVEY.md §8(d) formulas (unit = one map-pass = N²·s bytes)."""
+    mp = N * N * s
+    lf = 4 * n * (15 * P * B + 2 * Bphi) * mp
+    delta = 4 * n * (30 * P * B + 30 * B + 7 * Bphi) * mp
+    pre = (18 + 10 * (2 * n + 1)) * Bphi * mp
+    grad = pre + 2 * lf + 2 * delta + 60 * P * B * mp
+    return dict(map_pass=mp, lenseflow=lf, delta_flow=delta, precompute=pre, grad_lnP=grad)
+
+
+# share of SURVEY §8(d)'s per-stage map-passes carried by each of our kernels, per (pol,batch) slice
+KERNEL_SHARE = {
+    "flow_y_fwd": lambda P, B, Bphi: 10.5 * P * B + 2 * Bphi,      # y-halves of rfft/2 irfft, i·ly multiply, velocity ⊕ RK
+    "x_grad": lambda P, B, Bphi: 4.5 * P * B,                      # x-halves of rfft/irfft(∂x), i·lx multiply
+    "adj_y": lambda P, B, Bphi: 7.5 * P * B + 2 * Bphi,
+    "adj_x": lambda P, B, Bphi: 7.5 * P * B,
+    "delta_y": lambda P, B, Bphi: 18.0 * P * B + 2 * Bphi,         # f part (10.5) + δf part (7.5) of a δ-flow stage
+    "dphi_y": lambda P, B, Bphi: 19.0 * B + 5 * Bphi,              # δϕ part: w, u, 5 products, y-halves of 5 S0 rffts
+    "dphi_x": lambda P, B, Bphi: 11.0 * B,                         # x-halves, combine, RK update of δϕ
+}
+
+
+def cpu_baseline(N, pol, nsteps):
+    """The NumPy oracle (kind 'port': the Julia reference cannot run here) timed on the host cores: one ∇lnP
+    evaluation of the same workload (bounded sample)."""
+    import oracle as O
+    t0 = time.time()
+    so = O.load_sim(2.0, N, pol, np.float32, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=nsteps)
+    ds = so["ds"]
+    fo, po = ds.mix(so["f"], so["phi"])
+    t_setup = time.time() - t0
+    t0 = time.time()
+    ds._L = None
+    lp, gf, gp = ds.grad_logpdf_mixed(fo, po)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit="steps/s", cores=int(os.environ.get("CMBL_ORACLE_FFT_WORKERS", os.cpu_count() or 1)),
+                kind="port", sample=f"1 ∇logpdf(Mixed) evaluation, {N}² {pol} fp32, NumPy/SciPy-pocketfft oracle "
+                f"({dt:.2f} s; setup {t_setup:.1f} s not counted)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nside", type=int, default=1024)
+    ap.add_argument("--pol", default="P", choices=["I", "P", "IP"])
+    ap.add_argument("--nbatch", type=int, default=1, help="chains per GPU (batch dim 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import cmblensing_jl_amd as C
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+
+    N, pol, B, nrk = args.nside, args.pol, args.nbatch, 7
+    P = {"I": 1, "P": 2, "IP": 3}[pol]
+    # every rank = an independent chain: different simulation seeds per rank (seed = base + chain id)
+    seeds = (1 + 1000 * rank, 2 + 1000 * rank, 3 + 1000 * rank)
+    sim = C.load_sim(2.0, N, pol, synthetic_cls(), T=torch.float32, device=local, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0),
+                     nsteps=nrk, Nbatch=B, seeds=seeds)
+    ds, proj = sim["ds"], sim["proj"]
+    fo, po = ds.mix(sim["f"], sim["phi"])
+
+    def step():
+        return ds.gradient_logpdf_mixed(fo, po)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lp, gf, gp = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lp, gf, gp = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # the trivial result gather: per-chain logpdf scalars to every rank over RCCL
+        mine = torch.tensor(lp, device="cuda", dtype=torch.float64)
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        lps = torch.cat(allp).cpu().numpy()
+    else:
+        lps = np.asarray(lp)
+    assert np.all(np.isfinite(lps)), lps
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    out = {
+        "metric": "LenseFlow+∇logP steps/sec (∇logpdf(Mixed) evaluations/s, LenseFlow n=7, whole job)",
+        "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{N}² flat-sky {pol} (npol={P}), θpix=2′, ∇logpdf(Mixed(ds)) step = precompute + L\\f° + L·f + 2 δ-flows "
+                               f"+ diag/mask/reductions; 1° apodised border mask, LowPass(3000), 3 μK′ noise",
+                   "nside": N, "npol": P, "chains_per_gpu": B, "rk4_steps": nrk, "parallelism": f"{world} independent chains (no data-path collective)"},
+        "logpdf": [float(x) for x in lps],
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # roofline of the dominant kernel: per-launch HIP events on the library's stream over a re-run of the same K steps
+        proj.prof_reset(); proj.prof_enable(True)
+        for _ in range(args.steps):
+            step()
+        proj.prof_enable(False)
+        tab = proj.prof_table()
+        tot = sum(v[0] for v in tab.values())
+        dom = max((k for k in tab if k in KERNEL_SHARE), key=lambda k: tab[k][0])
+        ms, nl = tab[dom]
+        ab = algorithmic_bytes(N, P, B, B, nrk, 4)
+        bytes_per_launch = KERNEL_SHARE[dom](P, B, B) * ab["map_pass"]
+        achieved = bytes_per_launch / (ms / nl * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                           "traffic": None, "avg_launch_us": ms / nl * 1e3, "launches_per_step": nl / args.steps,
+                           "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "kernel_time_share": ms / tot,
+                           "whole_step": {"algorithmic_GB": ab["grad_lnP"] / 1e9,
+                                          "achieved_GB_per_s": ab["grad_lnP"] / 1e9 / (ms_per_step * 1e-3),
+                                          "frac": ab["grad_lnP"] / 1e9 / (ms_per_step * 1e-3) / 8000.0},
+                           "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, pol, nrk)
+    if rank == 0:
+        print(json.dumps(out, ensure_ascii=False))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

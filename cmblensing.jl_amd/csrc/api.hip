@@ -130,6 +130,21 @@ int cmbl_ctx_create(int Ny, int Nx, double theta, int dtype, int device, void* s
 int cmbl_ctx_destroy(cmbl_ctx* ctx) { return guard([&] { delete ctx; }); }
 int cmbl_ctx_synchronize(cmbl_ctx* ctx) { return guard([&] { NOTNULL(ctx); CMBL_HIP(hipStreamSynchronize(ctx->p->stream)); }); }
 
+int cmbl_prof_enable(cmbl_ctx* ctx, int on) {
+  return guard([&] { NOTNULL(ctx); if (!on) ctx->p->prof_collect(); ctx->p->prof_on = on != 0; });
+}
+int cmbl_prof_reset(cmbl_ctx* ctx) { return guard([&] { NOTNULL(ctx); ctx->p->prof_collect(); ctx->p->prof_reset(); }); }
+int cmbl_prof_count(void) { return K_COUNT; }
+const char* cmbl_prof_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
+int cmbl_prof_get(cmbl_ctx* ctx, int k, double* total_ms, long* launches) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(total_ms); NOTNULL(launches);
+    CMBL_REQUIRE(k >= 0 && k < K_COUNT, ERR_ARG, "bad kernel class");
+    ctx->p->prof_collect();
+    *total_ms = ctx->p->prof_ms[k]; *launches = ctx->p->prof_n[k];
+  });
+}
+
 int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out, size_t n) {
   return guard([&] {
     NOTNULL(ctx); NOTNULL(out);

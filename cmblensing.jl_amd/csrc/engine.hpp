@@ -22,10 +22,18 @@ inline void raise_lds_limit(const void* fn, size_t bytes) {
   CMBL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   done[fn] = bytes;
 }
-#define CMBL_LAUNCH(kernel, grid, lds, stream, ...)                                   \
+// kernel classes for the optional per-launch event timing (cmbl_prof_*)
+enum KernelId { K_LAYOUT = 0, K_Y_R2C, K_Y_C2R, K_X_FFT, K_X_GRAD, K_FLOW_Y, K_ADJ_Y, K_ADJ_X, K_DELTA_Y, K_DPHI_Y, K_DPHI_X,
+                K_GRADHESS, K_HARM, K_LINCOMB, K_MASK, K_REDUCE, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_y",
+                                                  "dphi_y", "dphi_x", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce"};
+
+#define CMBL_LAUNCH(ctxp, kid, kernel, grid, lds, stream, ...)                         \
   do {                                                                                \
     raise_lds_limit(reinterpret_cast<const void*>(kernel), (lds));                    \
+    (ctxp)->prof_begin(kid);                                                          \
     hipLaunchKernelGGL(kernel, grid, dim3(NT), (lds), (stream), __VA_ARGS__);         \
+    (ctxp)->prof_end(kid);                                                            \
     CMBL_HIP(hipGetLastError());                                                      \
   } while (0)
 
@@ -35,7 +43,39 @@ struct CtxBase {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::vector<double> h_lx, h_ly, h_lam, h_sin2, h_cos2, h_lmag;   // reference layout ([x][ky] planes)
-  virtual ~CtxBase() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+  // optional per-launch timing with HIP events on the context's stream (bench.py roofline leg)
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[K_COUNT];
+  size_t prof_used[K_COUNT] = {};
+  double prof_ms[K_COUNT] = {};
+  long prof_n[K_COUNT] = {};
+  void prof_begin(int k) {
+    if (!prof_on) return;
+    if (prof_used[k] == prof_ev[k].size()) {
+      hipEvent_t a, b; CMBL_HIP(hipEventCreate(&a)); CMBL_HIP(hipEventCreate(&b)); prof_ev[k].push_back({a, b});
+    }
+    CMBL_HIP(hipEventRecord(prof_ev[k][prof_used[k]].first, stream));
+  }
+  void prof_end(int k) {
+    if (!prof_on) return;
+    CMBL_HIP(hipEventRecord(prof_ev[k][prof_used[k]].second, stream));
+    ++prof_used[k];
+  }
+  void prof_collect() {                         // synchronises; folds recorded pairs into the totals
+    CMBL_HIP(hipStreamSynchronize(stream));
+    for (int k = 0; k < K_COUNT; ++k) {
+      for (size_t i = 0; i < prof_used[k]; ++i) {
+        float ms = 0; CMBL_HIP(hipEventElapsedTime(&ms, prof_ev[k][i].first, prof_ev[k][i].second));
+        prof_ms[k] += ms; ++prof_n[k];
+      }
+      prof_used[k] = 0;
+    }
+  }
+  void prof_reset() { for (int k = 0; k < K_COUNT; ++k) { prof_used[k] = 0; prof_ms[k] = 0; prof_n[k] = 0; } }
+  virtual ~CtxBase() {
+    for (auto& v : prof_ev) for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
   long plane() const { return (long)Nyh * Nx; }
   long npix() const { return (long)Ny * Nx; }
 };
@@ -127,27 +167,27 @@ struct Ctx : CtxBase {
 
   // ---- layout / transform primitives (all on `stream`) -----------------------------------------
   void ref2F(const cx<T>* in, cx<T>* out, long slices) {
-    CMBL_LAUNCH((k_ref2F<cx<T>>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
+    CMBL_LAUNCH(this, K_LAYOUT, (k_ref2F<cx<T>>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
   }
   void F2ref(const cx<T>* in, cx<T>* out, long slices) {
-    CMBL_LAUNCH((k_F2ref<cx<T>>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
+    CMBL_LAUNCH(this, K_LAYOUT, (k_F2ref<cx<T>>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
   }
   void ref2F_real(const T* in, T* out, long slices) {
-    CMBL_LAUNCH((k_ref2F<T>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
+    CMBL_LAUNCH(this, K_LAYOUT, (k_ref2F<T>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
   }
   void y_r2c(const T* map, cx<T>* mixed, long slices) {
     const int C = pickC(slices, false);
-    CMBL_LAUNCH((k_y_r2c<T>), dim3(Nx / C, (unsigned)slices), ldsY(C), stream, map, mixed, twY.as<cx<T>>(), Nx, lgM, C, ilog2(C));
+    CMBL_LAUNCH(this, K_Y_R2C, (k_y_r2c<T>), dim3(Nx / C, (unsigned)slices), ldsY(C), stream, map, mixed, twY.as<cx<T>>(), Nx, lgM, C, ilog2(C));
   }
   void y_c2r(const cx<T>* mixed, T* map, long slices) {
     const int C = pickC(slices, false);
-    CMBL_LAUNCH((k_y_c2r<T>), dim3(Nx / C, (unsigned)slices), ldsY(C), stream, mixed, map, twY.as<cx<T>>(), Nx, lgM, C, ilog2(C),
+    CMBL_LAUNCH(this, K_Y_C2R, (k_y_c2r<T>), dim3(Nx / C, (unsigned)slices), ldsY(C), stream, mixed, map, twY.as<cx<T>>(), Nx, lgM, C, ilog2(C),
                 (T)(1.0 / Ny));
   }
   template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices) {
     const long rows = slices * Nyh;
     const int RX = pickRX(1);
-    CMBL_LAUNCH((k_x_fft<T, MODE>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), stream, in, out, twX.as<cx<T>>(),
+    CMBL_LAUNCH(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), (k_x_fft<T, MODE>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), stream, in, out, twX.as<cx<T>>(),
                 lx_r.as<T>(), lgNx, rows, RX);
   }
   // map -> F  (m_rfft, src/util_fft.jl:20)
@@ -164,9 +204,9 @@ struct Ctx : CtxBase {
     a.kind = kind; a.in_qu = in_qu; a.out_qu = out_qu; a.transpose = transpose; a.alpha = alpha; a.beta = beta;
     a.plane = plane(); a.B = B;
     const dim3 grid((unsigned)((plane() + NT - 1) / NT));
-    if (P == 1) CMBL_LAUNCH((k_harm_apply<T, 1>), grid, 0, stream, a);
-    else if (P == 2) CMBL_LAUNCH((k_harm_apply<T, 2>), grid, 0, stream, a);
-    else CMBL_LAUNCH((k_harm_apply<T, 3>), grid, 0, stream, a);
+    if (P == 1) CMBL_LAUNCH(this, K_HARM, (k_harm_apply<T, 1>), grid, 0, stream, a);
+    else if (P == 2) CMBL_LAUNCH(this, K_HARM, (k_harm_apply<T, 2>), grid, 0, stream, a);
+    else CMBL_LAUNCH(this, K_HARM, (k_harm_apply<T, 3>), grid, 0, stream, a);
   }
 
   // out = a*x + c*y with per-batch scalars (n = reals per batch slot)
@@ -176,7 +216,7 @@ struct Ctx : CtxBase {
       BScal<T> sa{}, sc{};
       for (int i = 0; i < nb; ++i) { sa.v[i] = (T)a[b0 + i]; sc.v[i] = c ? (T)c[b0 + i] : (T)0; }
       const unsigned gx = (unsigned)std::min<long>((n + NT - 1) / NT, 2048);
-      CMBL_LAUNCH((k_lincomb<T>), dim3(gx, nb), 0, stream, out, x, y, sa, sc, n, b0);
+      CMBL_LAUNCH(this, K_LINCOMB, (k_lincomb<T>), dim3(gx, nb), 0, stream, out, x, y, sa, sc, n, b0);
     }
   }
   void lincomb1(T* out, const T* x, const T* y, double a, double c, long n, int B) {
@@ -185,27 +225,27 @@ struct Ctx : CtxBase {
   }
   void mask_mul(T* out, const T* in, const T* m, long slices) {
     const unsigned gx = (unsigned)std::min<long>((npix() + NT - 1) / NT, 2048);
-    CMBL_LAUNCH((k_mask_mul<T>), dim3(gx, (unsigned)slices), 0, stream, out, in, m, npix());
+    CMBL_LAUNCH(this, K_MASK, (k_mask_mul<T>), dim3(gx, (unsigned)slices), 0, stream, out, in, m, npix());
   }
 
   // per-batch reductions -> host doubles (synchronises the stream)
   void finish_reduce(int B, double scale, double* out_host) {
-    CMBL_LAUNCH(k_reduce_final, dim3(B), 0, stream, red_part.as<double>(), red_out.as<double>(), RED_BLOCKS, scale);
+    CMBL_LAUNCH(this, K_REDUCE, k_reduce_final, dim3(B), 0, stream, red_part.as<double>(), red_out.as<double>(), RED_BLOCKS, scale);
     CMBL_HIP(hipMemcpyAsync(out_host, red_out.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream));
     CMBL_HIP(hipStreamSynchronize(stream));
   }
   void dot_F(const cx<T>* a, const cx<T>* b, int P, int B, double* out_host) {
     CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
-    CMBL_LAUNCH((k_dot_F<T>), dim3(RED_BLOCKS, B), 0, stream, a, b, lam.as<T>(), red_part.as<double>(), (long)P * plane(), lgNx, Nyh);
+    CMBL_LAUNCH(this, K_REDUCE, (k_dot_F<T>), dim3(RED_BLOCKS, B), 0, stream, a, b, lam.as<T>(), red_part.as<double>(), (long)P * plane(), lgNx, Nyh);
     finish_reduce(B, 1.0 / ((double)Ny * Nx), out_host);
   }
   void dot_map(const T* a, const T* b, int P, int B, double* out_host) {
     CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
-    CMBL_LAUNCH((k_dot_map<T>), dim3(RED_BLOCKS, B), 0, stream, a, b, red_part.as<double>(), (long)P * npix());
+    CMBL_LAUNCH(this, K_REDUCE, (k_dot_map<T>), dim3(RED_BLOCKS, B), 0, stream, a, b, red_part.as<double>(), (long)P * npix());
     finish_reduce(B, 1.0, out_host);
   }
   void logdet_F(const T* d, int nplanes, double* out_host) {
-    CMBL_LAUNCH((k_logdet_F<T>), dim3(RED_BLOCKS, 1), 0, stream, d, lam.as<T>(), red_part.as<double>(), (long)nplanes * plane(), lgNx, Nyh);
+    CMBL_LAUNCH(this, K_REDUCE, (k_logdet_F<T>), dim3(RED_BLOCKS, 1), 0, stream, d, lam.as<T>(), red_part.as<double>(), (long)nplanes * plane(), lgNx, Nyh);
     finish_reduce(1, 1.0, out_host);
   }
 
@@ -257,7 +297,7 @@ struct Flow {
     gh.ensure(sizeof(cx<T>) * 5 * nb * pl);
     phimaps.ensure(sizeof(T) * 5 * nb * c->npix());
     // multipliers: out[comp][b][plane]
-    CMBL_LAUNCH((k_gradhess_mult<T>), dim3((unsigned)((pl + NT - 1) / NT)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
+    CMBL_LAUNCH(c, K_GRADHESS, (k_gradhess_mult<T>), dim3((unsigned)((pl + NT - 1) / NT)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
                 c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
     c->template x_pass<1>(gh.as<cx<T>>(), gh.as<cx<T>>(), 5L * nb);
     c->y_c2r(gh.as<cx<T>>(), phimaps.as<T>(), 5L * nb);
@@ -282,16 +322,16 @@ struct Flow {
   }
 
   template <int R> void launch_fwd_y(const FlowYArgs<T>& a, long slices, int C) {
-    CMBL_LAUNCH((k_flow_y_fwd<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
+    CMBL_LAUNCH(c, K_FLOW_Y, (k_flow_y_fwd<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
   }
   template <int R> void launch_adj_y(const AdjYArgs<T>& a, long slices, int C) {
-    CMBL_LAUNCH((k_adj_y<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
+    CMBL_LAUNCH(c, K_ADJ_Y, (k_adj_y<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
   }
   template <int R> void launch_delta_y(const DeltaYArgs<T>& a, long slices, int C) {
-    CMBL_LAUNCH((k_delta_y<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
+    CMBL_LAUNCH(c, K_DELTA_Y, (k_delta_y<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
   }
   template <int R> void launch_dphi_y(const DphiYArgs<T>& a, long B, int C) {
-    CMBL_LAUNCH((k_dphi_y<T, R>), dim3(c->Nx / C, (unsigned)B), c->ldsY(C), c->stream, a);
+    CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_y<T, R>), dim3(c->Nx / C, (unsigned)B), c->ldsY(C), c->stream, a);
   }
 #define CMBL_DISPATCH_R(R, fn, ...)                                                      \
   switch (R) {                                                                          \
@@ -354,7 +394,7 @@ struct Flow {
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = out; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
         x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.lgNx = c->lgNx; x.RX = RX; x.rows = rows; x.rk = rk;
-        CMBL_LAUNCH((k_adj_x<T>), dim3((unsigned)((rows + RX - 1) / RX)), c->ldsX(RX, 2), c->stream, x);
+        CMBL_LAUNCH(c, K_ADJ_X, (k_adj_x<T>), dim3((unsigned)((rows + RX - 1) / RX)), c->ldsX(RX, 2), c->stream, x);
       }
   }
 
@@ -396,7 +436,7 @@ struct Flow {
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
         x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.lgNx = c->lgNx; x.RX = RX2; x.rows = rows; x.rk = rk;
-        CMBL_LAUNCH((k_adj_x<T>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
+        CMBL_LAUNCH(c, K_ADJ_X, (k_adj_x<T>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
         // delta-phi
         DphiYArgs<T> py{};
         py.w1p = w1p.as<T>(); py.w2p = w2p.as<T>(); py.Z0 = Z0.as<cx<T>>(); py.Z1 = Z1.as<cx<T>>(); py.Z2 = Z2.as<cx<T>>();
@@ -406,7 +446,7 @@ struct Flow {
         DphiXArgs<T> px{};
         px.Z0 = Z0.as<cx<T>>(); px.Z1 = Z1.as<cx<T>>(); px.Z2 = Z2.as<cx<T>>(); px.Y0 = dphi; px.acc = Pacc.as<cx<T>>();
         px.twX = x.twX; px.lx_r = x.lx_r; px.lgNx = c->lgNx; px.RX = RX3; px.rows = rowsp; px.rk = rk;
-        CMBL_LAUNCH((k_dphi_x<T>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), c->stream, px);
+        CMBL_LAUNCH(c, K_DPHI_X, (k_dphi_x<T>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), c->stream, px);
       }
   }
 

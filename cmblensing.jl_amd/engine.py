@@ -81,6 +81,23 @@ class ProjLambert:
     def synchronize(self):
         check(self.lib.cmbl_ctx_synchronize(self._h))
 
+    # ---- optional per-kernel-class HIP-event timing (cmbl_prof_*)
+    def prof_enable(self, on=True):
+        check(self.lib.cmbl_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.cmbl_prof_reset(self._h))
+
+    def prof_table(self):
+        """{kernel class: (total_ms, launches)} accumulated since the last reset"""
+        out = {}
+        for k in range(self.lib.cmbl_prof_count()):
+            ms, n = ctypes.c_double(0), ctypes.c_long(0)
+            check(self.lib.cmbl_prof_get(self._h, k, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                out[self.lib.cmbl_prof_name(k).decode()] = (ms.value, n.value)
+        return out
+
     # ---- tensors
     def empty(self, basis, P, B):
         if basis == MAP:

@@ -9,7 +9,7 @@ _LIB = None
 # every symbol include/cmblens.h declares (tests/test_boundary.py checks the .so exports exactly these)
 SYMBOLS = [
     "cmbl_last_error", "cmbl_version", "cmbl_ctx_create", "cmbl_ctx_destroy", "cmbl_ctx_synchronize",
-    "cmbl_ctx_geometry_host", "cmbl_rfft", "cmbl_irfft", "cmbl_convert", "cmbl_diag_apply",
+    "cmbl_ctx_geometry_host", "cmbl_prof_enable", "cmbl_prof_reset", "cmbl_prof_count", "cmbl_prof_name", "cmbl_prof_get", "cmbl_rfft", "cmbl_irfft", "cmbl_convert", "cmbl_diag_apply",
     "cmbl_blockdiag_ieb_apply", "cmbl_dot", "cmbl_logdet", "cmbl_lenseflow_create", "cmbl_lenseflow_destroy",
     "cmbl_lenseflow_set_phi", "cmbl_lenseflow_apply", "cmbl_lenseflow_grad", "cmbl_dataset_create",
     "cmbl_dataset_destroy", "cmbl_dataset_set_op", "cmbl_dataset_set_data", "cmbl_dataset_set_logdet",
@@ -58,11 +58,18 @@ def load_library():
     lib.cmbl_last_error.restype = ctypes.c_char_p
     lib.cmbl_last_error.argtypes = []
     lib.cmbl_version.restype = ci
+    lib.cmbl_prof_count.restype = ci
+    lib.cmbl_prof_count.argtypes = []
+    lib.cmbl_prof_name.restype = ctypes.c_char_p
+    lib.cmbl_prof_name.argtypes = [ci]
     sig = {
         "cmbl_ctx_create": [ci, ci, cd, ci, ci, vp, ctypes.POINTER(vp)],
         "cmbl_ctx_destroy": [vp],
         "cmbl_ctx_synchronize": [vp],
         "cmbl_ctx_geometry_host": [vp, ci, pd, ctypes.c_size_t],
+        "cmbl_prof_enable": [vp, ci],
+        "cmbl_prof_reset": [vp],
+        "cmbl_prof_get": [vp, ci, pd, ctypes.POINTER(ctypes.c_long)],
         "cmbl_rfft": [vp, vp, vp, ci, ci],
         "cmbl_irfft": [vp, vp, vp, ci, ci],
         "cmbl_convert": [vp, ci, vp, ci, vp, ci, ci],

@@ -63,6 +63,14 @@ int cmbl_ctx_synchronize(cmbl_ctx* ctx);
  * 3 sin2phi[(Ny/2+1)*Nx], 4 cos2phi[...], 5 lmag[...]  (planes in the reference layout) */
 int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n);
 
+/* ---- optional per-launch timing of the library's kernel classes with HIP events on the context's stream
+ *      (the reference wraps the same call sites in TimerOutputs `@⌛`, src/util.jl:351-390).  Disabled by default. */
+int cmbl_prof_enable(cmbl_ctx* ctx, int on);
+int cmbl_prof_reset(cmbl_ctx* ctx);
+int cmbl_prof_count(void);
+const char* cmbl_prof_name(int kernel_class);
+int cmbl_prof_get(cmbl_ctx* ctx, int kernel_class, double* total_ms_host, long* launches_host);
+
 /* ---- basis transforms: m_rfft / m_irfft and the Basis conversion lattice
  *      (src/util_fft.jl:20-31, src/proj_lambert.jl:245-300) */
 int cmbl_rfft(cmbl_ctx* ctx, const void* map, void* fourier, int npol, int nbatch);

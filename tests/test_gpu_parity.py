@@ -216,11 +216,23 @@ def test_dataset_gradientf_and_wiener(prec, pol, Nside, mask):
     # Wiener filter: same tolerance-based stop; compare solution and history loosely, tight solve tightly
     fw_o, h_o = ods.argmaxf_logpdf(phi, tol=1e-1, nsteps=500)
     fw_g, h_g = ds.argmaxf_logpdf(F(phi, C.FOURIER), tol=1e-1, nsteps=500)
-    assert abs(len(h_g) - len(h_o)) <= 1, (len(h_g), len(h_o))
+    # iteration count depends on round-off (SURVEY §7 'CG reproducibility'): ±1 in fp64, within 5 % in fp32
+    assert abs(len(h_g) - len(h_o)) <= (1 if prec == "f64" else max(2, len(h_o) // 20)), (len(h_g), len(h_o))
     n = min(len(h_g), len(h_o)) - 1
     np.testing.assert_allclose(h_g[0][1], h_o[0][1], rtol=1e-3 if prec == "f32" else 1e-8)
     np.testing.assert_allclose(h_g[n // 2][1], h_o[n // 2][1], rtol=5e-2 if prec == "f32" else 1e-5)
-    assert rel(fw_g.arr.cpu().numpy(), fw_o) < (5e-3 if prec == "f32" else 1e-6)
+    # hundreds of CG iterations amplify round-off (loss of conjugacy): converged solutions agree loosely ...
+    assert rel(fw_g.arr.cpu().numpy(), fw_o) < (5e-3 if prec == "f32" else 1e-4)
+    # ... while a fixed, short run (no early stop) must agree tightly, iterate by iterate
+    fw_o, h_o = ods.argmaxf_logpdf(phi, tol=0.0, nsteps=8)
+    fw_g, h_g = ds.argmaxf_logpdf(F(phi, C.FOURIER), tol=0.0, nsteps=8)
+    assert len(h_g) == len(h_o) == 8
+    for (i, r_g), (_, r_o) in zip(h_g, h_o):
+        np.testing.assert_allclose(r_g, r_o, rtol=2e-3 if prec == "f32" else 1e-8)
+    assert rel(fw_g.arr.cpu().numpy(), fw_o) < (3e-4 if prec == "f32" else 1e-9)
+    # fstart (maximization.jl:26,37): restarting from the 8-step iterate continues to converge
+    fw_g2, h_g2 = ds.argmaxf_logpdf(F(phi, C.FOURIER), fstart=fw_g, tol=1e-1, nsteps=500)
+    assert h_g2[0][1][0] < h_g[0][1][0] and h_g2[-1][1][0] < 1e-1
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
