@@ -9,3 +9,4 @@ from .lib import load_library, library_path, CmblError, build            # noqa:
 from .engine import (ProjLambert, LenseFlow, BaseDataSet, Field, MAP, FOURIER, HARMONIC,   # noqa: F401
                      FLOW_FWD, FLOW_INV, FLOW_ADJ, FLOW_INVADJ)
 from .sim import (Cls, load_sim, noise_cls, beam_cls, lowpass, cl_to_2d, HarmOp, border_mask)   # noqa: F401
+from .chains import partition_chains, chain_seed, gather_chain_values   # noqa: F401
