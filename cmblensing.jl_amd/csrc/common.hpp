@@ -10,7 +10,8 @@
 
 namespace cmbl {
 
-constexpr int NT = 256;            // threads per workgroup for every kernel (4 waves of 64)
+constexpr int NTP = 256;           // threads per workgroup of the pointwise / reduction / layout kernels
+// FFT-carrying kernels take their workgroup size as a template parameter NT (256, 512 or 1024)
 
 template <typename T> struct cx { T x, y; };
 

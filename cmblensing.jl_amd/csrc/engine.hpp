@@ -5,6 +5,8 @@
 #include <cmath>
 #include <map>
 #include <memory>
+#include <type_traits>
+#include <cstdlib>
 #include "kernels_fft.hpp"
 #include "kernels_pointwise.hpp"
 #include "kernels_flow.hpp"
@@ -28,14 +30,26 @@ enum KernelId { K_LAYOUT = 0, K_Y_R2C, K_Y_C2R, K_X_FFT, K_X_GRAD, K_FLOW_Y, K_A
 static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_y",
                                                   "dphi_y", "dphi_x", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce"};
 
-#define CMBL_LAUNCH(ctxp, kid, kernel, grid, lds, stream, ...)                         \
+#define CMBL_LAUNCH_NT(ctxp, kid, nthreads, kernel, grid, lds, stream, ...)            \
   do {                                                                                \
     raise_lds_limit(reinterpret_cast<const void*>(kernel), (lds));                    \
     (ctxp)->prof_begin(kid);                                                          \
-    hipLaunchKernelGGL(kernel, grid, dim3(NT), (lds), (stream), __VA_ARGS__);         \
+    hipLaunchKernelGGL(kernel, grid, dim3(nthreads), (lds), (stream), __VA_ARGS__);   \
     (ctxp)->prof_end(kid);                                                            \
     CMBL_HIP(hipGetLastError());                                                      \
   } while (0)
+#define CMBL_LAUNCH(ctxp, kid, kernel, grid, lds, stream, ...) CMBL_LAUNCH_NT(ctxp, kid, NTP, kernel, grid, lds, stream, __VA_ARGS__)
+
+// compiled column-tile shapes (lgM, R, NT):  C = R*NT >> lgM columns per workgroup
+#ifndef CMBL_COL_LIST
+#define CMBL_COL_LIST(X) X(4, 1, 256) X(5, 1, 256) X(5, 2, 256) X(6, 1, 256) X(6, 2, 256) X(7, 2, 256) X(7, 4, 256) X(8, 4, 256) X(8, 8, 256) \
+                         X(9, 4, 256) X(9, 8, 256) X(9, 16, 256) X(10, 8, 256) X(10, 16, 256) X(11, 8, 1024)
+#endif
+#ifndef CMBL_ROW_LIST
+#define CMBL_ROW_LIST(X) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#endif
+
+inline int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
 
 struct CtxBase {
   int Ny = 0, Nx = 0, Nyh = 0, M = 0, lgM = 0, lgNx = 0, dtype = 0, device = 0;
@@ -144,26 +158,56 @@ struct Ctx : CtxBase {
   }
 
   // ---- launch geometry -----------------------------------------------------------------------
-  // column kernels: C columns per workgroup.  Fused kernels need C*M == R*NT with R in {1,..,32}.
-  int pickC(long slices, bool fused) const {
-    int C = sizeof(T) == 4 ? 8 : 4;
-    while (C > 4 && (long)(Nx / C) * slices < 512) C >>= 1;            // keep >= 2 workgroups per CU when possible
-    if (fused) {
-      while ((long)C * M < NT) C <<= 1;                                 // R >= 1
-      while ((long)C * M > 32L * NT && C > 1) C >>= 1;                  // R <= 32
+  // Column kernels are compiled for the tile shapes of CMBL_COL_LIST: (lgM, R, NT) with C = R*NT/M columns per workgroup of
+  // NT threads and R packed pairs per thread.  Pick the widest tile that still gives >= 2 workgroups per CU, else the narrowest;
+  // CMBL_TUNE_C forces a width, CMBL_TUNE_RX the rows per workgroup of the row kernels (tuning aids).
+  struct TileY { int C, NT, R; };
+  TileY tileY(long slices, bool pair) const {
+    static const int list[][3] = {
+#define CMBL_X(lgm, r, nt) {lgm, r, nt},
+        CMBL_COL_LIST(CMBL_X)
+#undef CMBL_X
+    };
+    const int forceC = env_int("CMBL_TUNE_C", 0);
+    TileY best{0, 0, 0}, narrow{0, 0, 0};
+    for (const auto& e : list) {
+      if (e[0] != lgM) continue;
+      const int C = (int)(((long)e[1] * e[2]) >> lgM);
+      if (C > Nx || ldsY(C, pair) > 160 * 1024) continue;
+      const TileY t{C, e[2], e[1]};
+      if (forceC == C) return t;
+      if (narrow.C == 0 || C < narrow.C) narrow = t;
+      if ((long)(Nx / C) * slices >= 512 && C > best.C) best = t;
     }
-    while (C > Nx) C >>= 1;
-    const size_t lds = ((size_t)M + (size_t)C * (M + 1)) * sizeof(cx<T>);
-    CMBL_REQUIRE(lds <= 160 * 1024, ERR_SHAPE, "column tile does not fit LDS");
-    return C;
+    CMBL_REQUIRE(narrow.C > 0, ERR_SHAPE, "no compiled column-tile shape fits this Ny / precision");
+    return best.C ? best : narrow;
   }
-  size_t ldsY(int C) const { return ((size_t)M + (size_t)C * (M + 1)) * sizeof(cx<T>); }
-  int pickRX(int nbuf) const {
-    const int RX = std::max(1, (int)(4096 / ((long)nbuf * Nx)));
+  // column tile: twiddles + C columns of an N-point (pair) or M-point (packed) transform, padded rows
+  size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
+  int pickRX(int nbuf, long rows) const {
+    int RX = env_int("CMBL_TUNE_RX", 0);
+    if (RX <= 0) RX = (int)std::max<long>(1, std::min<long>(4096 / ((long)nbuf * Nx), rows / 1024));
+    RX = std::max(RX, (int)((256 * 4 + Nx - 1) / Nx));                  // keep every thread busy in a radix-4 stage
+    while (RX > 1 && ldsX(RX, nbuf) > 160 * 1024) RX >>= 1;
     CMBL_REQUIRE(ldsX(RX, nbuf) <= 160 * 1024, ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
     return RX;
   }
-  size_t ldsX(int RX, int nbuf) const { return ((size_t)Nx / 2 + (size_t)nbuf * RX * Nx) * sizeof(cx<T>); }
+  size_t ldsX(int RX, int nbuf) const { return ((size_t)Nx / 2 + (size_t)nbuf * RX * tile_ld(Nx)) * sizeof(cx<T>); }
+
+  template <typename Fn> void dispatch_col(const TileY& t, Fn&& fn) const {
+    bool done = false;
+#define CMBL_X(lgm, r, nt) if (!done && lgM == lgm && t.R == r && t.NT == nt) { fn(std::integral_constant<int, lgm>{}, std::integral_constant<int, r>{}, std::integral_constant<int, nt>{}); done = true; }
+    CMBL_COL_LIST(CMBL_X)
+#undef CMBL_X
+    if (!done) fail(ERR_SHAPE, "unsupported column tile");
+  }
+  template <typename Fn> void dispatch_row(Fn&& fn) const {
+    bool done = false;
+#define CMBL_X(lgnx) if (!done && lgNx == lgnx) { fn(std::integral_constant<int, lgnx>{}); done = true; }
+    CMBL_ROW_LIST(CMBL_X)
+#undef CMBL_X
+    if (!done) fail(ERR_SHAPE, "unsupported Nx");
+  }
 
   // ---- layout / transform primitives (all on `stream`) -----------------------------------------
   void ref2F(const cx<T>* in, cx<T>* out, long slices) {
@@ -176,19 +220,27 @@ struct Ctx : CtxBase {
     CMBL_LAUNCH(this, K_LAYOUT, (k_ref2F<T>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
   }
   void y_r2c(const T* map, cx<T>* mixed, long slices) {
-    const int C = pickC(slices, false);
-    CMBL_LAUNCH(this, K_Y_R2C, (k_y_r2c<T>), dim3(Nx / C, (unsigned)slices), ldsY(C), stream, map, mixed, twY.as<cx<T>>(), Nx, lgM, C, ilog2(C));
+    const TileY t = tileY(slices, false);
+    dispatch_col(t, [&](auto lgm, auto r, auto nt) {
+      constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+      CMBL_LAUNCH_NT(this, K_Y_R2C, NT, (k_y_r2c<T, R, NT, LGM>), dim3(Nx / t.C, (unsigned)slices), ldsY(t.C, false), stream, map, mixed, twY.as<cx<T>>(), Nx);
+    });
   }
   void y_c2r(const cx<T>* mixed, T* map, long slices) {
-    const int C = pickC(slices, false);
-    CMBL_LAUNCH(this, K_Y_C2R, (k_y_c2r<T>), dim3(Nx / C, (unsigned)slices), ldsY(C), stream, mixed, map, twY.as<cx<T>>(), Nx, lgM, C, ilog2(C),
-                (T)(1.0 / Ny));
+    const TileY t = tileY(slices, false);
+    dispatch_col(t, [&](auto lgm, auto r, auto nt) {
+      constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+      CMBL_LAUNCH_NT(this, K_Y_C2R, NT, (k_y_c2r<T, R, NT, LGM>), dim3(Nx / t.C, (unsigned)slices), ldsY(t.C, false), stream, mixed, map, twY.as<cx<T>>(), Nx, (T)(1.0 / Ny));
+    });
   }
   template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices) {
     const long rows = slices * Nyh;
-    const int RX = pickRX(1);
-    CMBL_LAUNCH(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), (k_x_fft<T, MODE>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), stream, in, out, twX.as<cx<T>>(),
-                lx_r.as<T>(), lgNx, rows, RX);
+    const int RX = pickRX(1, rows);
+    dispatch_row([&](auto lgnx) {
+      constexpr int LGNX = decltype(lgnx)::value;
+      CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), 256, (k_x_fft<T, MODE, 256, LGNX>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), stream, in, out,
+                     twX.as<cx<T>>(), lx_r.as<T>(), rows, RX);
+    });
   }
   // map -> F  (m_rfft, src/util_fft.jl:20)
   void rfft2_F(const T* map, cx<T>* F, long slices) { y_r2c(map, F, slices); x_pass<0>(F, F, slices); }
@@ -203,7 +255,7 @@ struct Ctx : CtxBase {
     for (int k = 0; k < 5; ++k) a.d[k] = d ? d[k] : nullptr;
     a.kind = kind; a.in_qu = in_qu; a.out_qu = out_qu; a.transpose = transpose; a.alpha = alpha; a.beta = beta;
     a.plane = plane(); a.B = B;
-    const dim3 grid((unsigned)((plane() + NT - 1) / NT));
+    const dim3 grid((unsigned)((plane() + NTP - 1) / NTP));
     if (P == 1) CMBL_LAUNCH(this, K_HARM, (k_harm_apply<T, 1>), grid, 0, stream, a);
     else if (P == 2) CMBL_LAUNCH(this, K_HARM, (k_harm_apply<T, 2>), grid, 0, stream, a);
     else CMBL_LAUNCH(this, K_HARM, (k_harm_apply<T, 3>), grid, 0, stream, a);
@@ -215,7 +267,7 @@ struct Ctx : CtxBase {
       const int nb = std::min(MAXB, B - b0);
       BScal<T> sa{}, sc{};
       for (int i = 0; i < nb; ++i) { sa.v[i] = (T)a[b0 + i]; sc.v[i] = c ? (T)c[b0 + i] : (T)0; }
-      const unsigned gx = (unsigned)std::min<long>((n + NT - 1) / NT, 2048);
+      const unsigned gx = (unsigned)std::min<long>((n + NTP - 1) / NTP, 2048);
       CMBL_LAUNCH(this, K_LINCOMB, (k_lincomb<T>), dim3(gx, nb), 0, stream, out, x, y, sa, sc, n, b0);
     }
   }
@@ -224,7 +276,7 @@ struct Ctx : CtxBase {
     lincomb(out, x, y, va.data(), vc.data(), n, B);
   }
   void mask_mul(T* out, const T* in, const T* m, long slices) {
-    const unsigned gx = (unsigned)std::min<long>((npix() + NT - 1) / NT, 2048);
+    const unsigned gx = (unsigned)std::min<long>((npix() + NTP - 1) / NTP, 2048);
     CMBL_LAUNCH(this, K_MASK, (k_mask_mul<T>), dim3(gx, (unsigned)slices), 0, stream, out, in, m, npix());
   }
 
@@ -297,7 +349,7 @@ struct Flow {
     gh.ensure(sizeof(cx<T>) * 5 * nb * pl);
     phimaps.ensure(sizeof(T) * 5 * nb * c->npix());
     // multipliers: out[comp][b][plane]
-    CMBL_LAUNCH(c, K_GRADHESS, (k_gradhess_mult<T>), dim3((unsigned)((pl + NT - 1) / NT)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
+    CMBL_LAUNCH(c, K_GRADHESS, (k_gradhess_mult<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
                 c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
     c->template x_pass<1>(gh.as<cx<T>>(), gh.as<cx<T>>(), 5L * nb);
     c->y_c2r(gh.as<cx<T>>(), phimaps.as<T>(), 5L * nb);
@@ -321,26 +373,6 @@ struct Flow {
     return r;
   }
 
-  template <int R> void launch_fwd_y(const FlowYArgs<T>& a, long slices, int C) {
-    CMBL_LAUNCH(c, K_FLOW_Y, (k_flow_y_fwd<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
-  }
-  template <int R> void launch_adj_y(const AdjYArgs<T>& a, long slices, int C) {
-    CMBL_LAUNCH(c, K_ADJ_Y, (k_adj_y<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
-  }
-  template <int R> void launch_delta_y(const DeltaYArgs<T>& a, long slices, int C) {
-    CMBL_LAUNCH(c, K_DELTA_Y, (k_delta_y<T, R>), dim3(c->Nx / C, (unsigned)slices), c->ldsY(C), c->stream, a);
-  }
-  template <int R> void launch_dphi_y(const DphiYArgs<T>& a, long B, int C) {
-    CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_y<T, R>), dim3(c->Nx / C, (unsigned)B), c->ldsY(C), c->stream, a);
-  }
-#define CMBL_DISPATCH_R(R, fn, ...)                                                      \
-  switch (R) {                                                                          \
-    case 1: fn<1>(__VA_ARGS__); break;  case 2: fn<2>(__VA_ARGS__); break;                \
-    case 4: fn<4>(__VA_ARGS__); break;  case 8: fn<8>(__VA_ARGS__); break;                \
-    case 16: fn<16>(__VA_ARGS__); break; case 32: fn<32>(__VA_ARGS__); break;             \
-    default: fail(ERR_SHAPE, "unsupported tile shape");                                  \
-  }
-
   void check_ready(int B) const {
     CMBL_REQUIRE(Bphi >= 1, ERR_STATE, "cmbl_lenseflow_set_phi has not been called");
     CMBL_REQUIRE(Bphi == 1 || Bphi == B, ERR_SHAPE, "nbatch of phi must be 1 or equal to nbatch of f");
@@ -356,7 +388,7 @@ struct Flow {
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
     cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
     c->y_r2c(y, a_cur, slices);
-    const int C = c->pickC(slices, true), R = C * c->M / NT;
+    const auto tile = c->tileY(slices, true);
     const double t0 = inverse ? 1.0 : 0.0, h = (inverse ? -1.0 : 1.0) / n;
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
@@ -364,9 +396,12 @@ struct Flow {
         FlowYArgs<T> a{};
         a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = y; a.acc = acc.as<T>(); a.ph = ph();
         a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
-        a.Nx = c->Nx; a.lgM = c->lgM; a.C = C; a.lgC = ilog2(C); a.P = P;
+        a.Nx = c->Nx; a.P = P;
         a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
-        CMBL_DISPATCH_R(R, launch_fwd_y, a, slices, C);
+        c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
+          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+          CMBL_LAUNCH_NT(c, K_FLOW_Y, NT, (k_flow_y_fwd<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, a);
+        });
         std::swap(a_cur, a_nxt);
       }
   }
@@ -379,9 +414,9 @@ struct Flow {
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     c->template x_pass<1>(out, H.as<cx<T>>(), slices);
-    const int C = c->pickC(slices, true), R = C * c->M / NT;
-    const int RX = c->pickRX(2);
+    const auto tile = c->tileY(slices, true);
     const long rows = slices * c->Nyh;
+    const int RX = c->pickRX(2, rows);
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
@@ -389,12 +424,17 @@ struct Flow {
         AdjYArgs<T> a{};
         a.H = H.as<cx<T>>(); a.Wx = Wx.as<cx<T>>(); a.Wy = Wy.as<cx<T>>(); a.ph = ph();
         a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
-        a.Nx = c->Nx; a.lgM = c->lgM; a.C = C; a.lgC = ilog2(C); a.P = P; a.t = rk.t;
-        CMBL_DISPATCH_R(R, launch_adj_y, a, slices, C);
+        a.Nx = c->Nx; a.P = P; a.t = rk.t;
+        c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
+          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+          CMBL_LAUNCH_NT(c, K_ADJ_Y, NT, (k_adj_y<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, a);
+        });
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = out; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
-        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.lgNx = c->lgNx; x.RX = RX; x.rows = rows; x.rk = rk;
-        CMBL_LAUNCH(c, K_ADJ_X, (k_adj_x<T>), dim3((unsigned)((rows + RX - 1) / RX)), c->ldsX(RX, 2), c->stream, x);
+        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.rows = rows; x.rk = rk;
+        c->dispatch_row([&](auto lgnx) {
+          CMBL_LAUNCH_NT(c, K_ADJ_X, 256, (k_adj_x<T, 256, decltype(lgnx)::value>), dim3((unsigned)((rows + RX - 1) / RX)), c->ldsX(RX, 2), c->stream, x);
+        });
       }
   }
 
@@ -414,10 +454,9 @@ struct Flow {
     cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
     c->y_r2c(f, a_cur, slices);
     c->template x_pass<1>(df, H.as<cx<T>>(), slices);
-    const int C = c->pickC(slices, true), R = C * c->M / NT;
-    const int Cp = c->pickC(B, true), Rp = Cp * c->M / NT;
-    const int RX2 = c->pickRX(2), RX3 = c->pickRX(3);
+    const auto tile = c->tileY(slices, true), tilep = c->tileY(B, true);
     const long rows = slices * c->Nyh, rowsp = (long)B * c->Nyh;
+    const int RX2 = c->pickRX(2, rows), RX3 = c->pickRX(3, rowsp);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
@@ -428,25 +467,35 @@ struct Flow {
         FlowYArgs<T>& a = d.f;
         a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = f; a.acc = acc.as<T>(); a.ph = ph();
         a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
-        a.Nx = c->Nx; a.lgM = c->lgM; a.C = C; a.lgC = ilog2(C); a.P = P; a.rk = rk;
+        a.Nx = c->Nx; a.P = P; a.rk = rk;
         d.H = H.as<cx<T>>(); d.Wx = Wx.as<cx<T>>(); d.Wy = Wy.as<cx<T>>(); d.w1p = w1p.as<T>(); d.w2p = w2p.as<T>();
-        CMBL_DISPATCH_R(R, launch_delta_y, d, slices, C);
+        c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
+          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+          CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_y<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, d);
+        });
         std::swap(a_cur, a_nxt);
         // delta-f row pass (RK update of df + next H)
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
-        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.lgNx = c->lgNx; x.RX = RX2; x.rows = rows; x.rk = rk;
-        CMBL_LAUNCH(c, K_ADJ_X, (k_adj_x<T>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
+        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX2; x.rows = rows; x.rk = rk;
+        c->dispatch_row([&](auto lgnx) {
+          CMBL_LAUNCH_NT(c, K_ADJ_X, 256, (k_adj_x<T, 256, decltype(lgnx)::value>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
+        });
         // delta-phi
         DphiYArgs<T> py{};
         py.w1p = w1p.as<T>(); py.w2p = w2p.as<T>(); py.Z0 = Z0.as<cx<T>>(); py.Z1 = Z1.as<cx<T>>(); py.Z2 = Z2.as<cx<T>>();
-        py.ph = ph(); py.twY = a.twY; py.ly = a.ly; py.Nx = c->Nx; py.lgM = c->lgM; py.C = Cp; py.lgC = ilog2(Cp); py.P = P;
+        py.ph = ph(); py.twY = a.twY; py.ly = a.ly; py.Nx = c->Nx; py.P = P;
         py.alias_quirk = alias_quirk ? 1 : 0; py.t = rk.t;
-        CMBL_DISPATCH_R(Rp, launch_dphi_y, py, B, Cp);
+        c->dispatch_col(tilep, [&](auto lgm, auto r, auto nt) {
+          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+          CMBL_LAUNCH_NT(c, K_DPHI_Y, NT, (k_dphi_y<T, R, NT, LGM>), dim3(c->Nx / tilep.C, (unsigned)B), c->ldsY(tilep.C), c->stream, py);
+        });
         DphiXArgs<T> px{};
         px.Z0 = Z0.as<cx<T>>(); px.Z1 = Z1.as<cx<T>>(); px.Z2 = Z2.as<cx<T>>(); px.Y0 = dphi; px.acc = Pacc.as<cx<T>>();
-        px.twX = x.twX; px.lx_r = x.lx_r; px.lgNx = c->lgNx; px.RX = RX3; px.rows = rowsp; px.rk = rk;
-        CMBL_LAUNCH(c, K_DPHI_X, (k_dphi_x<T>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), c->stream, px);
+        px.twX = x.twX; px.lx_r = x.lx_r; px.RX = RX3; px.rows = rowsp; px.rk = rk;
+        c->dispatch_row([&](auto lgnx) {
+          CMBL_LAUNCH_NT(c, K_DPHI_X, 256, (k_dphi_x<T, 256, decltype(lgnx)::value>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), c->stream, px);
+        });
       }
   }
 

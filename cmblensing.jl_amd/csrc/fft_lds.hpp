@@ -1,124 +1,175 @@
-// In-LDS FFT building blocks (workgroup-cooperative, NT threads, runtime sizes).
+// In-LDS FFT building blocks (workgroup-cooperative, NT threads, compile-time sizes).
 //
-// Conventions (prototype + index-math check: tools/fft_proto.py):
-//   forward  = e^{-i}, in-place radix-2^2 DIF : natural order in  -> bit-reversed order out
-//   inverse  = e^{+i}, in-place radix-2^2 DIT : bit-reversed in   -> natural order out (unnormalised)
-// so a forward/pointwise/inverse chain never needs a reordering pass; frequency-domain data simply
-// lives at LDS slot brev(k).  Real transforms of length N=2M use the packed trick (M complex points);
-// the half-spectrum A[0..M] sits at slots brev(k) for k<M and slot M for k=M (tile leading dim LD>=M+1).
-// c2r drops Im A[0] and Im A[M] exactly like FFTW / pocketfft / cuFFT do (src/util_fft.jl:21-25 path).
+// Conventions (index math prototyped in tools/fft_proto.py):
+//   forward  = e^{-i}, in-place radix-2 DIF network : natural order in  -> bit-reversed order out
+//   inverse  = e^{+i}, in-place radix-2 DIT network : bit-reversed in   -> natural order out (unnormalised)
+// so a forward/pointwise/inverse chain never needs a reordering pass: frequency k lives at slot brev(k).
+// Up to four radix-2 levels are fused per LDS round trip: a thread pulls 2^LG elements into registers, runs LG levels of
+// the in-place network on them (radix-16 for LG=4) and writes them back, so a 1024-point transform is 3 round trips / 3
+// barriers.  Element i of a sequence lives at LDS index pad(i) = i + (i >> 4): the one-in-sixteen padding spreads the
+// power-of-two strides of bit-reversed and butterfly accesses over the 64 banks.  All sizes are template parameters, so
+// every LDS address inside a stage is `pad(base) + immediate` and every twiddle index is a constant shift.
 //
-// A "tile" is S sequences of LD complex slots each.  tw[] is an LDS table exp(-2*pi*i*k/Ntw), k<Ntw/2;
-// a transform of length n uses stride Ntw/n into it.
+// Real data, two flavours:
+//   * single: a length-N real sequence as an N/2-point complex transform (r2c_post / c2r_pre); half spectrum A[0..M] at
+//     slots brev(k) (k<M) and M.
+//   * pair:   two real sequences a, b as ONE N-point complex transform of a + i b (pair_* helpers in kernels_fft.hpp).
+// c2r drops Im A[0] and Im A[M] exactly like FFTW / pocketfft / cuFFT do (the src/util_fft.jl:21-25 path relies on it:
+// the reference feeds irfft non-Hermitian input, src/proj_lambert.jl:63-64).
+//
+// tw[] is an LDS table exp(-2*pi*i*k/Ntw), k < Ntw/2 (Ntw = 2^LGNTW); a transform of length n <= Ntw uses stride Ntw/n.
 #pragma once
 #include "common.hpp"
 
 namespace cmbl {
 
-template <typename T>
+__device__ __host__ __forceinline__ constexpr int pad(int i) { return i + (i >> 4); }
+// leading dimension (in complex slots) of a tile row holding n elements (+1 spare slot for the packed-real Nyquist term)
+__device__ __host__ __forceinline__ constexpr int tile_ld(int n) { return pad(n) + 1; }
+template <int LG> __device__ __forceinline__ int brevc(int i) { return LG == 0 ? 0 : (int)(__brev((unsigned)i) >> (32 - (LG == 0 ? 1 : LG))); }
+
+template <typename T, int NT>
 __device__ __forceinline__ void load_twiddles(cx<T>* tw_lds, const cx<T>* __restrict__ tw_g, int nhalf) {
   for (int i = threadIdx.x; i < nhalf; i += NT) tw_lds[i] = tw_g[i];
 }
 
-// ---- forward, DIF ------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void fft_dif(cx<T>* __restrict__ s, int S, int LD, int lgN,
-                                        const cx<T>* __restrict__ tw, int lgNtw) {
-  const int N = 1 << lgN;
-  int lgh = lgN - 1;                                   // h = 2^lgh : span of the first radix-2 level
-  // fused pairs of levels (spans h and h/2)
-  for (; lgh >= 1; lgh -= 2) {
-    const int h = 1 << lgh, hh = h >> 1;
-    const int tws1 = lgNtw - (lgh + 1);                // W_{2h}^j = tw[j << tws1]
-    const int nq = N >> 2;
-    for (int q = threadIdx.x; q < S * nq; q += NT) {
-      const int seq = q >> (lgN - 2), r = q & (nq - 1);
-      const int blk = r >> (lgh - 1), j = r & (hh - 1);
-      cx<T>* p = s + seq * LD + (blk << (lgh + 1)) + j;
-      cx<T> x0 = p[0], x1 = p[hh], x2 = p[h], x3 = p[h + hh];
-      const cx<T> w1 = tw[j << tws1];
-      const cx<T> w2 = tw[j << (tws1 + 1)];
-      cx<T> u0 = x0 + x2, u2 = (x0 - x2) * w1;
-      cx<T> u1 = x1 + x3, u3 = mul_mi((x1 - x3) * w1);      // W_{2h}^{j+h/2} = -i W_{2h}^j
-      p[0] = u0 + u1;       p[hh] = (u0 - u1) * w2;
-      p[h] = u2 + u3;       p[h + hh] = (u2 - u3) * w2;
+// exp(-2 pi i k/16), k = 0..7 (compile-time after unrolling)
+template <typename T> __device__ __forceinline__ cx<T> root16(int k) {
+  constexpr double c[8] = {1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0,
+                           -0.38268343236508977, -0.70710678118654752, -0.92387953251128674};
+  constexpr double s[8] = {0.0, -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
+                           -0.92387953251128674, -0.70710678118654752, -0.38268343236508977};
+  return mk<T>((T)c[k], (T)s[k]);
+}
+template <typename T> __device__ __forceinline__ cx<T> mul_root16(cx<T> a, int k) {       // a * exp(-2 pi i k/16)
+  if (k == 0) return a;
+  if (k == 4) return mul_mi(a);
+  return a * root16<T>(k);
+}
+template <typename T> __device__ __forceinline__ cx<T> mul_root16c(cx<T> a, int k) {      // a * exp(+2 pi i k/16)
+  if (k == 0) return a;
+  if (k == 4) return mul_i(a);
+  return cmulconj(a, root16<T>(k));
+}
+
+// ---- stage schedule: levels per stage as even as possible over ceil(lgN/4) stages (9 -> 3,3,3 ; 10 -> 4,3,3 ; 5 -> 3,2)
+constexpr int stage_levels(int remaining) { return (remaining + ((remaining + 3) >> 2) - 1) / ((remaining + 3) >> 2); }
+constexpr int num_stages(int lgN) { int n = 0; while (lgN > 0) { lgN -= stage_levels(lgN); ++n; } return n; }
+constexpr int stage_lg(int lgN, int idx) { int lg = 0; for (int i = 0; i <= idx; ++i) { lg = stage_levels(lgN); lgN -= lg; } return lg; }
+constexpr int levels_after(int lgN, int idx) { int tot = 0; for (int i = 0; i <= idx; ++i) tot += stage_lg(lgN, i); return lgN - tot; }
+
+// One fused DIF stage: LG radix-2 levels with spans h = 2^LGH (top) ... hmin = 2^(LGH-LG+1).
+template <typename T, int NT, int LD, int LGN, int LGNTW, int LGH, int LG>
+__device__ __forceinline__ void dif_stage(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
+  constexpr int r = 1 << LG, lghmin = LGH - LG + 1, hmin = 1 << lghmin, lgnb = LGN - LG;
+  for (int q = threadIdx.x; q < (S << lgnb); q += NT) {
+    const int seq = q >> lgnb, rr = q & ((1 << lgnb) - 1);
+    const int blk = rr >> lghmin, j = rr & (hmin - 1);
+    cx<T>* p = s + seq * LD + pad((blk << (LGH + 1)) + j);
+    cx<T> v[r];
+#pragma unroll
+    for (int m = 0; m < r; ++m) v[m] = p[pad(m << lghmin)];       // pad(base + m*hmin) == pad(base) + pad(m*hmin) here
+#pragma unroll
+    for (int t = 0; t < LG; ++t) {
+      // level t: span h_t = h >> t ; pairs (m, m + r/2^(t+1)) inside groups of r/2^t
+      const cx<T> w = tw[j << (LGNTW - (LGH - t) - 1)];            // W_{2 h_t}^j
+      const int half = r >> (t + 1);
+#pragma unroll
+      for (int m = 0; m < r; ++m) {
+        if ((m & half) == 0) {
+          const int mp = m & (half - 1);                            // position inside the half group
+          const cx<T> a = v[m], b = v[m + half];
+          v[m] = a + b;
+          // twiddle W_{2h_t}^{j + mp*hmin} = w * W_{r/2^t}^{mp} = w * root16^(mp * 16 / (r >> t))
+          v[m + half] = mul_root16((a - b) * w, mp << (4 - (LG - t)));
+        }
+      }
     }
-    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < r; ++m) p[pad(m << lghmin)] = v[m];
   }
-  if (lgh == 0) {                                      // odd log2: last plain radix-2 level, h = 1, w = 1
-    const int nb = N >> 1;
-    for (int q = threadIdx.x; q < S * nb; q += NT) {
-      const int seq = q >> (lgN - 1), r = q & (nb - 1);
-      cx<T>* p = s + seq * LD + (r << 1);
-      cx<T> a = p[0], b = p[1];
-      p[0] = a + b; p[1] = a - b;
+  __syncthreads();
+}
+
+// One fused DIT stage: LG levels with spans hmin = 2^LGH (bottom) ... hmin * 2^(LG-1).
+template <typename T, int NT, int LD, int LGN, int LGNTW, int LGH, int LG>
+__device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
+  constexpr int r = 1 << LG, hmin = 1 << LGH, lgnb = LGN - LG;
+  for (int q = threadIdx.x; q < (S << lgnb); q += NT) {
+    const int seq = q >> lgnb, rr = q & ((1 << lgnb) - 1);
+    const int blk = rr >> LGH, j = rr & (hmin - 1);
+    cx<T>* p = s + seq * LD + pad((blk << (LGH + LG)) + j);
+    cx<T> v[r];
+#pragma unroll
+    for (int m = 0; m < r; ++m) v[m] = p[pad(m << LGH)];
+#pragma unroll
+    for (int t = 0; t < LG; ++t) {
+      // level t: span h_t = hmin << t ; pairs (m, m + 2^t) inside groups of 2^(t+1)
+      const cx<T> w = tw[j << (LGNTW - (LGH + t) - 1)];            // W_{2 h_t}^j  (conjugated below)
+      const int half = 1 << t;
+#pragma unroll
+      for (int m = 0; m < r; ++m) {
+        if ((m & half) == 0) {
+          const int mp = m & (half - 1);
+          const cx<T> a = v[m];
+          // conj( W_{2h_t}^{j + mp*hmin} ) = conj(w) * conj(W_{2^(t+1)}^{mp})
+          const cx<T> b = mul_root16c(cmulconj(v[m + half], w), mp << (4 - (t + 1)));
+          v[m] = a + b;
+          v[m + half] = a - b;
+        }
+      }
     }
-    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < r; ++m) p[pad(m << LGH)] = v[m];
+  }
+  __syncthreads();
+}
+
+// ---- forward, DIF: natural -> bit-reversed -------------------------------------------------------
+template <typename T, int NT, int LD, int LGN, int LGNTW, int I = 0>
+__device__ __forceinline__ void fft_dif(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
+  if constexpr (I < num_stages(LGN)) {
+    constexpr int LG = stage_lg(LGN, I);
+    constexpr int LGH = levels_after(LGN, I) + LG - 1;             // top span index of this stage
+    dif_stage<T, NT, LD, LGN, LGNTW, LGH, LG>(s, S, tw);
+    fft_dif<T, NT, LD, LGN, LGNTW, I + 1>(s, S, tw);
   }
 }
 
-// ---- inverse, DIT ------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, int LD, int lgN,
-                                        const cx<T>* __restrict__ tw, int lgNtw) {
-  const int N = 1 << lgN;
-  int lgh = 0;
-  if (lgN & 1) {                                       // odd log2: first plain radix-2 level, h = 1
-    const int nb = N >> 1;
-    for (int q = threadIdx.x; q < S * nb; q += NT) {
-      const int seq = q >> (lgN - 1), r = q & (nb - 1);
-      cx<T>* p = s + seq * LD + (r << 1);
-      cx<T> a = p[0], b = p[1];
-      p[0] = a + b; p[1] = a - b;
-    }
-    __syncthreads();
-    lgh = 1;
-  }
-  for (; lgh + 1 < lgN + 0 && lgh + 2 <= lgN; lgh += 2) {   // fused levels with spans h and 2h
-    const int h = 1 << lgh;
-    const int tws1 = lgNtw - (lgh + 1);                // conj W_{2h}^j
-    const int nq = N >> 2;
-    for (int q = threadIdx.x; q < S * nq; q += NT) {
-      const int seq = q >> (lgN - 2), r = q & (nq - 1);
-      const int blk = r >> lgh, j = r & (h - 1);
-      cx<T>* p = s + seq * LD + (blk << (lgh + 2)) + j;
-      cx<T> x0 = p[0], x1 = p[h], x2 = p[2 * h], x3 = p[3 * h];
-      const cx<T> w1 = tw[j << tws1];
-      const cx<T> w2 = tw[j << (tws1 - 1)];            // W_{4h}^j
-      cx<T> t = cmulconj(x1, w1); cx<T> u0 = x0 + t, u1 = x0 - t;
-      t = cmulconj(x3, w1);       cx<T> u2 = x2 + t, u3 = x2 - t;
-      t = cmulconj(u2, w2);       p[0] = u0 + t;  p[2 * h] = u0 - t;
-      t = mul_i(cmulconj(u3, w2));                      // conj W_{4h}^{j+h} = +i conj W_{4h}^j
-      p[h] = u1 + t;  p[3 * h] = u1 - t;
-    }
-    __syncthreads();
+// ---- inverse, DIT: bit-reversed -> natural (unnormalised); the forward schedule replayed backwards ----
+template <typename T, int NT, int LD, int LGN, int LGNTW, int I = num_stages(LGN) - 1>
+__device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
+  if constexpr (I >= 0) {
+    constexpr int LG = stage_lg(LGN, I);
+    constexpr int LGH = levels_after(LGN, I);                      // bottom span index of this stage
+    dit_stage<T, NT, LD, LGN, LGNTW, LGH, LG>(s, S, tw);
+    fft_dit<T, NT, LD, LGN, LGNTW, I - 1>(s, S, tw);
   }
 }
 
 // ---- packed real <-> half spectrum, in place on the tile ------------------------------------------
-// slot of half-spectrum index k (0..M)
-__device__ __forceinline__ int hslot(int k, int M, int lgM) { return k < M ? brev(k, lgM) : M; }
+// LDS index of half-spectrum entry k (0..M); the Nyquist entry k = M uses the spare slot M
+template <int LGM> __device__ __forceinline__ int hslot(int k) { return pad(k < (1 << LGM) ? brevc<LGM>(k) : (1 << LGM)); }
 
 // after fft_dif on z[j] = f[2j] + i f[2j+1]:  A[k] for k = 0..M   (twN: exp(-2 pi i k/N), N = 2M, k < M)
-template <typename T>
-__device__ __forceinline__ void r2c_post(cx<T>* __restrict__ s, int S, int LD, int lgM,
-                                         const cx<T>* __restrict__ twN) {
-  const int M = 1 << lgM, np = (M >> 1) + 1;           // pairs k = 0..M/2
+template <typename T, int NT, int LD, int LGM>
+__device__ __forceinline__ void r2c_post(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ twN) {
+  constexpr int M = 1 << LGM, np = (M >> 1) + 1;       // pairs k = 0..M/2
   for (int q = threadIdx.x; q < S * np; q += NT) {
     const int seq = q / np, k = q - seq * np;
     cx<T>* p = s + seq * LD;
     if (k == 0) {
       cx<T> z = p[0];
       p[0] = mk<T>(z.x + z.y, 0);
-      p[M] = mk<T>(z.x - z.y, 0);
+      p[pad(M)] = mk<T>(z.x - z.y, 0);
     } else {
-      const int k2 = M - k, i1 = brev(k, lgM), i2 = brev(k2, lgM);
+      const int k2 = M - k, i1 = pad(brevc<LGM>(k)), i2 = pad(brevc<LGM>(k2));
       cx<T> a = p[i1], b = p[i2];
       cx<T> e = mk<T>(T(0.5) * (a.x + b.x), T(0.5) * (a.y - b.y));   // (a + conj b)/2
       cx<T> o = mk<T>(T(0.5) * (a.x - b.x), T(0.5) * (a.y + b.y));   // (a - conj b)/2
       cx<T> wo = mul_mi(o * twN[k]);                                 // -i w^k o
       p[i1] = e + wo;
-      if (k2 != k) p[i2] = conj(e - wo);                             // A[M-k] = conj(e) - (-i w^{M-k}) ... = conj(e - wo)
+      if (k2 != k) p[i2] = conj(e - wo);
     }
   }
   __syncthreads();
@@ -126,18 +177,17 @@ __device__ __forceinline__ void r2c_post(cx<T>* __restrict__ s, int S, int LD, i
 
 // before fft_dit: Z[k] from A[k]; imaginary parts of A[0], A[M] are dropped (FFTW c2r semantics).
 // Result of fft_dit is then  (f[2j] + i f[2j+1]) * N   (unnormalised, like FFTW's backward transform).
-template <typename T>
-__device__ __forceinline__ void c2r_pre(cx<T>* __restrict__ s, int S, int LD, int lgM,
-                                        const cx<T>* __restrict__ twN) {
-  const int M = 1 << lgM, np = (M >> 1) + 1;
+template <typename T, int NT, int LD, int LGM>
+__device__ __forceinline__ void c2r_pre(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ twN) {
+  constexpr int M = 1 << LGM, np = (M >> 1) + 1;
   for (int q = threadIdx.x; q < S * np; q += NT) {
     const int seq = q / np, k = q - seq * np;
     cx<T>* p = s + seq * LD;
     if (k == 0) {
-      T a0 = p[0].x, am = p[M].x;
+      T a0 = p[0].x, am = p[pad(M)].x;
       p[0] = mk<T>(a0 + am, a0 - am);
     } else {
-      const int k2 = M - k, i1 = brev(k, lgM), i2 = brev(k2, lgM);
+      const int k2 = M - k, i1 = pad(brevc<LGM>(k)), i2 = pad(brevc<LGM>(k2));
       cx<T> a = p[i1], b = p[i2];
       cx<T> e = mk<T>(a.x + b.x, a.y - b.y);                         // a + conj b
       cx<T> o = mk<T>(a.x - b.x, a.y + b.y);                         // a - conj b

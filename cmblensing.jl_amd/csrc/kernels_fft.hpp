@@ -12,10 +12,15 @@
 
 namespace cmbl {
 
+// Column tiles that are neighbours in x share 64/128-byte lines of the [ky][x] arrays.  Workgroup b is observed to run
+// on XCD b % 8 (speed only, never correctness), so give every XCD a contiguous range of tiles: its private L2 then sees
+// both halves of each shared line.
+__device__ __forceinline__ int xcd_tile(int b, int nb) { return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3); }
+
 // ---------------------------------------------------------------------------------------------
 // ref <-> F  (transpose + bit reversal of x), V = cx<T> or T.   grid (Nx/32, ceil(Nyh/32), slices), block 256
 template <typename V>
-__global__ __launch_bounds__(NT) void k_ref2F(const V* __restrict__ in, V* __restrict__ out, int Nx, int lgNx, int Nyh) {
+__global__ __launch_bounds__(NTP) void k_ref2F(const V* __restrict__ in, V* __restrict__ out, int Nx, int lgNx, int Nyh) {
   __shared__ V tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const size_t sl = blockIdx.z;
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(NT) void k_ref2F(const V* __restrict__ in, V* __res
 }
 
 template <typename V>
-__global__ __launch_bounds__(NT) void k_F2ref(const V* __restrict__ in, V* __restrict__ out, int Nx, int lgNx, int Nyh) {
+__global__ __launch_bounds__(NTP) void k_F2ref(const V* __restrict__ in, V* __restrict__ out, int Nx, int lgNx, int Nyh) {
   __shared__ V tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const size_t sl = blockIdx.z;
@@ -53,105 +58,153 @@ __global__ __launch_bounds__(NT) void k_F2ref(const V* __restrict__ in, V* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column-tile geometry, all compile time: C columns per workgroup of NT threads, M = Ny/2, R = C*M/NT packed pairs/thread.
+constexpr int ilog2c(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+template <int R, int NT, int LGM> struct ColTile {
+  static constexpr int M = 1 << LGM, N = 2 * M, LGN = LGM + 1, Nyh = M + 1;
+  static constexpr int C = (R * NT) >> LGM, LGC = ilog2c(C);
+  static constexpr int LDN = tile_ld(N);          // tile row stride when the buffer also carries N-point (pair) transforms
+  static constexpr int LDM = tile_ld(M);          // stride for kernels that only do packed M-point transforms
+  static constexpr int RZ = (C * (M + 1) + NT - 1) / NT;   // half-spectrum entries per thread (R, or R+1)
+  static_assert(C >= 1 && (C << LGM) == R * NT, "tile shape must satisfy C*M == R*NT");
+};
+
 // tile <-> mixed-layout global helpers for column kernels.  Tile: C sequences x LD slots, half-spectrum at hslot(k).
 // lanes run over c fastest so each wave touches (64/C) segments of C contiguous complex values.
-template <typename T, typename F>
-__device__ __forceinline__ void tile_load_mixed(cx<T>* __restrict__ s, const cx<T>* __restrict__ g /*slice base*/,
-                                                int Nx, int x0, int C, int lgC, int lgM, F&& f) {
-  const int M = 1 << lgM, LD = M + 1;
+template <typename T, int NT, int LD, int LGM, int LGC, typename F>
+__device__ __forceinline__ void tile_load_mixed(cx<T>* __restrict__ s, const cx<T>* __restrict__ g /*slice base*/, int Nx, int x0, F&& f) {
+  constexpr int M = 1 << LGM, C = 1 << LGC;
   for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
-    const int c = e & (C - 1), k = e >> lgC;
-    s[c * LD + hslot(k, M, lgM)] = f(g[(size_t)k * Nx + x0 + c], k);
+    const int c = e & (C - 1), k = e >> LGC;
+    s[c * LD + hslot<LGM>(k)] = f(g[(size_t)k * Nx + x0 + c], k);
   }
 }
-template <typename T, typename F>
-__device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g,
-                                                 int Nx, int x0, int C, int lgC, int lgM, F&& f) {
-  const int M = 1 << lgM, LD = M + 1;
+template <typename T, int NT, int LD, int LGM, int LGC, typename F>
+__device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int Nx, int x0, F&& f) {
+  constexpr int M = 1 << LGM, C = 1 << LGC;
   for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
-    const int c = e & (C - 1), k = e >> lgC;
-    g[(size_t)k * Nx + x0 + c] = f(s[c * LD + hslot(k, M, lgM)], k);
+    const int c = e & (C - 1), k = e >> LGC;
+    g[(size_t)k * Nx + x0 + c] = f(s[c * LD + hslot<LGM>(k)], k);
+  }
+}
+
+// Two real sequences per complex transform.  Z = X + iY with X, Y the (Hermitian-extended) half spectra:
+//   Z[k] = X[k] + i Y[k],  Z[N-k] = conj(X[k]) + i conj(Y[k])  (0<k<M);  Z[0], Z[M] from the real parts only (c2r semantics).
+// After the N-point DIT the tile holds N*(x[n] + i y[n]).  Frequency k sits at slot pad(brev_N(k)).
+template <typename T, int NT, int LD, int LGN, int LGC, typename FX, typename FY>
+__device__ __forceinline__ void pair_load_mixed(cx<T>* __restrict__ s, const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY,
+                                                int Nx, int x0, FX&& fX, FY&& fY) {
+  constexpr int N = 1 << LGN, M = N >> 1, C = 1 << LGC;
+  for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
+    const int c = e & (C - 1), k = e >> LGC;
+    const size_t gi = (size_t)k * Nx + x0 + c;
+    const cx<T> X = fX(gX[gi], k), Y = fY(gY[gi], k);
+    cx<T>* p = s + c * LD;
+    if (k == 0 || k == M) {
+      p[pad(brevc<LGN>(k))] = mk<T>(X.x, Y.x);
+    } else {
+      p[pad(brevc<LGN>(k))] = mk<T>(X.x - Y.y, X.y + Y.x);
+      p[pad(brevc<LGN>(N - k))] = mk<T>(X.x + Y.y, Y.x - X.y);
+    }
+  }
+}
+// After the N-point DIF of a + i b (a, b real): A[k] = (Z[k] + conj Z[N-k])/2, B[k] = (Z[k] - conj Z[N-k])/(2i), k = 0..M.
+// f(k, c, A, B) consumes the pair (stores it, or combines it with something held in registers).
+template <typename T, int NT, int LD, int LGN, int LGC, int RZ, typename F>
+__device__ __forceinline__ void pair_split(const cx<T>* __restrict__ s, F&& f) {
+  constexpr int N = 1 << LGN, M = N >> 1, C = 1 << LGC;
+#pragma unroll
+  for (int i = 0; i < RZ; ++i) {                    // RZ = ceil(C*(M+1)/NT): compile-time trip count keeps f's captures in registers
+    const int e = threadIdx.x + i * NT;
+    if (e < C * (M + 1)) {
+      const int c = e & (C - 1), k = e >> LGC;
+      const cx<T>* p = s + c * LD;
+      const cx<T> zk = p[pad(brevc<LGN>(k))], zn = p[pad(brevc<LGN>((N - k) & (N - 1)))];
+      f(i, k, c, mk<T>(T(0.5) * (zk.x + zn.x), T(0.5) * (zk.y - zn.y)), mk<T>(T(0.5) * (zk.y + zn.y), T(0.5) * (zn.x - zk.x)));
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// y pass, forward: map -> mixed.   grid (Nx/C, slices).  LDS: twY[M] + C*(M+1) cplx
-template <typename T>
-__global__ __launch_bounds__(NT) void k_y_r2c(const T* __restrict__ in, cx<T>* __restrict__ out,
-                                              const cx<T>* __restrict__ twY, int Nx, int lgM, int C, int lgC) {
+// y pass, forward: map -> mixed.   grid (Nx/C, slices).  LDS: twY[M] + C*tile_ld(M) cplx
+template <typename T, int R, int NT, int LGM>
+__global__ __launch_bounds__(NT) void k_y_r2c(const T* __restrict__ in, cx<T>* __restrict__ out, const cx<T>* __restrict__ twY, int Nx) {
+  using G = ColTile<R, NT, LGM>;
+  constexpr int M = G::M, LD = G::LDM, C = G::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int M = 1 << lgM, LD = M + 1, Nyh = M + 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + M;
-  const int x0 = blockIdx.x * C;
+  const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
-  load_twiddles(tw, twY, M);
+  load_twiddles<T, NT>(tw, twY, M);
   const cx<T>* src = reinterpret_cast<const cx<T>*>(in) + (sl * Nx + x0) * (size_t)M;
-  for (int e = threadIdx.x; e < C * M; e += NT) {
-    const int c = e >> lgM, j = e & (M - 1);
-    s[c * LD + j] = src[(size_t)c * M + j];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int e = threadIdx.x + i * NT, c = e >> LGM, j = e & (M - 1);
+    s[c * LD + pad(j)] = src[e];
   }
   __syncthreads();
-  fft_dif(s, C, LD, lgM, tw, lgM + 1);
-  r2c_post(s, C, LD, lgM, tw);
-  tile_store_mixed(s, out + sl * (size_t)Nyh * Nx, Nx, x0, C, lgC, lgM, [](cx<T> v, int) { return v; });
+  fft_dif<T, NT, LD, LGM, LGM + 1>(s, C, tw);
+  r2c_post<T, NT, LD, LGM>(s, C, tw);
+  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)G::Nyh * Nx, Nx, x0, [](cx<T> v, int) { return v; });
 }
 
 // y pass, inverse: mixed -> map, scaled by `scale` (1/Ny; the x pass already carries 1/Nx)
-template <typename T>
-__global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* __restrict__ out,
-                                              const cx<T>* __restrict__ twY, int Nx, int lgM, int C, int lgC, T scale) {
+template <typename T, int R, int NT, int LGM>
+__global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* __restrict__ out, const cx<T>* __restrict__ twY, int Nx, T scale) {
+  using G = ColTile<R, NT, LGM>;
+  constexpr int M = G::M, LD = G::LDM, C = G::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int M = 1 << lgM, LD = M + 1, Nyh = M + 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + M;
-  const int x0 = blockIdx.x * C;
+  const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
-  load_twiddles(tw, twY, M);
-  tile_load_mixed(s, in + sl * (size_t)Nyh * Nx, Nx, x0, C, lgC, lgM, [](cx<T> v, int) { return v; });
+  load_twiddles<T, NT>(tw, twY, M);
+  tile_load_mixed<T, NT, LD, LGM, G::LGC>(s, in + sl * (size_t)G::Nyh * Nx, Nx, x0, [](cx<T> v, int) { return v; });
   __syncthreads();
-  c2r_pre(s, C, LD, lgM, tw);
-  fft_dit(s, C, LD, lgM, tw, lgM + 1);
+  c2r_pre<T, NT, LD, LGM>(s, C, tw);
+  fft_dit<T, NT, LD, LGM, LGM + 1>(s, C, tw);
   cx<T>* dst = reinterpret_cast<cx<T>*>(out) + (sl * Nx + x0) * (size_t)M;
-  for (int e = threadIdx.x; e < C * M; e += NT) {
-    const int c = e >> lgM, j = e & (M - 1);
-    dst[(size_t)c * M + j] = scale * s[c * LD + j];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int e = threadIdx.x + i * NT, c = e >> LGM, j = e & (M - 1);
+    dst[e] = scale * s[c * LD + pad(j)];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// x pass on contiguous rows.  `rows` = slices*Nyh rows of Nx.  grid ceil(rows/RX).  LDS: twX[Nx/2] + RX*Nx cplx
+// x pass on contiguous rows.  `rows` = slices*Nyh rows of Nx.  grid ceil(rows/RX).  LDS: twX[Nx/2] + RX*tile_ld(Nx) cplx
 //   MODE 0: forward  (mixed -> F)
 //   MODE 1: inverse  (F -> mixed), scaled by 1/Nx
 //   MODE 2: x-derivative  (mixed -> mixed):  ifft_x( i*lx * fft_x(row) ) / Nx        (src/proj_lambert.jl:146-159, coord 1)
-template <typename T, int MODE>
+template <typename T, int MODE, int NT, int LGNX>
 __global__ __launch_bounds__(NT) void k_x_fft(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
-                                              const cx<T>* __restrict__ twX, const T* __restrict__ lx_r,
-                                              int lgNx, long rows, int RX) {
+                                              const cx<T>* __restrict__ twX, const T* __restrict__ lx_r, long rows, int RX) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int Nx = 1 << lgNx;
+  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
   const long r0 = (long)blockIdx.x * RX;
   const int nr = (int)min((long)RX, rows - r0);
-  load_twiddles(tw, twX, Nx >> 1);
+  load_twiddles<T, NT>(tw, twX, Nx >> 1);
   const cx<T>* src = in + r0 * Nx;
-  for (int e = threadIdx.x; e < nr * Nx; e += NT) s[e] = src[e];
+  for (int e = threadIdx.x; e < nr * Nx; e += NT) s[(e >> LGNX) * LD + pad(e & (Nx - 1))] = src[e];
   __syncthreads();
   const T inv = T(1) / T(Nx);
-  if (MODE == 0 || MODE == 2) fft_dif(s, nr, Nx, lgNx, tw, lgNx);
+  if (MODE == 0 || MODE == 2) fft_dif<T, NT, LD, LGNX, LGNX>(s, nr, tw);
   if (MODE == 2) {
     for (int e = threadIdx.x; e < nr * Nx; e += NT) {
-      const T l = lx_r[e & (Nx - 1)] * inv;
-      cx<T> v = s[e];
-      s[e] = mk<T>(-l * v.y, l * v.x);
+      const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
+      const T l = lx_r[i] * inv;
+      cx<T> v = s[si];
+      s[si] = mk<T>(-l * v.y, l * v.x);
     }
     __syncthreads();
   }
-  if (MODE == 1 || MODE == 2) fft_dit(s, nr, Nx, lgNx, tw, lgNx);
+  if (MODE == 1 || MODE == 2) fft_dit<T, NT, LD, LGNX, LGNX>(s, nr, tw);
   cx<T>* dst = out + r0 * Nx;
-  if (MODE == 1) { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = inv * s[e]; }
-  else           { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[e]; }
+  if (MODE == 1) { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = inv * s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }
+  else           { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }
 }
 
 }  // namespace cmbl

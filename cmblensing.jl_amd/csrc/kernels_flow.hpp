@@ -44,189 +44,197 @@ __device__ __forceinline__ V rk_update(const RKCoef<T>& rk, V k, V& y0, V& acc) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward / inverse flow, column kernel.  grid (Nx/C, P*B).  C*M == R*NT.
+// Register-phase helpers.  A thread owns R "pairs": pair e = threadIdx.x + i*NT of the tile, column c = e >> LGM, rows
+// (2jj, 2jj+1) with jj = e & (M-1) -- i.e. the cx<T> at index e of a map column tile viewed as packed pairs.
+template <typename T>
+__device__ __forceinline__ void load_p_pair(const PhiMaps<T>& ph, size_t gi, T t, cx<T>& px, cx<T>& py, cx<T>& m11, cx<T>& m12, cx<T>& m22) {
+  const cx<T> gx = reinterpret_cast<const cx<T>*>(ph.gx)[gi], gy = reinterpret_cast<const cx<T>*>(ph.gy)[gi];
+  const cx<T> hxx = reinterpret_cast<const cx<T>*>(ph.hxx)[gi], hyx = reinterpret_cast<const cx<T>*>(ph.hyx)[gi];
+  const cx<T> hyy = reinterpret_cast<const cx<T>*>(ph.hyy)[gi];
+  flow_pm(t, gx.x, gy.x, hxx.x, hyx.x, hyy.x, px.x, py.x, m11.x, m12.x, m22.x);
+  flow_pm(t, gx.y, gy.y, hxx.y, hyx.y, hyy.y, px.y, py.y, m11.y, m12.y, m22.y);
+}
+// tile of N-point complex columns after a pair DIT: slots pad(2jj), pad(2jj)+1 hold (x,y)[2jj], (x,y)[2jj+1]
+template <typename T>
+__device__ __forceinline__ void read_pair(const cx<T>* col, int jj, T scale, cx<T>& x, cx<T>& y) {
+  const cx<T> z0 = col[pad(2 * jj)], z1 = col[pad(2 * jj) + 1];
+  x = mk<T>(z0.x * scale, z1.x * scale); y = mk<T>(z0.y * scale, z1.y * scale);
+}
+template <typename T>
+__device__ __forceinline__ void write_pair(cx<T>* col, int jj, cx<T> x, cx<T> y) {
+  col[pad(2 * jj)] = mk<T>(x.x, y.x); col[pad(2 * jj) + 1] = mk<T>(x.y, y.y);
+}
+template <typename T> __device__ __forceinline__ cx<T> mul_il(cx<T> v, T l) { return mk<T>(-l * v.y, l * v.x); }   // i*l*v
+template <typename T> __device__ __forceinline__ cx<T> pmul(cx<T> a, cx<T> b) { return mk<T>(a.x * b.x, a.y * b.y); }   // elementwise on a pair
+
+// ---------------------------------------------------------------------------------------------
+// Forward / inverse flow, column kernel.  grid (Nx/C, P*B).  LDS: twY[M] + C*tile_ld(2M).
 //   in : A  = rfft_y(f_s)  (mixed), Gx = d/dx f_s y-transformed (mixed; from k_x_fft<MODE 2>)
 //   out: y0/acc updated, Anext = rfft_y(f_{s+1}) (mixed)
+// d/dx f and d/dy f come out of ONE N-point complex inverse transform of Gx + i*(i*ly*A).
 template <typename T> struct FlowYArgs {
   const cx<T>* A; const cx<T>* Gx; cx<T>* Anext;
   T* y0; T* acc;
   PhiMaps<T> ph;
   const cx<T>* twY; const T* ly;
-  int Nx, lgM, C, lgC, P;
+  int Nx, P;
   RKCoef<T> rk;
 };
 
-template <typename T, int R>
+template <typename T, int R, int NT, int LGM>
 __global__ __launch_bounds__(NT) void k_flow_y_fwd(FlowYArgs<T> a) {
+  using G = ColTile<R, NT, LGM>;
+  constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int M = 1 << a.lgM, LD = M + 1, Nyh = M + 1, Nx = a.Nx, C = a.C;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + M;
-  const int x0 = blockIdx.x * C;
+  const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
-  load_twiddles(tw, a.twY, M);
-
-  // d/dx f
-  tile_load_mixed(s, a.Gx + sl * (size_t)Nyh * Nx, Nx, x0, C, a.lgC, a.lgM, [](cx<T> v, int) { return v; });
-  __syncthreads();
-  c2r_pre(s, C, LD, a.lgM, tw);
-  fft_dit(s, C, LD, a.lgM, tw, a.lgM + 1);
-  cx<T> k[R], pyr[R];
-  const size_t pbase = ((size_t)bphi * Nx + x0) * M;            // in units of pairs
+  const size_t moff = sl * (size_t)Nyh * Nx;
+  load_twiddles<T, NT>(tw, a.twY, M);
+  const T* ly = a.ly;
+  pair_load_mixed<T, NT, LD, LGN, LGC>(s, a.Gx + moff, a.A + moff, Nx, x0, [](cx<T> v, int) { return v; },
+                                       [ly](cx<T> v, int kk) { return mul_il(v, ly[kk]); });
+  // everything else this workgroup needs from HBM is requested before the transform starts
+  const size_t pbase = ((size_t)bphi * Nx + x0) * M, mbase = (sl * Nx + x0) * (size_t)M;
+  cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
+  cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
+  cx<T> px[R], py[R], y0[R], acc[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    const size_t gi = pbase + (size_t)c * M + j;
-    const cx<T> gx = reinterpret_cast<const cx<T>*>(a.ph.gx)[gi], gy = reinterpret_cast<const cx<T>*>(a.ph.gy)[gi];
-    const cx<T> hxx = reinterpret_cast<const cx<T>*>(a.ph.hxx)[gi], hyx = reinterpret_cast<const cx<T>*>(a.ph.hyx)[gi];
-    const cx<T> hyy = reinterpret_cast<const cx<T>*>(a.ph.hyy)[gi];
-    T px0, py0, px1, py1, m11, m12, m22;
-    flow_pm(a.rk.t, gx.x, gy.x, hxx.x, hyx.x, hyy.x, px0, py0, m11, m12, m22);
-    flow_pm(a.rk.t, gx.y, gy.y, hxx.y, hyx.y, hyy.y, px1, py1, m11, m12, m22);
-    const cx<T> d = s[c * LD + j];
-    k[i] = mk<T>(px0 * (d.x * invNy), px1 * (d.y * invNy));
-    pyr[i] = mk<T>(py0, py1);
+    const int e = threadIdx.x + i * NT;
+    cx<T> m11, m12, m22;
+    load_p_pair(a.ph, pbase + e, a.rk.t, px[i], py[i], m11, m12, m22);
+    y0[i] = y0p[e];
+    acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
   }
   __syncthreads();
-
-  // d/dy f : i*ly applied on load
-  const T* ly = a.ly;
-  tile_load_mixed(s, a.A + sl * (size_t)Nyh * Nx, Nx, x0, C, a.lgC, a.lgM,
-                  [ly](cx<T> v, int kk) { const T l = ly[kk]; return mk<T>(-l * v.y, l * v.x); });
-  __syncthreads();
-  c2r_pre(s, C, LD, a.lgM, tw);
-  fft_dit(s, C, LD, a.lgM, tw, a.lgM + 1);
-  cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + (sl * Nx + x0) * (size_t)M;
-  cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + (sl * Nx + x0) * (size_t)M;
+  fft_dit<T, NT, LD, LGN, LGN>(s, C, tw);
   cx<T> fn[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    const cx<T> d = s[c * LD + j];
-    const cx<T> kv = mk<T>(k[i].x + pyr[i].x * (d.x * invNy), k[i].y + pyr[i].y * (d.y * invNy));
-    const size_t gi = (size_t)c * M + j;
-    cx<T> y0 = y0p[gi];
-    cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : accp[gi];
-    fn[i] = rk_update(a.rk, kv, y0, acc);
-    if (a.rk.stage == 4) y0p[gi] = y0; else accp[gi] = acc;
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    cx<T> dx, dy;
+    read_pair(s + c * LD, jj, invNy, dx, dy);
+    const cx<T> kv = pmul(px[i], dx) + pmul(py[i], dy);
+    fn[i] = rk_update(a.rk, kv, y0[i], acc[i]);
+    if (a.rk.stage == 4) y0p[e] = y0[i]; else accp[e] = acc[i];
   }
   if (a.rk.last) return;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    s[c * LD + j] = fn[i];
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    s[c * LD + pad(jj)] = fn[i];
   }
   __syncthreads();
-  fft_dif(s, C, LD, a.lgM, tw, a.lgM + 1);
-  r2c_post(s, C, LD, a.lgM, tw);
-  tile_store_mixed(s, a.Anext + sl * (size_t)Nyh * Nx, Nx, x0, C, a.lgC, a.lgM, [](cx<T> v, int) { return v; });
+  fft_dif<T, NT, LD, LGM, LGN>(s, C, tw);
+  r2c_post<T, NT, LD, LGM>(s, C, tw);
+  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0, [](cx<T> v, int) { return v; });
 }
 
 // ---------------------------------------------------------------------------------------------
 // Adjoint flow, column kernel: H = ifft_x(Y) (mixed)  ->  Wx = rfft_y(px*y), Wy' = i*ly*rfft_y(py*y) (mixed)
-//   (src/lenseflow.jl:163-174).  Optionally (delta flow) multiplies y by grad f and writes w-partials.
+//   (src/lenseflow.jl:163-174).  The two forward transforms are ONE N-point complex transform of px*y + i*py*y.
 template <typename T> struct AdjYArgs {
   const cx<T>* H; cx<T>* Wx; cx<T>* Wy;
   PhiMaps<T> ph;
   const cx<T>* twY; const T* ly;
-  int Nx, lgM, C, lgC, P;
+  int Nx, P;
   T t;
 };
 
-template <typename T, int R>
+template <typename T, int R, int NT, int LGM>
 __global__ __launch_bounds__(NT) void k_adj_y(AdjYArgs<T> a) {
+  using G = ColTile<R, NT, LGM>;
+  constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int M = 1 << a.lgM, LD = M + 1, Nyh = M + 1, Nx = a.Nx, C = a.C;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + M;
-  const int x0 = blockIdx.x * C;
+  const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
-  load_twiddles(tw, a.twY, M);
-  tile_load_mixed(s, a.H + sl * (size_t)Nyh * Nx, Nx, x0, C, a.lgC, a.lgM, [](cx<T> v, int) { return v; });
-  __syncthreads();
-  c2r_pre(s, C, LD, a.lgM, tw);
-  fft_dit(s, C, LD, a.lgM, tw, a.lgM + 1);
-  cx<T> wy[R];
+  const size_t moff = sl * (size_t)Nyh * Nx;
+  load_twiddles<T, NT>(tw, a.twY, M);
+  tile_load_mixed<T, NT, LD, LGM, LGC>(s, a.H + moff, Nx, x0, [](cx<T> v, int) { return v; });
   const size_t pbase = ((size_t)bphi * Nx + x0) * M;
+  cx<T> px[R], py[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    const size_t gi = pbase + (size_t)c * M + j;
-    const cx<T> gx = reinterpret_cast<const cx<T>*>(a.ph.gx)[gi], gy = reinterpret_cast<const cx<T>*>(a.ph.gy)[gi];
-    const cx<T> hxx = reinterpret_cast<const cx<T>*>(a.ph.hxx)[gi], hyx = reinterpret_cast<const cx<T>*>(a.ph.hyx)[gi];
-    const cx<T> hyy = reinterpret_cast<const cx<T>*>(a.ph.hyy)[gi];
-    T px0, py0, px1, py1, m11, m12, m22;
-    flow_pm(a.t, gx.x, gy.x, hxx.x, hyx.x, hyy.x, px0, py0, m11, m12, m22);
-    flow_pm(a.t, gx.y, gy.y, hxx.y, hyx.y, hyy.y, px1, py1, m11, m12, m22);
-    const cx<T> d = s[c * LD + j];
-    const cx<T> yv = mk<T>(d.x * invNy, d.y * invNy);
-    wy[i] = mk<T>(py0 * yv.x, py1 * yv.y);
-    s[c * LD + j] = mk<T>(px0 * yv.x, px1 * yv.y);            // own slot: no hazard
+    cx<T> m11, m12, m22;
+    load_p_pair(a.ph, pbase + threadIdx.x + i * NT, a.t, px[i], py[i], m11, m12, m22);
   }
   __syncthreads();
-  fft_dif(s, C, LD, a.lgM, tw, a.lgM + 1);
-  r2c_post(s, C, LD, a.lgM, tw);
-  tile_store_mixed(s, a.Wx + sl * (size_t)Nyh * Nx, Nx, x0, C, a.lgC, a.lgM, [](cx<T> v, int) { return v; });
+  c2r_pre<T, NT, LD, LGM>(s, C, tw);
+  fft_dit<T, NT, LD, LGM, LGN>(s, C, tw);
+  cx<T> yv[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    yv[i] = invNy * s[c * LD + pad(jj)];
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    s[c * LD + j] = wy[i];
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    write_pair(s + c * LD, jj, pmul(px[i], yv[i]), pmul(py[i], yv[i]));
   }
   __syncthreads();
-  fft_dif(s, C, LD, a.lgM, tw, a.lgM + 1);
-  r2c_post(s, C, LD, a.lgM, tw);
+  fft_dif<T, NT, LD, LGN, LGN>(s, C, tw);
   const T* ly = a.ly;
-  tile_store_mixed(s, a.Wy + sl * (size_t)Nyh * Nx, Nx, x0, C, a.lgC, a.lgM,
-                   [ly](cx<T> v, int kk) { const T l = ly[kk]; return mk<T>(-l * v.y, l * v.x); });
+  cx<T>* Wx = a.Wx + moff; cx<T>* Wy = a.Wy + moff;
+  pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [=](int, int k, int c, cx<T> A, cx<T> B) {
+    const size_t gi = (size_t)k * Nx + x0 + c;
+    Wx[gi] = A; Wy[gi] = mul_il(B, ly[k]);
+  });
 }
 
 // Adjoint flow, row kernel:  k = i*lx*fft_x(Wx) + fft_x(Wy')  -> RK update of the Fourier state (F layout)
-//   -> Hnext = ifft_x(next stage input) (mixed).     rows = slices*Nyh, grid ceil(rows/RX).  LDS: twX + 2*RX*Nx
+//   -> Hnext = ifft_x(next stage input) (mixed).     rows = slices*Nyh, grid ceil(rows/RX).  LDS: twX + 2*RX*tile_ld(Nx)
 template <typename T> struct AdjXArgs {
   const cx<T>* Wx; const cx<T>* Wy; cx<T>* Y0; cx<T>* acc; cx<T>* Hnext;
   const cx<T>* twX; const T* lx_r;
-  int lgNx, RX; long rows;
+  int RX; long rows;
   RKCoef<T> rk;
 };
 
-template <typename T>
+template <typename T, int NT, int LGNX>
 __global__ __launch_bounds__(NT) void k_adj_x(AdjXArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int Nx = 1 << a.lgNx;
+  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
   const long r0 = (long)blockIdx.x * a.RX;
   const int nr = (int)min((long)a.RX, a.rows - r0);
-  cx<T>* s2 = s + (size_t)a.RX * Nx;
-  load_twiddles(tw, a.twX, Nx >> 1);
+  cx<T>* s2 = s + (size_t)a.RX * LD;
+  load_twiddles<T, NT>(tw, a.twX, Nx >> 1);
   const int n = nr * Nx;
-  for (int e = threadIdx.x; e < n; e += NT) { s[e] = a.Wx[r0 * Nx + e]; s2[e] = a.Wy[r0 * Nx + e]; }
+  for (int e = threadIdx.x; e < n; e += NT) {
+    const int si = (e >> LGNX) * LD + pad(e & (Nx - 1));
+    s[si] = a.Wx[r0 * Nx + e]; s2[si] = a.Wy[r0 * Nx + e];
+  }
   __syncthreads();
   // both row sets in one go: they are adjacent in LDS when nr == RX; otherwise two calls
-  if (nr == a.RX) fft_dif(s, 2 * nr, Nx, a.lgNx, tw, a.lgNx);
-  else { fft_dif(s, nr, Nx, a.lgNx, tw, a.lgNx); fft_dif(s2, nr, Nx, a.lgNx, tw, a.lgNx); }
+  if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX>(s, 2 * nr, tw);
+  else { fft_dif<T, NT, LD, LGNX, LGNX>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX>(s2, nr, tw); }
   const T inv = T(1) / T(Nx);
   for (int e = threadIdx.x; e < n; e += NT) {
-    const T l = a.lx_r[e & (Nx - 1)];
-    const cx<T> u = s[e], v = s2[e];
-    const cx<T> kv = mk<T>(-l * u.y + v.x, l * u.x + v.y);
+    const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
+    const cx<T> kv = mul_il(s[si], a.lx_r[i]) + s2[si];
     const long gi = r0 * Nx + e;
     cx<T> y0 = a.Y0[gi];
     cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
     cx<T> fn = rk_update(a.rk, kv, y0, acc);
     if (a.rk.stage == 4) a.Y0[gi] = y0; else a.acc[gi] = acc;
-    s[e] = inv * fn;
+    s[si] = inv * fn;
   }
   if (a.rk.last) return;
   __syncthreads();
-  fft_dit(s, nr, Nx, a.lgNx, tw, a.lgNx);
-  for (int e = threadIdx.x; e < n; e += NT) a.Hnext[r0 * Nx + e] = s[e];
+  fft_dit<T, NT, LD, LGNX, LGNX>(s, nr, tw);
+  for (int e = threadIdx.x; e < n; e += NT) a.Hnext[r0 * Nx + e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -239,237 +247,206 @@ template <typename T> struct DeltaYArgs {
   T* w1p; T* w2p;           // (P*B, Nx, Ny)
 };
 
-template <typename T, int R>
+template <typename T, int R, int NT, int LGM>
 __global__ __launch_bounds__(NT) void k_delta_y(DeltaYArgs<T> d) {
+  using G = ColTile<R, NT, LGM>;
+  constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const FlowYArgs<T>& a = d.f;
-  const int M = 1 << a.lgM, LD = M + 1, Nyh = M + 1, Nx = a.Nx, C = a.C;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + M;
-  const int x0 = blockIdx.x * C;
+  const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
   const size_t moff = sl * (size_t)Nyh * Nx;
-  load_twiddles(tw, a.twY, M);
-
-  // L(delta f) = irfft2(delta f)
-  tile_load_mixed(s, d.H + moff, Nx, x0, C, a.lgC, a.lgM, [](cx<T> v, int) { return v; });
-  __syncthreads();
-  c2r_pre(s, C, LD, a.lgM, tw);
-  fft_dit(s, C, LD, a.lgM, tw, a.lgM + 1);
-  cx<T> ldf[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    const cx<T> v = s[c * LD + j];
-    ldf[i] = mk<T>(v.x * invNy, v.y * invNy);
-  }
-  __syncthreads();
-  // d/dx f
-  tile_load_mixed(s, a.Gx + moff, Nx, x0, C, a.lgC, a.lgM, [](cx<T> v, int) { return v; });
-  __syncthreads();
-  c2r_pre(s, C, LD, a.lgM, tw);
-  fft_dit(s, C, LD, a.lgM, tw, a.lgM + 1);
-  cx<T> k[R];
-  const size_t pbase = ((size_t)bphi * Nx + x0) * M;
-  const size_t mbase = (sl * Nx + x0) * (size_t)M;
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    const size_t gi = pbase + (size_t)c * M + j;
-    const cx<T> gx = reinterpret_cast<const cx<T>*>(a.ph.gx)[gi], gy = reinterpret_cast<const cx<T>*>(a.ph.gy)[gi];
-    const cx<T> hxx = reinterpret_cast<const cx<T>*>(a.ph.hxx)[gi], hyx = reinterpret_cast<const cx<T>*>(a.ph.hyx)[gi];
-    const cx<T> hyy = reinterpret_cast<const cx<T>*>(a.ph.hyy)[gi];
-    T px0, py0, px1, py1, m11, m12, m22;
-    flow_pm(a.rk.t, gx.x, gy.x, hxx.x, hyx.x, hyy.x, px0, py0, m11, m12, m22);
-    flow_pm(a.rk.t, gx.y, gy.y, hxx.y, hyx.y, hyy.y, px1, py1, m11, m12, m22);
-    const cx<T> v = s[c * LD + j];
-    const cx<T> dx = mk<T>(v.x * invNy, v.y * invNy);
-    k[i] = mk<T>(px0 * dx.x, px1 * dx.y);
-    reinterpret_cast<cx<T>*>(d.w1p)[mbase + (size_t)c * M + j] = mk<T>(ldf[i].x * dx.x, ldf[i].y * dx.y);
-  }
-  __syncthreads();
-  // d/dy f
+  const size_t pbase = ((size_t)bphi * Nx + x0) * M, mbase = (sl * Nx + x0) * (size_t)M;
+  load_twiddles<T, NT>(tw, a.twY, M);
   const T* ly = a.ly;
-  tile_load_mixed(s, a.A + moff, Nx, x0, C, a.lgC, a.lgM,
-                  [ly](cx<T> v, int kk) { const T l = ly[kk]; return mk<T>(-l * v.y, l * v.x); });
+
+  // (d/dx f, d/dy f) from one N-point inverse transform
+  pair_load_mixed<T, NT, LD, LGN, LGC>(s, a.Gx + moff, a.A + moff, Nx, x0, [](cx<T> v, int) { return v; },
+                                       [ly](cx<T> v, int kk) { return mul_il(v, ly[kk]); });
+  cx<T> px[R], py[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    cx<T> m11, m12, m22;
+    load_p_pair(a.ph, pbase + threadIdx.x + i * NT, a.rk.t, px[i], py[i], m11, m12, m22);
+  }
   __syncthreads();
-  c2r_pre(s, C, LD, a.lgM, tw);
-  fft_dit(s, C, LD, a.lgM, tw, a.lgM + 1);
+  fft_dit<T, NT, LD, LGN, LGN>(s, C, tw);
+  cx<T> dx[R], dy[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    read_pair(s + c * LD, jj, invNy, dx[i], dy[i]);
+  }
+  __syncthreads();
+  // L(delta f) = irfft2(delta f)
+  tile_load_mixed<T, NT, LD, LGM, LGC>(s, d.H + moff, Nx, x0, [](cx<T> v, int) { return v; });
+  __syncthreads();
+  c2r_pre<T, NT, LD, LGM>(s, C, tw);
+  fft_dit<T, NT, LD, LGM, LGN>(s, C, tw);
   cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
   cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
-  cx<T> fn[R];
+  cx<T> fn[R], ldf[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    const size_t gi = pbase + (size_t)c * M + j;
-    const cx<T> gx = reinterpret_cast<const cx<T>*>(a.ph.gx)[gi], gy = reinterpret_cast<const cx<T>*>(a.ph.gy)[gi];
-    const cx<T> hxx = reinterpret_cast<const cx<T>*>(a.ph.hxx)[gi], hyx = reinterpret_cast<const cx<T>*>(a.ph.hyx)[gi];
-    const cx<T> hyy = reinterpret_cast<const cx<T>*>(a.ph.hyy)[gi];
-    T px0, py0, px1, py1, m11, m12, m22;
-    flow_pm(a.rk.t, gx.x, gy.x, hxx.x, hyx.x, hyy.x, px0, py0, m11, m12, m22);
-    flow_pm(a.rk.t, gx.y, gy.y, hxx.y, hyx.y, hyy.y, px1, py1, m11, m12, m22);
-    const cx<T> v = s[c * LD + j];
-    const cx<T> dy = mk<T>(v.x * invNy, v.y * invNy);
-    const cx<T> kv = mk<T>(k[i].x + py0 * dy.x, k[i].y + py1 * dy.y);
-    const size_t li = (size_t)c * M + j;
-    reinterpret_cast<cx<T>*>(d.w2p)[mbase + li] = mk<T>(ldf[i].x * dy.x, ldf[i].y * dy.y);
-    cx<T> y0 = y0p[li];
-    cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : accp[li];
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    ldf[i] = invNy * s[c * LD + pad(jj)];
+    reinterpret_cast<cx<T>*>(d.w1p)[mbase + e] = pmul(ldf[i], dx[i]);
+    reinterpret_cast<cx<T>*>(d.w2p)[mbase + e] = pmul(ldf[i], dy[i]);
+    const cx<T> kv = pmul(px[i], dx[i]) + pmul(py[i], dy[i]);
+    cx<T> y0 = y0p[e];
+    cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
     fn[i] = rk_update(a.rk, kv, y0, acc);
-    if (a.rk.stage == 4) y0p[li] = y0; else accp[li] = acc;
-    // reuse k[] / ldf[] for the delta-f products  (px*Ldf -> k, py*Ldf -> ldf)
-    k[i] = mk<T>(px0 * ldf[i].x, px1 * ldf[i].y);
-    ldf[i] = mk<T>(py0 * ldf[i].x, py1 * ldf[i].y);
+    if (a.rk.stage == 4) y0p[e] = y0; else accp[e] = acc;
   }
+  __syncthreads();
+  // (Wx, Wy') from one N-point forward transform of px*Ldf + i*py*Ldf
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    write_pair(s + c * LD, jj, pmul(px[i], ldf[i]), pmul(py[i], ldf[i]));
+  }
+  __syncthreads();
+  fft_dif<T, NT, LD, LGN, LGN>(s, C, tw);
+  {
+    cx<T>* Wx = d.Wx + moff; cx<T>* Wy = d.Wy + moff;
+    pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [=](int, int k, int c, cx<T> A, cx<T> B) {
+      const size_t gi = (size_t)k * Nx + x0 + c;
+      Wx[gi] = A; Wy[gi] = mul_il(B, ly[k]);
+    });
+  }
+  if (a.rk.last) return;
   __syncthreads();
   // next-stage f : rfft_y
-  if (!a.rk.last) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) { const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1); s[c * LD + j] = fn[i]; }
-    __syncthreads();
-    fft_dif(s, C, LD, a.lgM, tw, a.lgM + 1);
-    r2c_post(s, C, LD, a.lgM, tw);
-    tile_store_mixed(s, a.Anext + moff, Nx, x0, C, a.lgC, a.lgM, [](cx<T> v, int) { return v; });
-    __syncthreads();
-  }
-  // Wx = rfft_y(px*Ldf)
-#pragma unroll
-  for (int i = 0; i < R; ++i) { const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1); s[c * LD + j] = k[i]; }
+  for (int i = 0; i < R; ++i) { const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1); s[c * LD + pad(jj)] = fn[i]; }
   __syncthreads();
-  fft_dif(s, C, LD, a.lgM, tw, a.lgM + 1);
-  r2c_post(s, C, LD, a.lgM, tw);
-  tile_store_mixed(s, d.Wx + moff, Nx, x0, C, a.lgC, a.lgM, [](cx<T> v, int) { return v; });
-  __syncthreads();
-  // Wy' = i*ly*rfft_y(py*Ldf)
-#pragma unroll
-  for (int i = 0; i < R; ++i) { const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1); s[c * LD + j] = ldf[i]; }
-  __syncthreads();
-  fft_dif(s, C, LD, a.lgM, tw, a.lgM + 1);
-  r2c_post(s, C, LD, a.lgM, tw);
-  tile_store_mixed(s, d.Wy + moff, Nx, x0, C, a.lgC, a.lgM,
-                   [ly](cx<T> v, int kk) { const T l = ly[kk]; return mk<T>(-l * v.y, l * v.x); });
+  fft_dif<T, NT, LD, LGM, LGN>(s, C, tw);
+  r2c_post<T, NT, LD, LGM>(s, C, tw);
+  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0, [](cx<T> v, int) { return v; });
 }
 
 // delta-phi part, column kernel (one per batch slot): w = sum_pol partials; u = M^-1 w (quirk Q1 optional);
 //   Z0 = i*ly*Y(u2) - ly^2*Y(t*py*u2) ; Z1 = Y(u1) + i*ly*Y(t*(py*u1 + px*u2)) ; Z2 = Y(t*px*u1)   (mixed, S0)
-// so that d(dphi)/dt = fft_x(Z0) + i*lx*fft_x(Z1) - lx^2*fft_x(Z2)        (src/lenseflow.jl:198-206)
+// so that d(dphi)/dt = fft_x(Z0) + i*lx*fft_x(Z1) - lx^2*fft_x(Z2)        (src/lenseflow.jl:198-206).
+// Five real transforms = two N-point complex transforms, (u1, u2) and (bb, cc) -- sequences of like magnitude are paired so
+// neither loses precision to the other -- and one packed transform (aa).
 template <typename T> struct DphiYArgs {
   const T* w1p; const T* w2p;   // (B*P, Nx, Ny)
   cx<T>* Z0; cx<T>* Z1; cx<T>* Z2;   // (B, Nyh, Nx) mixed
   PhiMaps<T> ph;
   const cx<T>* twY; const T* ly;
-  int Nx, lgM, C, lgC, P, alias_quirk;
+  int Nx, P, alias_quirk;
   T t;
 };
 
-template <typename T, int R>
+template <typename T, int R, int NT, int LGM>
 __global__ __launch_bounds__(NT) void k_dphi_y(DphiYArgs<T> a) {
+  using G = ColTile<R, NT, LGM>;
+  constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
+  constexpr int RZ = G::RZ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int M = 1 << a.lgM, LD = M + 1, Nyh = M + 1, Nx = a.Nx, C = a.C;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + M;
-  const int x0 = blockIdx.x * C;
+  const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t b = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)b;
-  load_twiddles(tw, a.twY, M);
+  load_twiddles<T, NT>(tw, a.twY, M);
   const size_t pbase = ((size_t)bphi * Nx + x0) * M;
   cx<T> u1[R], u2[R], pxr[R], pyr[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1);
-    const size_t gi = pbase + (size_t)c * M + j;
-    const cx<T> gx = reinterpret_cast<const cx<T>*>(a.ph.gx)[gi], gy = reinterpret_cast<const cx<T>*>(a.ph.gy)[gi];
-    const cx<T> hxx = reinterpret_cast<const cx<T>*>(a.ph.hxx)[gi], hyx = reinterpret_cast<const cx<T>*>(a.ph.hyx)[gi];
-    const cx<T> hyy = reinterpret_cast<const cx<T>*>(a.ph.hyy)[gi];
-    T px0, py0, px1, py1, a11, a12, a22, b11, b12, b22;
-    flow_pm(a.t, gx.x, gy.x, hxx.x, hyx.x, hyy.x, px0, py0, a11, a12, a22);
-    flow_pm(a.t, gx.y, gy.y, hxx.y, hyx.y, hyy.y, px1, py1, b11, b12, b22);
+    const int e = threadIdx.x + i * NT;
+    cx<T> m11, m12, m22;
+    load_p_pair(a.ph, pbase + e, a.t, pxr[i], pyr[i], m11, m12, m22);
     cx<T> w1 = mk<T>(0, 0), w2 = mk<T>(0, 0);
     for (int p = 0; p < a.P; ++p) {                       // spin-adjoint product: sum over pol (src/proj_lambert.jl:423-430)
-      const size_t mi = (((size_t)b * a.P + p) * Nx + x0) * M + (size_t)c * M + j;
+      const size_t mi = (((size_t)b * a.P + p) * Nx + x0) * M + e;
       w1 = w1 + reinterpret_cast<const cx<T>*>(a.w1p)[mi];
       w2 = w2 + reinterpret_cast<const cx<T>*>(a.w2p)[mi];
     }
     // u = M^-1 w   (src/field_vectors.jl:48-49; with the reference's aliasing, v[2] sees the updated v[1])
-    cx<T> v1 = mk<T>(a11 * w1.x + a12 * w2.x, b11 * w1.y + b12 * w2.y);
-    cx<T> in1 = a.alias_quirk ? v1 : w1;
-    cx<T> v2 = mk<T>(a12 * in1.x + a22 * w2.x, b12 * in1.y + b22 * w2.y);
-    u1[i] = v1; u2[i] = v2; pxr[i] = mk<T>(px0, px1); pyr[i] = mk<T>(py0, py1);
+    const cx<T> v1 = pmul(m11, w1) + pmul(m12, w2);
+    const cx<T> in1 = a.alias_quirk ? v1 : w1;
+    u1[i] = v1;
+    u2[i] = pmul(m12, in1) + pmul(m22, w2);
   }
   const T* ly = a.ly; const T t = a.t;
   const size_t moff = b * (size_t)Nyh * Nx;
-  constexpr int RZ = R + 1;                                // a thread stores at most R+1 half-spectrum entries (C*(M+1) = R*NT + C)
-  cx<T> zr[RZ];
-  auto fwd = [&](auto&& gen) {
-    __syncthreads();
+  // pair (u1, u2): keep Y(u1), Y(u2) of this thread's half-spectrum entries in registers
 #pragma unroll
-    for (int i = 0; i < R; ++i) { const int e = threadIdx.x + i * NT, c = e >> a.lgM, j = e & (M - 1); s[c * LD + j] = gen(i); }
-    __syncthreads();
-    fft_dif(s, C, LD, a.lgM, tw, a.lgM + 1);
-    r2c_post(s, C, LD, a.lgM, tw);
-  };
-  auto slot = [&](int i, int& kk) -> cx<T> {               // this thread's i-th half-spectrum entry
-    const int e = threadIdx.x + i * NT; const int c = e & (C - 1); kk = e >> a.lgC;
-    return (e < C * (M + 1)) ? s[c * LD + hslot(kk, M, a.lgM)] : mk<T>(0, 0);
-  };
-  auto put = [&](cx<T>* Z, int i, cx<T> v) {
-    const int e = threadIdx.x + i * NT; const int c = e & (C - 1), kk = e >> a.lgC;
-    if (e < C * (M + 1)) Z[moff + (size_t)kk * Nx + x0 + c] = v;
-  };
-  // Z2 = Y(t*px*u1)
-  fwd([&](int i) { return mk<T>(t * pxr[i].x * u1[i].x, t * pxr[i].y * u1[i].y); });
+  for (int i = 0; i < R; ++i) {
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    write_pair(s + c * LD, jj, u1[i], u2[i]);
+  }
+  __syncthreads();
+  fft_dif<T, NT, LD, LGN, LGN>(s, C, tw);
+  cx<T> yu1[RZ], yu2[RZ];
+  pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int, int, cx<T> A, cx<T> B) { yu1[i] = A; yu2[i] = B; });
+  __syncthreads();
+  // pair (bb, cc) = (t*(py*u1 + px*u2), t*py*u2):  Z1 = Y(u1) + i*ly*Y(bb) ;  Z0 = i*ly*Y(u2) - ly^2*Y(cc)
 #pragma unroll
-  for (int i = 0; i < RZ; ++i) { int kk; cx<T> v = slot(i, kk); put(a.Z2, i, v); }
-  // Z1 = Y(u1) + i*ly*Y(t*(py*u1 + px*u2))
-  fwd([&](int i) { return u1[i]; });
+  for (int i = 0; i < R; ++i) {
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    write_pair(s + c * LD, jj, t * (pmul(pyr[i], u1[i]) + pmul(pxr[i], u2[i])), t * pmul(pyr[i], u2[i]));
+  }
+  __syncthreads();
+  fft_dif<T, NT, LD, LGN, LGN>(s, C, tw);
+  {
+    cx<T>* Z0 = a.Z0 + moff; cx<T>* Z1 = a.Z1 + moff;
+    pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> Yb, cx<T> Yc) {
+      const T l = ly[k];
+      const size_t gi = (size_t)k * Nx + x0 + c;
+      Z1[gi] = yu1[i] + mul_il(Yb, l);
+      Z0[gi] = mul_il(yu2[i], l) - (l * l) * Yc;
+    });
+  }
+  __syncthreads();
+  // aa = t*px*u1  ->  Z2 = Y(aa)   (packed single transform)
 #pragma unroll
-  for (int i = 0; i < RZ; ++i) { int kk; zr[i] = slot(i, kk); }
-  fwd([&](int i) { return mk<T>(t * (pyr[i].x * u1[i].x + pxr[i].x * u2[i].x), t * (pyr[i].y * u1[i].y + pxr[i].y * u2[i].y)); });
-#pragma unroll
-  for (int i = 0; i < RZ; ++i) { int kk; cx<T> v = slot(i, kk); const T l = (threadIdx.x + i * NT < C * (M + 1)) ? ly[kk] : T(0);
-    put(a.Z1, i, mk<T>(zr[i].x - l * v.y, zr[i].y + l * v.x)); }
-  // Z0 = i*ly*Y(u2) - ly^2*Y(t*py*u2)
-  fwd([&](int i) { return u2[i]; });
-#pragma unroll
-  for (int i = 0; i < RZ; ++i) { int kk; cx<T> v = slot(i, kk); const T l = (threadIdx.x + i * NT < C * (M + 1)) ? ly[kk] : T(0);
-    zr[i] = mk<T>(-l * v.y, l * v.x); }
-  fwd([&](int i) { return mk<T>(t * pyr[i].x * u2[i].x, t * pyr[i].y * u2[i].y); });
-#pragma unroll
-  for (int i = 0; i < RZ; ++i) { int kk; cx<T> v = slot(i, kk); const T l = (threadIdx.x + i * NT < C * (M + 1)) ? ly[kk] : T(0);
-    put(a.Z0, i, mk<T>(zr[i].x - l * l * v.x, zr[i].y - l * l * v.y)); }
+  for (int i = 0; i < R; ++i) {
+    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    s[c * LD + pad(jj)] = t * pmul(pxr[i], u1[i]);
+  }
+  __syncthreads();
+  fft_dif<T, NT, LD, LGM, LGN>(s, C, tw);
+  r2c_post<T, NT, LD, LGM>(s, C, tw);
+  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Z2 + moff, Nx, x0, [](cx<T> v, int) { return v; });
 }
 
 // delta-phi part, row kernel: k = fft_x(Z0) + i*lx*fft_x(Z1) - lx^2*fft_x(Z2) ; RK update of the S0 Fourier state
 template <typename T> struct DphiXArgs {
   const cx<T>* Z0; const cx<T>* Z1; const cx<T>* Z2; cx<T>* Y0; cx<T>* acc;
   const cx<T>* twX; const T* lx_r;
-  int lgNx, RX; long rows;
+  int RX; long rows;
   RKCoef<T> rk;
 };
 
-template <typename T>
+template <typename T, int NT, int LGNX>
 __global__ __launch_bounds__(NT) void k_dphi_x(DphiXArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int Nx = 1 << a.lgNx;
+  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
   const long r0 = (long)blockIdx.x * a.RX;
   const int nr = (int)min((long)a.RX, a.rows - r0);
-  const size_t st = (size_t)a.RX * Nx;
-  load_twiddles(tw, a.twX, Nx >> 1);
+  const size_t st = (size_t)a.RX * LD;
+  load_twiddles<T, NT>(tw, a.twX, Nx >> 1);
   const int n = nr * Nx;
   for (int e = threadIdx.x; e < n; e += NT) {
-    s[e] = a.Z0[r0 * Nx + e]; s[st + e] = a.Z1[r0 * Nx + e]; s[2 * st + e] = a.Z2[r0 * Nx + e];
+    const int si = (e >> LGNX) * LD + pad(e & (Nx - 1));
+    s[si] = a.Z0[r0 * Nx + e]; s[st + si] = a.Z1[r0 * Nx + e]; s[2 * st + si] = a.Z2[r0 * Nx + e];
   }
   __syncthreads();
-  if (nr == a.RX) fft_dif(s, 3 * nr, Nx, a.lgNx, tw, a.lgNx);
-  else { fft_dif(s, nr, Nx, a.lgNx, tw, a.lgNx); fft_dif(s + st, nr, Nx, a.lgNx, tw, a.lgNx); fft_dif(s + 2 * st, nr, Nx, a.lgNx, tw, a.lgNx); }
+  if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX>(s, 3 * nr, tw);
+  else { fft_dif<T, NT, LD, LGNX, LGNX>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX>(s + st, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX>(s + 2 * st, nr, tw); }
   for (int e = threadIdx.x; e < n; e += NT) {
-    const T l = a.lx_r[e & (Nx - 1)];
-    const cx<T> z0 = s[e], z1 = s[st + e], z2 = s[2 * st + e];
-    const cx<T> kv = mk<T>(z0.x - l * z1.y - l * l * z2.x, z0.y + l * z1.x - l * l * z2.y);
+    const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
+    const T l = a.lx_r[i];
+    const cx<T> kv = s[si] + mul_il(s[st + si], l) - (l * l) * s[2 * st + si];
     const long gi = r0 * Nx + e;
     cx<T> y0 = a.Y0[gi];
     cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
@@ -481,11 +458,11 @@ __global__ __launch_bounds__(NT) void k_dphi_x(DphiXArgs<T> a) {
 // gradient / hessian multipliers for precompute (src/specialops.jl:184-188): F layout in, five F-layout outputs
 //   out[0]=i lx phi, out[1]=i ly phi, out[2]=-lx^2 phi, out[3]=(i lx)(i ly) phi, out[4]=-ly^2 phi
 template <typename T>
-__global__ __launch_bounds__(NT) void k_gradhess_mult(const cx<T>* __restrict__ phi, cx<T>* __restrict__ out,
+__global__ __launch_bounds__(NTP) void k_gradhess_mult(const cx<T>* __restrict__ phi, cx<T>* __restrict__ out,
                                                       const T* __restrict__ lx_r, const T* __restrict__ ly,
                                                       int lgNx, int Nyh, int B) {
   const long plane = (long)Nyh << lgNx;
-  const long i = (long)blockIdx.x * NT + threadIdx.x;
+  const long i = (long)blockIdx.x * NTP + threadIdx.x;
   if (i >= plane) return;
   const T lx = lx_r[i & ((1 << lgNx) - 1)], l_y = ly[i >> lgNx];
   for (int b = 0; b < B; ++b) {

@@ -28,8 +28,8 @@ template <typename T> struct HarmOpArgs {
 template <typename T> __device__ __forceinline__ T nan2zero(T v) { return isfinite(v) ? v : T(0); }
 
 template <typename T, int P>
-__global__ __launch_bounds__(NT) void k_harm_apply(HarmOpArgs<T> a) {
-  const long i = (long)blockIdx.x * NT + threadIdx.x;
+__global__ __launch_bounds__(NTP) void k_harm_apply(HarmOpArgs<T> a) {
+  const long i = (long)blockIdx.x * NTP + threadIdx.x;
   if (i >= a.plane) return;
   T c = 0, s = 0;
   if (P >= 2 && (a.in_qu || a.out_qu)) { c = a.cos2[i]; s = a.sin2[i]; }
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(NT) void k_harm_apply(HarmOpArgs<T> a) {
 // ---------------------------------------------------------------------------------------------
 // out[b][i] = a[b]*x[b][i] + c[b]*y[b][i]   on real views (complex arrays are passed as 2n reals).  grid (blocks, nb)
 template <typename T>
-__global__ __launch_bounds__(NT) void k_lincomb(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ y,
+__global__ __launch_bounds__(NTP) void k_lincomb(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ y,
                                                 BScal<T> a, BScal<T> c, long n, int b0) {
   const int b = blockIdx.y;
   const T av = a.v[b], cv = c.v[b];
   const long off = (long)(b0 + b) * n;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) {
     T r = av * x[off + i];
     if (y) r += cv * y[off + i];
     out[off + i] = r;
@@ -91,35 +91,35 @@ __global__ __launch_bounds__(NT) void k_lincomb(T* __restrict__ out, const T* __
 
 // out[b][p][i] = m[i] * in[b][p][i]  (pixel mask, src/dataset.jl:281)   grid (blocks, slices)
 template <typename T>
-__global__ __launch_bounds__(NT) void k_mask_mul(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ m, long n) {
+__global__ __launch_bounds__(NTP) void k_mask_mul(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ m, long n) {
   const long off = (long)blockIdx.y * n;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[off + i] = m[i] * in[off + i];
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) out[off + i] = m[i] * in[off + i];
 }
 
 // ---------------------------------------------------------------------------------------------
 // Reductions, deterministic two-pass (fixed partition, fixed tree), accumulated in double.
 template <int DUMMY = 0>
 __device__ __forceinline__ double block_sum(double v) {
-  __shared__ double red[NT / 64];
+  __shared__ double red[NTP / 64];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   double r = 0;
-  if (threadIdx.x == 0) { for (int w = 0; w < NT / 64; ++w) r += red[w]; }
+  if (threadIdx.x == 0) { for (int w = 0; w < NTP / 64; ++w) r += red[w]; }
   __syncthreads();
   return r;
 }
 
 // Fourier dot in F layout: sum lam[ky] * Re(conj(a) b)   (src/proj_lambert.jl:322-325); n = P*Nyh*Nx per batch
 template <typename T>
-__global__ __launch_bounds__(NT) void k_dot_F(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
+__global__ __launch_bounds__(NTP) void k_dot_F(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
                                               const T* __restrict__ lam, double* __restrict__ part,
                                               long n, int lgNx, int Nyh) {
   const int bt = blockIdx.y;
   const long off = (long)bt * n;
   double acc = 0;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) {
     const int ky = (int)((i >> lgNx) % Nyh);
     cx<T> u = a[off + i], v = b[off + i];
     acc += (double)lam[ky] * ((double)u.x * (double)v.x + (double)u.y * (double)v.y);
@@ -130,11 +130,11 @@ __global__ __launch_bounds__(NT) void k_dot_F(const cx<T>* __restrict__ a, const
 
 // Map dot: sum a*b  (src/proj_lambert.jl:318-321)
 template <typename T>
-__global__ __launch_bounds__(NT) void k_dot_map(const T* __restrict__ a, const T* __restrict__ b, double* __restrict__ part, long n) {
+__global__ __launch_bounds__(NTP) void k_dot_map(const T* __restrict__ a, const T* __restrict__ b, double* __restrict__ part, long n) {
   const int bt = blockIdx.y;
   const long off = (long)bt * n;
   double acc = 0;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT)
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP)
     acc += (double)a[off + i] * (double)b[off + i];
   double r = block_sum(acc);
   if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = r;
@@ -142,12 +142,12 @@ __global__ __launch_bounds__(NT) void k_dot_map(const T* __restrict__ a, const T
 
 // logdet of a real diagonal in F layout: sum lam * log|d|, non-finite -> 0  (src/proj_lambert.jl:331-336)
 template <typename T>
-__global__ __launch_bounds__(NT) void k_logdet_F(const T* __restrict__ d, const T* __restrict__ lam, double* __restrict__ part,
+__global__ __launch_bounds__(NTP) void k_logdet_F(const T* __restrict__ d, const T* __restrict__ lam, double* __restrict__ part,
                                                  long n, int lgNx, int Nyh) {
   const int bt = blockIdx.y;
   const long off = (long)bt * n;
   double acc = 0;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) {
     const int ky = (int)((i >> lgNx) % Nyh);
     double v = log(fabs((double)d[off + i])) * (double)lam[ky];
     acc += isfinite(v) ? v : 0.0;
@@ -156,10 +156,10 @@ __global__ __launch_bounds__(NT) void k_logdet_F(const T* __restrict__ d, const 
   if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = r;
 }
 
-__global__ __launch_bounds__(NT) void k_reduce_final(const double* __restrict__ part, double* __restrict__ out, int nblk, double scale) {
+__global__ __launch_bounds__(NTP) void k_reduce_final(const double* __restrict__ part, double* __restrict__ out, int nblk, double scale) {
   const int bt = blockIdx.x;
   double acc = 0;
-  for (int i = threadIdx.x; i < nblk; i += NT) acc += part[(long)bt * nblk + i];
+  for (int i = threadIdx.x; i < nblk; i += NTP) acc += part[(long)bt * nblk + i];
   double r = block_sum(acc);
   if (threadIdx.x == 0) out[bt] = r * scale;
 }
