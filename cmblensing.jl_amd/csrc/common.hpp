@@ -13,7 +13,7 @@ namespace cmbl {
 constexpr int NTP = 256;           // threads per workgroup of the pointwise / reduction / layout kernels
 // FFT-carrying kernels take their workgroup size as a template parameter NT (256, 512 or 1024)
 
-template <typename T> struct cx { T x, y; };
+template <typename T> struct alignas(2 * sizeof(T)) cx { T x, y; };   // 8/16-byte aligned: one ds_*_b64/b128, global_*_dwordx2/x4 per element
 
 template <typename T> __host__ __device__ __forceinline__ cx<T> mk(T a, T b) { cx<T> r; r.x = a; r.y = b; return r; }
 template <typename T> __host__ __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }

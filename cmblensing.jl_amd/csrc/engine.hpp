@@ -43,7 +43,8 @@ static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x
 // compiled column-tile shapes (lgM, R, NT):  C = R*NT >> lgM columns per workgroup
 #ifndef CMBL_COL_LIST
 #define CMBL_COL_LIST(X) X(4, 1, 256) X(5, 1, 256) X(5, 2, 256) X(6, 1, 256) X(6, 2, 256) X(7, 2, 256) X(7, 4, 256) X(8, 4, 256) X(8, 8, 256) \
-                         X(9, 4, 256) X(9, 8, 256) X(9, 16, 256) X(10, 8, 256) X(10, 16, 256) X(11, 8, 1024)
+                         X(9, 4, 256) X(9, 8, 256) X(9, 16, 256) X(10, 8, 256) X(10, 16, 256) X(11, 8, 1024) \
+                         X(8, 2, 512) X(8, 4, 512) X(9, 4, 512) X(9, 8, 512) X(10, 4, 512) X(10, 8, 512) X(9, 2, 1024) X(9, 4, 1024) X(10, 4, 1024)
 #endif
 #ifndef CMBL_ROW_LIST
 #define CMBL_ROW_LIST(X) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
@@ -159,7 +160,7 @@ struct Ctx : CtxBase {
 
   // ---- launch geometry -----------------------------------------------------------------------
   // Column kernels are compiled for the tile shapes of CMBL_COL_LIST: (lgM, R, NT) with C = R*NT/M columns per workgroup of
-  // NT threads and R packed pairs per thread.  Pick the widest tile that still gives >= 2 workgroups per CU, else the narrowest;
+  // NT threads and R packed pairs per thread.
   // CMBL_TUNE_C forces a width, CMBL_TUNE_RX the rows per workgroup of the row kernels (tuning aids).
   struct TileY { int C, NT, R; };
   TileY tileY(long slices, bool pair) const {
@@ -168,26 +169,30 @@ struct Ctx : CtxBase {
         CMBL_COL_LIST(CMBL_X)
 #undef CMBL_X
     };
-    const int forceC = env_int("CMBL_TUNE_C", 0);
-    TileY best{0, 0, 0}, narrow{0, 0, 0};
+    // Measured on MI355X (1024^2, B = 1..8): the kernels are bound by resident waves per CU (register file), not by segment
+    // width, so the narrowest tile with C >= 4 wins, 512 threads when compiled (more waves per tile, fewer registers per thread).
+    const int forceC = env_int("CMBL_TUNE_C", 0), forceNT = env_int("CMBL_TUNE_NT", 0);
+    TileY best{0, 0, 0};
+    long bestScore = -1;
     for (const auto& e : list) {
       if (e[0] != lgM) continue;
       const int C = (int)(((long)e[1] * e[2]) >> lgM);
       if (C > Nx || ldsY(C, pair) > 160 * 1024) continue;
       const TileY t{C, e[2], e[1]};
-      if (forceC == C) return t;
-      if (narrow.C == 0 || C < narrow.C) narrow = t;
-      if ((long)(Nx / C) * slices >= 512 && C > best.C) best = t;
+      if (forceC == C && (forceNT == 0 || forceNT == e[2])) return t;
+      const long score = (C >= 4 ? 1000 - C : C) * 10 + (e[2] == 512 ? 2 : (e[2] == 256 ? 1 : 0));
+      if (score > bestScore) { bestScore = score; best = t; }
     }
-    CMBL_REQUIRE(narrow.C > 0, ERR_SHAPE, "no compiled column-tile shape fits this Ny / precision");
-    return best.C ? best : narrow;
+    (void)slices;
+    CMBL_REQUIRE(best.C > 0, ERR_SHAPE, "no compiled column-tile shape fits this Ny / precision");
+    return best;
   }
   // column tile: twiddles + C columns of an N-point (pair) or M-point (packed) transform, padded rows
   size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
   int pickRX(int nbuf, long rows) const {
     int RX = env_int("CMBL_TUNE_RX", 0);
     if (RX <= 0) RX = (int)std::max<long>(1, std::min<long>(4096 / ((long)nbuf * Nx), rows / 1024));
-    RX = std::max(RX, (int)((256 * 4 + Nx - 1) / Nx));                  // keep every thread busy in a radix-4 stage
+    RX = std::max(RX, (int)((64 * 4 + Nx - 1) / Nx));                   // keep every lane of a wave busy in a radix-4 stage
     while (RX > 1 && ldsX(RX, nbuf) > 160 * 1024) RX >>= 1;
     CMBL_REQUIRE(ldsX(RX, nbuf) <= 160 * 1024, ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
     return RX;
@@ -201,9 +206,16 @@ struct Ctx : CtxBase {
 #undef CMBL_X
     if (!done) fail(ERR_SHAPE, "unsupported column tile");
   }
-  template <typename Fn> void dispatch_row(Fn&& fn) const {
+  // row kernels: workgroup of XNT threads (64 = one wave per row tile, no cross-wave barriers; 256 for big batches)
+  int pickXNT(long rows, int RX) const {
+    const int f = env_int("CMBL_TUNE_XNT", 0);
+    if (f == 64 || f == 256) return f;
+    return 256;                                    // one-wave workgroups measured slower (less intra-row parallelism)
+  }
+  template <typename Fn> void dispatch_row(int XNT, Fn&& fn) const {
     bool done = false;
-#define CMBL_X(lgnx) if (!done && lgNx == lgnx) { fn(std::integral_constant<int, lgnx>{}); done = true; }
+#define CMBL_X(lgnx) if (!done && lgNx == lgnx) { if (XNT == 64) fn(std::integral_constant<int, lgnx>{}, std::integral_constant<int, 64>{}); \
+                                                  else fn(std::integral_constant<int, lgnx>{}, std::integral_constant<int, 256>{}); done = true; }
     CMBL_ROW_LIST(CMBL_X)
 #undef CMBL_X
     if (!done) fail(ERR_SHAPE, "unsupported Nx");
@@ -236,9 +248,9 @@ struct Ctx : CtxBase {
   template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices) {
     const long rows = slices * Nyh;
     const int RX = pickRX(1, rows);
-    dispatch_row([&](auto lgnx) {
-      constexpr int LGNX = decltype(lgnx)::value;
-      CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), 256, (k_x_fft<T, MODE, 256, LGNX>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), stream, in, out,
+    dispatch_row(pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
+      constexpr int LGNX = decltype(lgnx)::value, XNT = decltype(xnt)::value;
+      CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), XNT, (k_x_fft<T, MODE, XNT, LGNX>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), stream, in, out,
                      twX.as<cx<T>>(), lx_r.as<T>(), rows, RX);
     });
   }
@@ -432,8 +444,9 @@ struct Flow {
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = out; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
         x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.rows = rows; x.rk = rk;
-        c->dispatch_row([&](auto lgnx) {
-          CMBL_LAUNCH_NT(c, K_ADJ_X, 256, (k_adj_x<T, 256, decltype(lgnx)::value>), dim3((unsigned)((rows + RX - 1) / RX)), c->ldsX(RX, 2), c->stream, x);
+        c->dispatch_row(c->pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
+          constexpr int XNT = decltype(xnt)::value;
+          CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rows + RX - 1) / RX)), c->ldsX(RX, 2), c->stream, x);
         });
       }
   }
@@ -478,8 +491,9 @@ struct Flow {
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
         x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX2; x.rows = rows; x.rk = rk;
-        c->dispatch_row([&](auto lgnx) {
-          CMBL_LAUNCH_NT(c, K_ADJ_X, 256, (k_adj_x<T, 256, decltype(lgnx)::value>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
+        c->dispatch_row(c->pickXNT(rows, RX2), [&](auto lgnx, auto xnt) {
+          constexpr int XNT = decltype(xnt)::value;
+          CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
         });
         // delta-phi
         DphiYArgs<T> py{};
@@ -493,8 +507,9 @@ struct Flow {
         DphiXArgs<T> px{};
         px.Z0 = Z0.as<cx<T>>(); px.Z1 = Z1.as<cx<T>>(); px.Z2 = Z2.as<cx<T>>(); px.Y0 = dphi; px.acc = Pacc.as<cx<T>>();
         px.twX = x.twX; px.lx_r = x.lx_r; px.RX = RX3; px.rows = rowsp; px.rk = rk;
-        c->dispatch_row([&](auto lgnx) {
-          CMBL_LAUNCH_NT(c, K_DPHI_X, 256, (k_dphi_x<T, 256, decltype(lgnx)::value>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), c->stream, px);
+        c->dispatch_row(c->pickXNT(rowsp, RX3), [&](auto lgnx, auto xnt) {
+          constexpr int XNT = decltype(xnt)::value;
+          CMBL_LAUNCH_NT(c, K_DPHI_X, XNT, (k_dphi_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), c->stream, px);
         });
       }
   }
