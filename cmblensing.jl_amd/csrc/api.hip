@@ -231,6 +231,46 @@ int cmbl_lenseflow_grad(cmbl_flow* L, int mode, const void* f_end, int bdel, con
   });
 }
 
+int cmbl_max_lensing_step(cmbl_flow* L, int basis, const void* phi, const void* eta, int nb, double* out) {
+  return guard([&] {
+    NOTNULL(L); NOTNULL(phi); NOTNULL(eta); NOTNULL(out); BASIS_OK(basis); CMBL_REQUIRE(nb >= 1, ERR_SHAPE, "nbatch >= 1");
+    BY_DTYPE(L->ctx, L->f32->max_lensing_step(basis, phi, eta, nb, out), L->f64->max_lensing_step(basis, phi, eta, nb, out));
+  });
+}
+
+// ---- small linear algebra / quadratic-estimate helpers ---------------------------------------------------
+int cmbl_axpby(cmbl_ctx* ctx, int basis, const double* a, const void* x, const double* b, const void* y, void* out, int P, int B) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(a); NOTNULL(x); NOTNULL(out); BASIS_OK(basis); POLB_OK(P, B);
+    CMBL_REQUIRE(y == nullptr || b != nullptr, ERR_ARG, "b is required when y is given");
+    const long n = (basis == B_MAP ? ctx->p->npix() : 2 * ctx->p->plane()) * P;
+    BY_DTYPE(ctx, C<float>(ctx)->lincomb((float*)out, (const float*)x, (const float*)y, a, b, n, B),
+             C<double>(ctx)->lincomb((double*)out, (const double*)x, (const double*)y, a, b, n, B));
+  });
+}
+int cmbl_qe_leg(cmbl_ctx* ctx, const void* in_fourier, int n, int p1, int p2, void* out_map, int B) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(in_fourier); NOTNULL(out_map); CMBL_REQUIRE(B >= 1 && n >= 0 && p1 >= 0 && p2 >= 0, ERR_ARG, "bad leg indices");
+    BY_DTYPE(ctx, C<float>(ctx)->qe_leg((const cx<float>*)in_fourier, (float*)out_map, n, p1, p2, B),
+             C<double>(ctx)->qe_leg((const cx<double>*)in_fourier, (double*)out_map, n, p1, p2, B));
+  });
+}
+int cmbl_fourier_lmul(cmbl_ctx* ctx, const void* in_map, int p1, int p2, int take_abs, void* out_fourier, int B) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(in_map); NOTNULL(out_fourier); CMBL_REQUIRE(B >= 1 && p1 >= 0 && p2 >= 0, ERR_ARG, "bad exponents");
+    BY_DTYPE(ctx, C<float>(ctx)->fourier_lmul((const float*)in_map, (cx<float>*)out_fourier, p1, p2, take_abs != 0, B),
+             C<double>(ctx)->fourier_lmul((const double*)in_map, (cx<double>*)out_fourier, p1, p2, take_abs != 0, B));
+  });
+}
+int cmbl_map_fma(cmbl_ctx* ctx, const void* a, const void* b, double scale, void* out, int accumulate, int nslices) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(a); NOTNULL(b); NOTNULL(out); CMBL_REQUIRE(nslices >= 1, ERR_SHAPE, "nslices >= 1");
+    const long n = ctx->p->npix() * nslices;
+    BY_DTYPE(ctx, C<float>(ctx)->map_fma((float*)out, (const float*)a, (const float*)b, scale, accumulate != 0, n),
+             C<double>(ctx)->map_fma((double*)out, (const double*)a, (const double*)b, scale, accumulate != 0, n));
+  });
+}
+
 // ---- dataset ---------------------------------------------------------------------------------------
 int cmbl_dataset_create(cmbl_ctx* ctx, int npol, cmbl_dataset** out) {
   return guard([&] {

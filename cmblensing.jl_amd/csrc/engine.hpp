@@ -313,6 +313,28 @@ struct Ctx : CtxBase {
     finish_reduce(1, 1.0, out_host);
   }
 
+  // ---- quadratic-estimate / line-search helpers --------------------------------------------------
+  // QE_leg (src/quadratic_estimate.jl:89-91): Fourier S0 field (reference layout) -> map
+  void qe_leg(const cx<T>* in_ref, T* out_map, int n, int p1, int p2, int B) {
+    tmpA.ensure(sizeof(cx<T>) * B * plane());
+    cx<T>* F = tmpA.as<cx<T>>();
+    ref2F(in_ref, F, B);
+    CMBL_LAUNCH(this, K_HARM, (k_qe_leg<T>), dim3((unsigned)((plane() + NTP - 1) / NTP)), 0, stream, F, F, lx_r.as<T>(), ly.as<T>(), lgNx, plane(), B, n, p1, p2, 0);
+    x_pass<1>(F, F, B); y_c2r(F, out_map, B);
+  }
+  // (i lx)^p1 (i ly)^p2 * rfft2(map)  (or its modulus, stored in the real part) -> Fourier reference layout
+  void fourier_lmul(const T* in_map, cx<T>* out_ref, int p1, int p2, bool take_abs, int B) {
+    tmpA.ensure(sizeof(cx<T>) * B * plane());
+    cx<T>* F = tmpA.as<cx<T>>();
+    rfft2_F(in_map, F, B);
+    CMBL_LAUNCH(this, K_HARM, (k_qe_leg<T>), dim3((unsigned)((plane() + NTP - 1) / NTP)), 0, stream, F, F, lx_r.as<T>(), ly.as<T>(), lgNx, plane(), B, 0, p1, p2, take_abs ? 1 : 0);
+    F2ref(F, out_ref, B);
+  }
+  void map_fma(T* out, const T* a, const T* b, double scale, bool accumulate, long n) {
+    const unsigned gx = (unsigned)std::min<long>((n + NTP - 1) / NTP, 4096);
+    CMBL_LAUNCH(this, K_LINCOMB, (k_map_fma<T>), dim3(gx), 0, stream, out, a, b, (T)scale, accumulate ? 1 : 0, n);
+  }
+
   // ---- basis conversion between reference-layout arrays and the internal F layout ----------------
   // to F: out_F is (P*B*plane) complex in `want` (B_FOURIER = QU Fourier, B_HARMONIC = EB Fourier)
   void to_F(int basis_in, const void* in, cx<T>* out_F, int want, int P, int B) {
@@ -371,6 +393,29 @@ struct Flow {
     phiF.ensure(sizeof(cx<T>) * nb * c->plane());
     c->to_F(basis, phi, phiF.as<cx<T>>(), B_FOURIER, 1, nb);
     set_phi_F(phiF.as<cx<T>>(), nb);
+  }
+
+  // gradhess maps [5][nb][npix] of an S0 field given in F layout (scratch: gh)
+  void gradhess_maps(const cx<T>* phi_F, T* maps, int nb) {
+    const long pl = c->plane();
+    gh.ensure(sizeof(cx<T>) * 5 * nb * pl);
+    CMBL_LAUNCH(c, K_GRADHESS, (k_gradhess_mult<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
+                c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
+    c->template x_pass<1>(gh.as<cx<T>>(), gh.as<cx<T>>(), 5L * nb);
+    c->y_c2r(gh.as<cx<T>>(), maps, 5L * nb);
+  }
+  // get_max_lensing_step (src/lenseflow.jl:242-256); does not touch the flow's own phi cache
+  void max_lensing_step(int basis, const void* phi, const void* eta, int nb, double* out_host) {
+    CMBL_REQUIRE(nb <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    const long np = c->npix();
+    DevBuf mp, me, pf;
+    mp.ensure(sizeof(T) * 5 * nb * np); me.ensure(sizeof(T) * 5 * nb * np); pf.ensure(sizeof(cx<T>) * nb * c->plane());
+    c->to_F(basis, phi, pf.as<cx<T>>(), B_FOURIER, 1, nb); gradhess_maps(pf.as<cx<T>>(), mp.as<T>(), nb);
+    c->to_F(basis, eta, pf.as<cx<T>>(), B_FOURIER, 1, nb); gradhess_maps(pf.as<cx<T>>(), me.as<T>(), nb);
+    CMBL_LAUNCH(c, K_REDUCE, (k_max_step<T>), dim3(Ctx<T>::RED_BLOCKS, nb), 0, c->stream, mp.as<T>(), me.as<T>(), c->red_part.template as<double>(), np, (long)nb * np);
+    CMBL_LAUNCH(c, K_REDUCE, k_min_final, dim3(nb), 0, c->stream, c->red_part.template as<double>(), c->red_out.template as<double>(), Ctx<T>::RED_BLOCKS);
+    CMBL_HIP(hipMemcpyAsync(out_host, c->red_out.p, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+    CMBL_HIP(hipStreamSynchronize(c->stream));
   }
 
   RKCoef<T> coef(int step, int stage, double t0, double h, bool last) const {

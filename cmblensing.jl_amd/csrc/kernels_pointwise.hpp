@@ -164,4 +164,78 @@ __global__ __launch_bounds__(NTP) void k_reduce_final(const double* __restrict__
   if (threadIdx.x == 0) out[bt] = r * scale;
 }
 
+// ---------------------------------------------------------------------------------------------
+// quadratic_estimate building blocks (src/quadratic_estimate.jl:83-91): one "leg"
+//   out = nan2zero( in * (i lx)^p1 * (i ly)^p2 / |l|^n )      in F layout (S0, batched); caller inverse-transforms it.
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_qe_leg(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, const T* __restrict__ lx_r,
+                                                const T* __restrict__ ly, int lgNx, long plane, int B, int n, int p1, int p2, int take_abs) {
+  const long i = (long)blockIdx.x * NTP + threadIdx.x;
+  if (i >= plane) return;
+  const T lx = lx_r[i & ((1 << lgNx) - 1)], l_y = ly[i >> lgNx];
+  T mag = T(1);
+  for (int k = 0; k < p1; ++k) mag *= lx;
+  for (int k = 0; k < p2; ++k) mag *= l_y;
+  if (n > 0) { const T lm = sqrt(lx * lx + l_y * l_y); for (int k = 0; k < n; ++k) mag /= lm; }
+  const int rot = (p1 + p2) & 3;                          // i^(p1+p2)
+  for (int b = 0; b < B; ++b) {
+    const cx<T> v = in[(long)b * plane + i];
+    cx<T> r = mk<T>(mag * v.x, mag * v.y);
+    if (rot == 1) r = mul_i(r); else if (rot == 2) r = mk<T>(-r.x, -r.y); else if (rot == 3) r = mul_mi(r);
+    r = mk<T>(nan2zero(r.x), nan2zero(r.y));
+    if (take_abs) r = mk<T>(sqrt(r.x * r.x + r.y * r.y), T(0));
+    out[(long)b * plane + i] = r;
+  }
+}
+
+// out = (accumulate ? out : 0) + scale * a * b   (maps)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_map_fma(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b, T scale, int accumulate, long n) {
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) {
+    const T v = scale * a[i] * b[i];
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+// get_max_lensing_step (src/lenseflow.jl:242-256): per pixel the two roots alpha of det(I + H(phi) + alpha H(eta)) = 0,
+// minimum over the positive ones.  hp/he: [5][B][npix] maps from gradhess (gx, gy, Hxx, Hyx, Hyy); part: per-block minima.
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_max_step(const T* __restrict__ hp, const T* __restrict__ he, double* __restrict__ part, long npix, long comp_stride) {
+  const int bt = blockIdx.y;
+  double best = 1e300;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
+    const long o = (long)bt * npix + i;
+    const double p11 = hp[2 * comp_stride + o], p12 = hp[3 * comp_stride + o], p22 = hp[4 * comp_stride + o];
+    const double e11 = he[2 * comp_stride + o], e12 = he[3 * comp_stride + o], e22 = he[4 * comp_stride + o];
+    const double a = e11 * e22 - e12 * e12;
+    const double b = e11 * (1 + p22) + e22 * (1 + p11) - 2 * e12 * p12;
+    const double c = (1 + p11) * (1 + p22) - p12 * p12;
+    const double sq = sqrt(b * b - 4 * a * c);
+    const double a1 = (-b + sq) / (2 * a), a2 = (-b - sq) / (2 * a);
+    if (a1 > 0 && a1 < best) best = a1;
+    if (a2 > 0 && a2 < best) best = a2;
+  }
+  __shared__ double red[NTP / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmin(best, __shfl_down(best, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = red[0];
+    for (int w = 1; w < NTP / 64; ++w) r = fmin(r, red[w]);
+    part[(long)bt * gridDim.x + blockIdx.x] = r;
+  }
+}
+__global__ __launch_bounds__(NTP) void k_min_final(const double* __restrict__ part, double* __restrict__ out, int nblk) {
+  __shared__ double red[NTP / 64];
+  const int bt = blockIdx.x;
+  double best = 1e300;
+  for (int i = threadIdx.x; i < nblk; i += NTP) best = fmin(best, part[(long)bt * nblk + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmin(best, __shfl_down(best, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) { double r = red[0]; for (int w = 1; w < NTP / 64; ++w) r = fmin(r, red[w]); out[bt] = r; }
+}
+
 }  // namespace cmbl

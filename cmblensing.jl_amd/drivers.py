@@ -1,0 +1,303 @@
+"""Host-side drivers on top of the C-ABI operators: quadratic_estimate, MAP_joint, the HMC / Gibbs passes of sample_joint.
+
+These mirror the reference's Julia drivers (src/quadratic_estimate.jl, src/maximization.jl:116-233, src/sampling.jl:14-46,
+388-464): control flow on the host, every field operation a library call.
+"""
+import itertools
+
+import numpy as np
+import torch
+
+from .engine import Field, MAP, FOURIER, HARMONIC
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def brent_minimize(f, lo, hi, abs_tol=1e-4, rel_tol=None, max_iter=1000):
+    """Brent's bounded 1-D minimiser (golden section + successive parabolic interpolation), the algorithm behind
+    `Optim.optimize(f, lo, hi, Brent(); abs_tol)` used at src/maximization.jl:194-199.  Returns (xmin, fmin, nfev)."""
+    rel_tol = np.sqrt(np.finfo(float).eps) if rel_tol is None else rel_tol
+    golden = (3 - np.sqrt(5)) / 2
+    x = w = v = lo + golden * (hi - lo)
+    fx = fw = fv = f(x)
+    nfev, step, old_step = 1, 0.0, 0.0
+    for _ in range(max_iter):
+        mid = (lo + hi) / 2
+        tol = rel_tol * abs(x) + abs_tol
+        if abs(x - mid) <= 2 * tol - (hi - lo) / 2:
+            break
+        p = q = 0.0
+        if abs(old_step) > tol:
+            r = (x - w) * (fx - fv)
+            q = (x - v) * (fx - fw)
+            p = (x - v) * q - (x - w) * r
+            q = 2 * (q - r)
+            if q > 0:
+                p = -p
+            else:
+                q = -q
+        if abs(p) < abs(q * old_step / 2) and p > q * (lo - x) and p < q * (hi - x):
+            old_step, step = step, p / q
+            xt = x + step
+            if (xt - lo) < 2 * tol or (hi - xt) < 2 * tol:
+                step = tol if x < mid else -tol
+        else:
+            old_step = (hi - x) if x < mid else (lo - x)
+            step = golden * old_step
+        u = x + (step if abs(step) >= tol else (tol if step > 0 else -tol))
+        fu = f(u)
+        nfev += 1
+        if fu <= fx:
+            if u < x:
+                hi = x
+            else:
+                lo = x
+            v, fv, w, fw, x, fx = w, fw, x, fx, u, fu
+        else:
+            if u < x:
+                lo = u
+            else:
+                hi = u
+            if fu <= fw or w == x:
+                v, fv, w, fw = w, fw, u, fu
+            elif fu <= fv or v == x or v == w:
+                v, fv = u, fu
+    return x, fx, nfev
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _eps3(a, b):
+    return 1 if (a, b) == (1, 2) else (-1 if (a, b) == (2, 1) else 0)
+
+
+def _inds(D):
+    return list(itertools.product((1, 2), repeat=D))
+
+
+class _Legs:
+    """memoised QE_leg evaluations (src/quadratic_estimate.jl:83-91): key = (field id, n, p1, p2)"""
+
+    def __init__(self, proj):
+        self.proj, self.cache, self.keep = proj, {}, []
+
+    def __call__(self, C, *inds):
+        n = sum(1 for x in inds if isinstance(x, int))
+        first = [x[0] if isinstance(x, tuple) else x for x in inds]
+        key = (id(C), n, first.count(1), first.count(2))
+        if key not in self.cache:
+            self.keep.append(C)
+            self.cache[key] = self.proj.qe_leg(C, n, first.count(1), first.count(2))
+        return self.cache[key]
+
+
+def quadratic_estimate(ds, which=None, wiener_filtered=True, AL=None):
+    """`quadratic_estimate(ds, which)` (src/quadratic_estimate.jl:29-47) with unlensed weights, using the Fourier-diagonal
+    approximations M̂·B̂, Cn̂ exactly like the reference.  Returns dict(phiqe [Field FOURIER], AL, Nphi) (planes as numpy)."""
+    proj, h = ds.proj, ds.host
+    which = which or ("TT" if ds.P == 1 else "EB")
+    off = {1: {"T": 0}, 2: {"E": 0, "B": 1}, 3: {"T": 0, "E": 3, "B": 4}}[ds.P]          # plane index (BlockDiagIEB: TT,TE,ET,EE,BB)
+    dof = {1: {"T": 0}, 2: {"E": 0, "B": 1}, 3: {"T": 0, "E": 1, "B": 2}}[ds.P]          # data component index
+    plane = lambda op, k: np.asarray(op.p[off[k]], float)
+    Bsz = ds.d.arr.shape[0]
+
+    def fld(a, batch=False):                          # numpy plane or (B,1,..) array -> complex device tensor (B or 1,1,Nx,Nyh)
+        a = np.asarray(a)
+        a = a[None, None] if a.ndim == 2 else a
+        return proj.tensor(a.astype(np.complex128))
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        def filt(k, extra=1.0):                       # extra * (Σtot \ (TF * d[k]))   host-side diagonal algebra, device data
+            TFk = plane(h["Mf"], k) * plane(h["B"], k)
+            S = TFk ** 2 * plane(h["Cftilde"], k) + plane(h["Cn"], k)
+            w = TFk / S * extra
+            w[~np.isfinite(w)] = 0
+            dk = ds.d.arr[:, dof[k]:dof[k] + 1].contiguous()
+            return dk * proj.tensor(w)[None, None].to(dk.dtype)
+        W = {}
+        for k in off:
+            TFk = plane(h["Mf"], k) * plane(h["B"], k)
+            S = TFk ** 2 * plane(h["Cftilde"], k) + plane(h["Cn"], k)
+            iS = 1 / S
+            iS[~np.isfinite(iS)] = 0
+            C = plane(h["Cf"], k)
+            W[k] = (fld(TFk ** 2 * iS), fld(TFk ** 2 * C * iS), fld(TFk ** 2 * C ** 2 * iS))   # orders 0, 1, 2 in C
+    L = _Legs(proj)
+    mul = lambda a, b, s=1.0, out=None: proj.map_fma(a, b, s, out)
+
+    if which == "TT":
+        a, b = filt("T"), filt("T", plane(h["Cf"], "T"))
+        un = None
+        for i in (1, 2):
+            t = proj.fourier_lmul(mul(L(a), L(b, (i,))), int(i == 1), int(i == 2))
+            un = proj.axpby(-1.0, t, basis=FOURIER) if un is None else proj.axpby(1.0, un, -1.0, t, basis=FOURIER)
+        w0, w1, w2 = W["T"]
+        def A(i, j):
+            acc = mul(L(w2, (i,), (j,)), L(w0))
+            return mul(L(w1, (i,)), L(w1, (j,)), 1.0, acc)
+    elif which == "EE":
+        a1, a2 = filt("E", plane(h["Cf"], "E")), filt("E")
+        un = None
+        for i in (1, 2):
+            acc = None
+            for (j, k) in _inds(2):
+                acc = mul(L(a1, (i,), j, k), L(a2, j, k), -2.0, acc)
+            acc = mul(L(a1, (i,)), L(a2), 1.0, acc)
+            t = proj.fourier_lmul(acc, int(i == 1), int(i == 2))
+            un = t if un is None else proj.axpby(1.0, un, 1.0, t, basis=FOURIER)
+        w0, w1, w2 = W["E"]
+        def A(i, j):
+            acc = None
+            for (k, l, m, n, p, q) in _inds(6):
+                e = _eps3(m, p) * _eps3(n, q)
+                if e:
+                    acc = mul(L(w2, (i,), (j,), k, l, m, n), L(w0, k, l, p, q), -4.0 * e, acc)
+                    acc = mul(L(w1, (i,), k, l, m, n), L(w1, (j,), k, l, p, q), -4.0 * e, acc)
+            acc = mul(L(w2, (i,), (j,)), L(w0), 1.0, acc)
+            return mul(L(w1, (i,)), L(w1, (j,)), 1.0, acc)
+    elif which == "EB":
+        e1, b2 = filt("E"), filt("B")
+        ce1, cb2 = filt("E", plane(h["Cf"], "E")), filt("B", plane(h["Cf"], "B"))
+        un = None
+        for i in (1, 2):
+            acc = None
+            for (j, k, l) in _inds(3):
+                e = _eps3(k, l)
+                if e:
+                    acc = mul(L(ce1, (i,), j, k), L(b2, j, l), 2.0 * e, acc)
+                    acc = mul(L(e1, j, k), L(cb2, (i,), j, l), -2.0 * e, acc)
+            t = proj.fourier_lmul(acc, int(i == 1), int(i == 2))
+            un = t if un is None else proj.axpby(1.0, un, 1.0, t, basis=FOURIER)
+        (E0, E1, E2), (B0, B1, B2) = W["E"], W["B"]
+        def A(i, j):
+            acc = None
+            for (k, l, m, n, p, q) in _inds(6):
+                e = _eps3(m, p) * _eps3(n, q)
+                if e:
+                    acc = mul(L(E2, (i,), (j,), k, l, m, n), L(B0, k, l, p, q), 4.0 * e, acc)
+                    acc = mul(L(E1, (i,), k, l, m, n), L(B1, (j,), k, l, p, q), -8.0 * e, acc)
+                    acc = mul(L(E0, k, l, m, n), L(B2, (i,), (j,), k, l, p, q), 4.0 * e, acc)
+            return acc
+    else:
+        raise ValueError(f"which={which!r} not implemented")          # src/quadratic_estimate.jl:41
+
+    if AL is None:
+        tot = None
+        for (i, j) in _inds(2):
+            t = proj.fourier_lmul(A(i, j), int(i == 1) + int(j == 1), int(i == 2) + int(j == 2), take_abs=True)
+            tot = t if tot is None else proj.axpby(1.0, tot, 1.0, t, basis=FOURIER)
+        tot = tot[0, 0].real.double().cpu().numpy()
+        with np.errstate(divide="ignore"):
+            AL = 1 / tot
+        AL[~np.isfinite(AL)] = 0
+    Cphi = np.asarray(h["Cphi"], float)
+    wf = AL.copy()
+    if wiener_filtered:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            g = Cphi / (Cphi + AL)
+        g[~np.isfinite(g)] = 0
+        wf = g * AL
+    phiqe = proj.diag_apply(wf[None], un, FOURIER, FOURIER)
+    return dict(phiqe=Field(proj, phiqe, FOURIER), AL=AL, Nphi=AL.copy())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def MAP_joint_step(ds, phi, fstart=None, alpha_prev=1.0, alpha_tol=1e-4, alpha_max=None, cg_tol=1e-1, cg_nsteps=500):
+    """One iteration of the `MAP_joint` loop body (src/maximization.jl:160-206) at fiducial θ with G = I (:146)."""
+    proj, h = ds.proj, ds.host
+    Ginv_saved = ds.ops["G_inv"]
+    ds.set_op("G_inv", np.ones_like(h["Cphi"])[None])
+    try:
+        f, hist = ds.argmaxf_logpdf(phi, fstart=fstart, tol=cg_tol, nsteps=cg_nsteps)              # :164-169
+        fo, po = ds.mix(f, phi, G=np.ones_like(h["Cphi"]))                                         # :176
+        lp0, gfo, gpo = ds.gradient_logpdf_mixed(fo, po)                                           # :178
+        with np.errstate(divide="ignore"):
+            Hinv = 1 / (_pinv(h["Cphi"]) + _pinv(h["Nphi"]))                                       # dataset.jl:134-137
+        Hinv[~np.isfinite(Hinv)] = 0
+        dphi = Field(proj, proj.diag_apply(Hinv[None], gpo.arr, FOURIER, FOURIER), FOURIER)        # :188
+        amax = 2 * alpha_prev if alpha_max is None else alpha_max                                  # :193
+        def neg(a):
+            v = -float(np.sum(ds.logpdf_mixed(fo, proj.axpby(1.0, po, a, dphi))))
+            return v if np.isfinite(v) else (a / amax) * np.finfo(np.float64).max                  # :198
+        alpha, _, nls = brent_minimize(neg, 0.0, amax, abs_tol=alpha_tol)                          # :194-199
+        po2 = proj.axpby(1.0, po, alpha, dphi)                                                     # :201
+        lp = ds.logpdf_mixed(fo, po2)                                                              # :205
+        f2, phi2 = ds.unmix(fo, po2, G=np.ones_like(h["Cphi"]))                                    # :206
+        return dict(f=f, phi=phi2, f_mixed=fo, phi_mixed=po2, grad_phi=gpo, dphi=dphi, alpha=alpha, logpdf=lp, logpdf_before=lp0,
+                    cg_hist=hist, linesearch_evals=nls, dphi_norm=float(np.sqrt(np.sum(dphi.dot(dphi)))))
+    finally:
+        ds.set_op("G_inv", Ginv_saved)
+
+
+def MAP_joint(ds, nsteps=20, phi_start=None, **kw):
+    """`MAP_joint(ds; nsteps)` (src/maximization.jl:116-233): returns (f, ϕ, history)."""
+    proj = ds.proj
+    B = ds.d.arr.shape[0]
+    phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER) if phi_start is None else phi_start
+    f, alpha, hist = None, 1.0, []
+    for _ in range(nsteps):
+        st = MAP_joint_step(ds, phi, fstart=f, alpha_prev=alpha, **kw)
+        f, phi, alpha = st["f"], st["phi"], st["alpha"]
+        hist.append(dict(logpdf=st["logpdf"], alpha=alpha, ncg=len(st["cg_hist"]), dphi_norm=st["dphi_norm"],
+                         linesearch_evals=st["linesearch_evals"]))
+    return f, phi, hist
+
+
+def _pinv(x):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = 1.0 / np.asarray(x, float)
+    r[~np.isfinite(r)] = 0
+    return r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def mass_matrix_phi(ds):
+    """src/sampling.jl:422-425"""
+    h = ds.host
+    return _pinv(h["G"]) ** 2 * (_pinv(h["Cphi"]) + _pinv(h["Nphi"]))
+
+
+def symplectic_integrate(proj, x0, p0, Lam, U, dUdx, N=50, eps=0.1):
+    """src/sampling.jl:14-46 on FOURIER Fields; Λ a real plane.  Returns (ΔH, x, p)."""
+    Li = _pinv(Lam)[None]
+    Linv = lambda p: Field(proj, proj.diag_apply(Li, p.arr, FOURIER, FOURIER), FOURIER)
+    H = lambda x, p: U(x) - p.dot(Linv(p)) / 2
+    x, p = x0, p0
+    g = dUdx(x)
+    for _ in range(N):
+        x1 = proj.axpby(1.0, x, -eps, Linv(proj.axpby(1.0, p, -eps / 2, g)))
+        g1 = dUdx(x1)
+        p = proj.axpby(1.0, p, -eps / 2, proj.axpby(1.0, g1, 1.0, g))
+        x, g = x1, g1
+    return H(x, p) - H(x0, p0), x, p
+
+
+def hmc_step(ds, fo, po, white_p, log_u, N=25, eps=0.01, always_accept=False, alias_quirk=False):
+    """`hmc_step` (src/sampling.jl:405-418) over ϕ° with U = logpdf(Mixed(ds)); white_p / log_u are the injected draws."""
+    proj = ds.proj
+    Lam = mass_matrix_phi(ds)
+    p0 = Field(proj, proj.diag_apply(np.sqrt(Lam)[None], proj.rfft(proj.tensor(white_p)), FOURIER, FOURIER), FOURIER)
+    U = lambda x: ds.logpdf_mixed(fo, x)
+    dU = lambda x: ds.gradient_logpdf_mixed(fo, x, alias_quirk=alias_quirk)[2]
+    dH, xt, _ = symplectic_integrate(proj, po, p0, Lam, U, dU, N=N, eps=eps)
+    accept = np.logical_or(always_accept, np.asarray(log_u) < dH)
+    x = proj.axpby(accept.astype(float), xt, 1.0 - accept.astype(float), po)      # x = accept*xtest + (1-accept)*x   (:415)
+    return x, dH, accept
+
+
+def sample_f(ds, phi, white_f, white_n, fstart=None, tol=1e-1, nsteps=500):
+    """`sample_f` (src/maximization.jl:56-62)"""
+    proj, h = ds.proj, ds.host
+    raw = lambda w, op: Field(proj, proj.diag_apply(op.sqrt().p, proj.rfft(proj.tensor(w)), HARMONIC, HARMONIC), HARMONIC)
+    fs, ns = raw(white_f, h["Cf"]), raw(white_n, h["Cn"])
+    dsim = ds.mean(fs, phi) + ns
+    df, hist = ds.argmaxf_logpdf(phi, d=ds.d - dsim, fstart=fstart, tol=tol, nsteps=nsteps)
+    return fs + df, hist
+
+
+def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always_accept=False):
+    """One `sample_joint` step at fixed θ (src/sampling.jl:187-193, 388-464)."""
+    f, hist = sample_f(ds, phi, white_f, white_n)
+    fo, po = ds.mix(f, phi)
+    po2, dH, accept = hmc_step(ds, fo, po, white_p, log_u, N=N, eps=eps, always_accept=always_accept)
+    f2, phi2 = ds.unmix(fo, po2)
+    lp = ds.logpdf(f2, phi2)
+    return dict(f=f2, phi=phi2, dH=dH, accept=accept, logpdf=lp, cg_hist=hist)

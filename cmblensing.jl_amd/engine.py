@@ -151,6 +151,47 @@ class ProjLambert:
         check(self.lib.cmbl_dot(self._h, basis, _ptr(a), _ptr(b), P, B, out))
         return np.array(out[:])
 
+    # ---- helpers for the drivers (CG / line-search / leapfrog axpys, quadratic-estimate legs)
+    def axpby(self, a, x, b=None, y=None, basis=None):
+        """a·x + b·y with scalars or per-batch vectors (src/batching.jl BatchedReal broadcasting)"""
+        arr = x.arr if isinstance(x, Field) else x
+        basis = x.basis if isinstance(x, Field) else basis
+        P, B = self._check(arr, basis)
+        av = (ctypes.c_double * B)(*np.broadcast_to(np.asarray(a, float), (B,)))
+        out = self.empty(basis, P, B)
+        if y is None:
+            check(self.lib.cmbl_axpby(self._h, basis, av, _ptr(arr), None, None, _ptr(out), P, B))
+        else:
+            yarr = y.to(basis).arr if isinstance(y, Field) else y
+            self._check(yarr, basis)
+            bv = (ctypes.c_double * B)(*np.broadcast_to(np.asarray(b, float), (B,)))
+            check(self.lib.cmbl_axpby(self._h, basis, av, _ptr(arr), bv, _ptr(yarr), _ptr(out), P, B))
+        return Field(self, out, basis) if isinstance(x, Field) else out
+
+    def qe_leg(self, fl, n, p1, p2):
+        """QE_leg (src/quadratic_estimate.jl:89-91): Fourier S0 tensor (B,1,Nx,Nyh) -> map tensor"""
+        P, B = self._check(fl, FOURIER)
+        assert P == 1
+        out = self.empty(MAP, 1, B)
+        check(self.lib.cmbl_qe_leg(self._h, _ptr(fl), n, p1, p2, _ptr(out), B))
+        return out
+
+    def fourier_lmul(self, m, p1, p2, take_abs=False):
+        P, B = self._check(m, MAP)
+        assert P == 1
+        out = self.empty(FOURIER, 1, B)
+        check(self.lib.cmbl_fourier_lmul(self._h, _ptr(m), p1, p2, 1 if take_abs else 0, _ptr(out), B))
+        return out
+
+    def map_fma(self, a, b, scale=1.0, out=None):
+        P, B = self._check(a, MAP)
+        self._check(b, MAP)
+        acc = out is not None
+        if out is None:
+            out = self.empty(MAP, P, B)
+        check(self.lib.cmbl_map_fma(self._h, _ptr(a), _ptr(b), float(scale), _ptr(out), 1 if acc else 0, P * B))
+        return out
+
     def logdet(self, diag):
         d = self.tensor(diag)
         d = d.reshape(-1, self.Nx, self.Nyh)
@@ -173,13 +214,16 @@ class Field:
         return self.proj.dot(self.arr, o.arr, self.basis)
 
     def __add__(self, o):
-        return Field(self.proj, self.arr + o.to(self.basis).arr, self.basis)
+        return self.proj.axpby(1.0, self, 1.0, o)
 
     def __sub__(self, o):
-        return Field(self.proj, self.arr - o.to(self.basis).arr, self.basis)
+        return self.proj.axpby(1.0, self, -1.0, o)
 
     def __rmul__(self, s):
-        return Field(self.proj, self.arr * s, self.basis)
+        return self.proj.axpby(s, self)
+
+    def __neg__(self):
+        return self.proj.axpby(-1.0, self)
 
 
 class _Adjoint:
@@ -246,6 +290,14 @@ class LenseFlow:
     def adjoint(self):
         return _Adjoint(self)
 
+    def max_lensing_step(self, phi, eta):
+        """get_max_lensing_step (src/lenseflow.jl:242-256), one value per batch slot"""
+        eta = eta.to(phi.basis)
+        P, B = self.proj._check(phi.arr, phi.basis)
+        out = (ctypes.c_double * B)()
+        check(self.lib.cmbl_max_lensing_step(self._h, phi.basis, _ptr(phi.arr), _ptr(eta.arr), B, out))
+        return np.array(out[:])
+
     def gradient(self, mode, f_end, delta, alias_quirk=False, basis_df=None):
         """Pullback of `L*f` (mode=FLOW_FWD) or `L\\f` (FLOW_INV) (src/flowops.jl:40-68).
         f_end: primal OUTPUT (map Field); delta: cotangent.  Returns (δϕ [FOURIER], δf, f_start)."""
@@ -287,7 +339,8 @@ class BaseDataSet:
         self.d = None
         if d is not None:
             self.set_data(d)
-        check(self.lib.cmbl_dataset_set_logdet(self._h, float(logdet_sum)))
+        self.logdet_sum = float(logdet_sum)
+        check(self.lib.cmbl_dataset_set_logdet(self._h, self.logdet_sum))
 
     def __del__(self):
         try:
@@ -296,6 +349,42 @@ class BaseDataSet:
                 self._h = None
         except Exception:
             pass
+
+    def set_op(self, name, planes):
+        t = self.proj.tensor(planes)
+        t = t.reshape(1, *t.shape) if t.dim() == 2 else t
+        self.ops[name] = t
+        check(self.lib.cmbl_dataset_set_op(self._h, self._ids[name], _ptr(t), t.shape[0]))
+
+    def _apply(self, name, f, basis_out=HARMONIC):
+        """harmonic-basis operator `name` applied to Field f"""
+        return Field(self.proj, self.proj.diag_apply(self.ops[name], f.arr, HARMONIC, f.basis, basis_out), basis_out)
+
+    def _mask(self, f):
+        """M = Mfourier * Mpix (src/dataset.jl:279-285) on a Field; returns HARMONIC"""
+        if "Mpix" in self.ops:
+            m = f.to(MAP)
+            key = tuple(m.arr.shape)
+            if getattr(self, "_mask_full", (None, None))[0] != key:
+                self._mask_full = (key, self.ops["Mpix"].reshape(1, 1, self.proj.Nx, self.proj.Ny).expand(*key).contiguous())
+            f = Field(self.proj, self.proj.map_fma(m.arr, self._mask_full[1]), MAP)
+        return self._apply("Mf", f)
+
+    def mean(self, f, phi):
+        """μ = M·B·L(ϕ)·f (src/dataset.jl:59-66)"""
+        ft = self.L(phi) * f.to(MAP)
+        return self._mask(self._apply("B", ft))
+
+    def logpdf(self, f, phi, d=None):
+        """logpdf(ds; f, ϕ) (src/dataset.jl:59-66, src/distributions.jl:11-15), per batch slot"""
+        f, phi = f.to(HARMONIC), phi.to(FOURIER)
+        d = self.d if d is None else d
+        z = self.mean(f, phi) - d
+        q1 = f.dot(self._apply("Cf_inv", f))
+        q3 = z.dot(self._apply("Cn_inv", z))
+        cp = Field(self.proj, self.proj.diag_apply(self.ops["Cphi_inv"], phi.arr, FOURIER, FOURIER), FOURIER)
+        q2 = phi.dot(cp)
+        return -0.5 * (q1 + q2 + q3 + self.logdet_sum)
 
     def set_data(self, d):
         d = d if isinstance(d, Field) else Field(self.proj, self.proj.tensor(d), HARMONIC)
@@ -348,12 +437,18 @@ class BaseDataSet:
                                               B, 1 if alias_quirk else 0))
         return np.array(lp[:]), Field(self.proj, gfo, MAP), Field(self.proj, gpo, FOURIER)
 
-    def mix(self, f, phi):
+    def mix(self, f, phi, G=None):
         """f° = L(ϕ)·D·f, ϕ° = G·ϕ (src/dataset.jl:96-101)"""
-        f = f.to(HARMONIC)
-        Df = Field(self.proj, self.proj.diag_apply(self.ops["D"], f.arr, HARMONIC, HARMONIC), HARMONIC)
-        fo = self.L(phi) * Df
-        G = 1.0 / self.ops["G_inv"]
-        G = torch.where(torch.isfinite(G), G, torch.zeros_like(G))
-        phio = Field(self.proj, self.proj.diag_apply(G, phi.to(FOURIER).arr, FOURIER, FOURIER), FOURIER)
+        fo = self.L(phi) * self._apply("D", f.to(HARMONIC))
+        if G is None:
+            G = 1.0 / self.ops["G_inv"]
+            G = torch.where(torch.isfinite(G), G, torch.zeros_like(G))
+        phio = Field(self.proj, self.proj.diag_apply(G if torch.is_tensor(G) else np.asarray(G)[None], phi.to(FOURIER).arr, FOURIER, FOURIER), FOURIER)
         return fo, phio
+
+    def unmix(self, fo, phio, G=None):
+        """ϕ = G \\ ϕ°, f = D \\ (L(ϕ) \\ f°) (src/dataset.jl:111-117)"""
+        Gi = self.ops["G_inv"] if G is None else (1.0 / np.asarray(G))[None]
+        phi = Field(self.proj, self.proj.diag_apply(Gi, phio.to(FOURIER).arr, FOURIER, FOURIER), FOURIER)
+        fhat = self.L(phi).ldiv(fo.to(MAP))
+        return self._apply("D_inv", fhat), phi

@@ -13,7 +13,7 @@ SYMBOLS = [
     "cmbl_blockdiag_ieb_apply", "cmbl_dot", "cmbl_logdet", "cmbl_lenseflow_create", "cmbl_lenseflow_destroy",
     "cmbl_lenseflow_set_phi", "cmbl_lenseflow_apply", "cmbl_lenseflow_grad", "cmbl_dataset_create",
     "cmbl_dataset_destroy", "cmbl_dataset_set_op", "cmbl_dataset_set_data", "cmbl_dataset_set_logdet",
-    "cmbl_gradientf_logpdf", "cmbl_wiener_cg", "cmbl_logpdf_mixed", "cmbl_grad_logpdf_mixed",
+    "cmbl_max_lensing_step", "cmbl_axpby", "cmbl_qe_leg", "cmbl_fourier_lmul", "cmbl_map_fma", "cmbl_gradientf_logpdf", "cmbl_wiener_cg", "cmbl_logpdf_mixed", "cmbl_grad_logpdf_mixed",
 ]
 
 
@@ -82,6 +82,11 @@ def load_library():
         "cmbl_lenseflow_set_phi": [vp, ci, vp, ci],
         "cmbl_lenseflow_apply": [vp, ci, ci, vp, ci, vp, ci, ci],
         "cmbl_lenseflow_grad": [vp, ci, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci],
+        "cmbl_max_lensing_step": [vp, ci, vp, vp, ci, pd],
+        "cmbl_axpby": [vp, ci, pd, vp, pd, vp, vp, ci, ci],
+        "cmbl_qe_leg": [vp, vp, ci, ci, ci, vp, ci],
+        "cmbl_fourier_lmul": [vp, vp, ci, ci, ci, vp, ci],
+        "cmbl_map_fma": [vp, vp, vp, cd, vp, ci, ci],
         "cmbl_dataset_create": [vp, ci, ctypes.POINTER(vp)],
         "cmbl_dataset_destroy": [vp],
         "cmbl_dataset_set_op": [vp, ci, vp, ci],

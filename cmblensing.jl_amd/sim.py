@@ -173,7 +173,8 @@ def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T
     ops = dict(Cf_inv=Cf.pinv().p, Cn_inv=Cn.pinv().p, B=Bop.p, Mf=Mf.p, D=D.p, D_inv=D.pinv().p,
                precond_inv=precond.pinv().p, Cphi_inv=_pinv(Cphi)[None], G_inv=_pinv(Gp)[None], Mpix=Mpix)
     ds = BaseDataSet(proj, P, ops, logdet_sum=logdet_sum, nsteps=nsteps)
-    ds.host = dict(Cf=Cf, Cn=Cn, Cphi=Cphi, Mf=Mf, B=Bop, D=D, Nphi=Nphi, G=Gp, Mpix=Mpix, precond=precond)
+    Cft = mk(cls["total"])                                                     # Cf̃ (:270)
+    ds.host = dict(Cf=Cf, Cn=Cn, Cphi=Cphi, Mf=Mf, B=Bop, D=D, Nphi=Nphi, G=Gp, Mpix=Mpix, precond=precond, Cftilde=Cft)
 
     # simulate: x = sqrt(C)·rfft(white)   (src/specialops.jl:6), white ~ PCG64(seed)
     def sim(op_planes, seed, Pp):

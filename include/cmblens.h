@@ -108,6 +108,22 @@ int cmbl_lenseflow_grad(cmbl_flow* L, int mode, const void* f_end, int basis_del
                         void* dphi_out, int basis_df, void* df_out, void* f_start_out,
                         int npol, int nbatch, int alias_quirk);
 
+/* get_max_lensing_step(phi, eta) (src/lenseflow.jl:242-256): largest alpha keeping I + grad grad(phi + alpha eta)
+ * non-singular, one value per batch slot. */
+int cmbl_max_lensing_step(cmbl_flow* L, int basis, const void* phi, const void* eta, int nbatch, double* out_host);
+
+/* ---- small helpers used by the drivers above the hot kernels
+ * axpby: out = a[b]*x + b[b]*y per batch slot (y may be NULL) -- the FieldTuple / Field broadcasts of the CG, line-search
+ *        and leapfrog updates (src/numerical_algorithms.jl:102-107, src/sampling.jl:29-31).
+ * qe_leg: Map(nan2zero(in * (i lx)^p1 (i ly)^p2 / |l|^n)) (src/quadratic_estimate.jl:89-91), in: Fourier S0.
+ * fourier_lmul: (i lx)^p1 (i ly)^p2 * rfft(map) or (take_abs) its modulus in the real part (src/quadratic_estimate.jl:97,118).
+ * map_fma: out = [out +] scale * a * b on maps (products of legs). */
+int cmbl_axpby(cmbl_ctx* ctx, int basis, const double* a_host, const void* x, const double* b_host, const void* y, void* out,
+               int npol, int nbatch);
+int cmbl_qe_leg(cmbl_ctx* ctx, const void* in_fourier, int n, int p1, int p2, void* out_map, int nbatch);
+int cmbl_fourier_lmul(cmbl_ctx* ctx, const void* in_map, int p1, int p2, int take_abs, void* out_fourier, int nbatch);
+int cmbl_map_fma(cmbl_ctx* ctx, const void* a, const void* b, double scale, void* out, int accumulate, int nslices);
+
 /* ---- data model, Wiener filter and posterior (src/dataset.jl:37-137, src/maximization.jl:17-42,
  *      src/numerical_algorithms.jl:73-134).  Operators are set as real planes in the reference
  *      layout; *_INV operators are the caller's pinv() of the reference operators. */

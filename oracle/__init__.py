@@ -35,3 +35,6 @@ from .flatsky import *          # noqa: F401,F403
 from .lenseflow import *        # noqa: F401,F403
 from .cg import *               # noqa: F401,F403
 from .dataset import *          # noqa: F401,F403
+from .quadratic_estimate import *   # noqa: F401,F403
+from .maximization import *     # noqa: F401,F403
+from .sampling import *         # noqa: F401,F403

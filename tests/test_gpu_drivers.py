@@ -1,0 +1,114 @@
+"""GPU parity of the drivers built on the hot path: quadratic_estimate, get_max_lensing_step, one MAP_joint step,
+one HMC / Gibbs step -- each against the NumPy oracle on identical inputs and identical random draws."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as O
+from test_gpu_parity import _dataset_pair, rel, DT
+
+
+def test_brent_minimizer_cpu_logic():
+    import cmblensing_jl_amd as C
+    x, fx, n = C.brent_minimize(lambda a: (a - 0.3) ** 2 + 1, 0.0, 2.0, abs_tol=1e-6)
+    assert abs(x - 0.3) < 1e-5 and n < 40
+    x, _, _ = C.brent_minimize(lambda a: -a, 0.0, 2.0, abs_tol=1e-4)          # monotone: converges to the upper end
+    assert x > 2.0 - 1e-3
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("pol,which", [("I", "TT"), ("P", "EB"), ("P", "EE"), ("IP", "EB")])
+def test_quadratic_estimate(prec, pol, which):
+    C, so, sd = _dataset_pair(prec, pol, (64, 128), mask=False, beam=1.0)
+    ods, ds, p = so["ds"], sd["ds"], sd["proj"]
+    ds.set_data(C.Field(p, p.tensor(so["d"]), C.HARMONIC))
+    key = {1: ["T"], 2: ["E", "B"], 3: ["T", "E", "B"]}[ods.P]
+    if ods.P == 3:
+        planes = lambda op: dict(T=op.te[0], E=op.te[3], B=op.bb)
+    else:
+        planes = lambda op: {k: op.d[i] for i, k in enumerate(key)}
+    TF = {k: planes(ods.Mf)[k] * planes(ods.B)[k] for k in key}
+    dd = {k: so["d"][:, i:i + 1] for i, k in enumerate(key)}
+    pq, AL, Nphi = O.quadratic_estimate(so["proj"], which, dd, dd, planes(ods.Cf), planes(ods.Cftilde), planes(ods.Cn), ods.Cphi, TF)
+    got = C.quadratic_estimate(ds, which)
+    m = ods.Cphi > 0
+    np.testing.assert_allclose(got["AL"][m], AL[m], rtol=2e-3 if prec == "f32" else 1e-9)
+    assert rel(got["phiqe"].arr.cpu().numpy(), pq) < (2e-3 if prec == "f32" else 1e-9)
+    # it is an estimate of ϕ: correlates with the truth
+    phi = so["phi"]
+    r = O.dot_fourier(so["proj"], pq, phi) / np.sqrt(O.dot_fourier(so["proj"], pq, pq) * O.dot_fourier(so["proj"], phi, phi))
+    assert r[0] > 0.5
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_max_lensing_step(prec):
+    C, so, sd = _dataset_pair(prec, "I", (64, 64), mask=False)
+    p, proj = sd["proj"], so["proj"]
+    phi = O.irfft2(so["phi"], proj.Ny)
+    eta = O.irfft2(np.sqrt(so["ds"].Cphi) * O.rfft2(O.white_noise(9, (1, 1, 64, 64), np.float64)), proj.Ny)
+    want = O.get_max_lensing_step(proj, phi, eta)
+    L = C.LenseFlow(p, 7)
+    got = L.max_lensing_step(C.Field(p, p.tensor(phi), C.MAP), C.Field(p, p.tensor(eta), C.MAP))
+    np.testing.assert_allclose(got[0], want, rtol=1e-3 if prec == "f32" else 1e-9)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("pol", ["P", "I"])
+def test_map_joint_step(prec, pol):
+    C, so, sd = _dataset_pair(prec, pol, (64, 64), mask=False, beam=1.0)
+    ods, ds, p = so["ds"], sd["ds"], sd["proj"]
+    ds.set_data(C.Field(p, p.tensor(so["d"]), C.HARMONIC))
+    # Nϕ as load_sim builds it (src/dataset.jl:316): quadratic_estimate(ds).Nϕ / Nϕ_fac, on both sides
+    Nphi = C.quadratic_estimate(ds)["Nphi"] / 2
+    ods.Nphi = Nphi
+    ds.host["Nphi"] = Nphi
+    phi0 = np.zeros_like(so["phi"])
+    # a fixed, short CG (no tolerance stop) keeps the f-step identical on both sides, so the ϕ-step can be compared tightly
+    st_o = O.map_joint_step(ods, phi0, alpha_tol=1e-4, cg_tol=0.0, cg_nsteps=10)
+    st_g = C.MAP_joint_step(ds, C.Field(p, p.tensor(phi0), C.FOURIER), alpha_tol=1e-4, cg_tol=0.0, cg_nsteps=10)
+    tol = 5e-3 if prec == "f32" else 1e-6
+    assert rel(st_g["f"].arr.cpu().numpy(), st_o["f"]) < (2e-3 if prec == "f32" else 1e-8)
+    assert rel(st_g["grad_phi"].arr.cpu().numpy(), st_o["grad_phi"]) < tol
+    assert rel(st_g["dphi"].arr.cpu().numpy(), st_o["dphi"]) < tol
+    # Brent (ours) vs SciPy's bounded Brent (oracle): same minimiser within the tolerance, same objective value
+    assert abs(st_g["alpha"] - st_o["alpha"]) < 5e-3, (st_g["alpha"], st_o["alpha"])
+    np.testing.assert_allclose(st_g["logpdf"], st_o["logpdf"], rtol=2e-5)
+    assert st_g["logpdf"][0] > st_g["logpdf_before"][0]
+    assert rel(st_g["phi"].arr.cpu().numpy(), st_o["phi"]) < 2e-2
+    # two more steps keep increasing the posterior and approach the true ϕ
+    f, phi, hist = C.MAP_joint(ds, nsteps=3)
+    lps = [h["logpdf"][0] for h in hist]
+    assert lps[0] < lps[1] < lps[2]
+    r = phi.dot(C.Field(p, p.tensor(so["phi"]), C.FOURIER)) / np.sqrt(phi.dot(phi) * O.dot_fourier(so["proj"], so["phi"], so["phi"]))
+    assert r[0] > 0.8
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_hmc_and_gibbs_step(prec):
+    C, so, sd = _dataset_pair(prec, "P", (64, 64), mask=True, beam=1.0)
+    ods, ds, p = so["ds"], sd["ds"], sd["proj"]
+    ds.set_data(C.Field(p, p.tensor(so["d"]), C.HARMONIC))
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    B, P, Nx, Ny = 1, 2, 64, 64
+    wf, wn, wp = (O.white_noise(s, (B, P if s < 9 else 1, Nx, Ny), np.float64) for s in (7, 8, 9))
+    logu = np.log(np.random.default_rng(3).random(B))
+    # HMC alone from the truth: ΔH, proposal and acceptance agree
+    fo, po = ods.mix(so["f"], so["phi"])
+    x_o, dH_o, acc_o = O.hmc_step(ods, fo, po, wp, logu, N=5, eps=0.01)
+    x_g, dH_g, acc_g = C.hmc_step(ds, F(fo, C.MAP), F(po, C.FOURIER), wp, logu, N=5, eps=0.01)
+    # ΔH is a difference of two H ~ 1e5: agreement is limited by the 1e-10 (fp64) / 2e-5 (fp32) relative accuracy of logpdf
+    np.testing.assert_allclose(dH_g, dH_o, atol=5.0 if prec == "f32" else 2e-3)
+    if prec == "f64":
+        assert bool(acc_g[0]) == bool(acc_o[0])
+    assert rel(x_g.arr.cpu().numpy(), x_o) < (2e-3 if prec == "f32" else 1e-7)
+    # posterior sample of f (src/maximization.jl:56-62): fixed short CG so both sides stop at the same iterate
+    f_o, _ = O.sample_f(ods, so["phi"], wf, wn, tol=0.0, nsteps=6)
+    f_g, _ = C.sample_f(ds, F(so["phi"], C.FOURIER), wf, wn, tol=0.0, nsteps=6)
+    assert rel(f_g.arr.cpu().numpy(), f_o) < (2e-3 if prec == "f32" else 1e-8)
+    # unmixed logpdf (gibbs_postprocess!, src/sampling.jl:455-464)
+    np.testing.assert_allclose(ds.logpdf(F(so["f"], C.HARMONIC), F(so["phi"], C.FOURIER)), ods.logpdf(so["f"], so["phi"]),
+                               rtol=2e-5 if prec == "f32" else 1e-10)
+    st = C.gibbs_step(ds, F(so["phi"], C.FOURIER), wf, wn, wp, logu, N=3, eps=0.01)
+    assert np.all(np.isfinite(st["logpdf"])) and st["f"].arr.shape == (B, P, Nx, Ny // 2 + 1)
