@@ -33,9 +33,9 @@ static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x
 #define CMBL_LAUNCH_NT(ctxp, kid, nthreads, kernel, grid, lds, stream, ...)            \
   do {                                                                                \
     raise_lds_limit(reinterpret_cast<const void*>(kernel), (lds));                    \
-    (ctxp)->prof_begin(kid);                                                          \
+    (ctxp)->prof_begin(kid, (stream));                                                \
     hipLaunchKernelGGL(kernel, grid, dim3(nthreads), (lds), (stream), __VA_ARGS__);   \
-    (ctxp)->prof_end(kid);                                                            \
+    (ctxp)->prof_end(kid, (stream));                                                  \
     CMBL_HIP(hipGetLastError());                                                      \
   } while (0)
 #define CMBL_LAUNCH(ctxp, kid, kernel, grid, lds, stream, ...) CMBL_LAUNCH_NT(ctxp, kid, NTP, kernel, grid, lds, stream, __VA_ARGS__)
@@ -64,20 +64,20 @@ struct CtxBase {
   size_t prof_used[K_COUNT] = {};
   double prof_ms[K_COUNT] = {};
   long prof_n[K_COUNT] = {};
-  void prof_begin(int k) {
+  void prof_begin(int k, hipStream_t st) {
     if (!prof_on) return;
     if (prof_used[k] == prof_ev[k].size()) {
       hipEvent_t a, b; CMBL_HIP(hipEventCreate(&a)); CMBL_HIP(hipEventCreate(&b)); prof_ev[k].push_back({a, b});
     }
-    CMBL_HIP(hipEventRecord(prof_ev[k][prof_used[k]].first, stream));
+    CMBL_HIP(hipEventRecord(prof_ev[k][prof_used[k]].first, st));
   }
-  void prof_end(int k) {
+  void prof_end(int k, hipStream_t st) {
     if (!prof_on) return;
-    CMBL_HIP(hipEventRecord(prof_ev[k][prof_used[k]].second, stream));
+    CMBL_HIP(hipEventRecord(prof_ev[k][prof_used[k]].second, st));
     ++prof_used[k];
   }
   void prof_collect() {                         // synchronises; folds recorded pairs into the totals
-    CMBL_HIP(hipStreamSynchronize(stream));
+    CMBL_HIP(hipDeviceSynchronize());
     for (int k = 0; k < K_COUNT; ++k) {
       for (size_t i = 0; i < prof_used[k]; ++i) {
         float ms = 0; CMBL_HIP(hipEventElapsedTime(&ms, prof_ev[k][i].first, prof_ev[k][i].second));
@@ -245,12 +245,13 @@ struct Ctx : CtxBase {
       CMBL_LAUNCH_NT(this, K_Y_C2R, NT, (k_y_c2r<T, R, NT, LGM>), dim3(Nx / t.C, (unsigned)slices), ldsY(t.C, false), stream, mixed, map, twY.as<cx<T>>(), Nx, (T)(1.0 / Ny));
     });
   }
-  template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices) {
+  template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices, hipStream_t st = nullptr) {
+    if (!st) st = stream;
     const long rows = slices * Nyh;
     const int RX = pickRX(1, rows);
     dispatch_row(pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
       constexpr int LGNX = decltype(lgnx)::value, XNT = decltype(xnt)::value;
-      CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), XNT, (k_x_fft<T, MODE, XNT, LGNX>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), stream, in, out,
+      CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), XNT, (k_x_fft<T, MODE, XNT, LGNX>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), st, in, out,
                      twX.as<cx<T>>(), lx_r.as<T>(), rows, RX);
     });
   }
@@ -368,7 +369,33 @@ struct Flow {
   DevBuf w1p, w2p, Z0, Z1, Z2, P0, Pacc;  // delta flow extras
   DevBuf cvt;                             // boundary conversion scratch
 
-  Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) { CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range"); }
+  // The delta-phi branch of the gradient flow never feeds back into the f / delta-f chain, so it runs on a second stream and
+  // overlaps with the next stage's kernels (the chain itself is a strict dependency line that cannot fill the chip at B = 1).
+  hipStream_t side = nullptr;   // (a third stream for the next stage's d/dx pass was measured slower: per-stage cross-stream waits cost more than they hide)
+  hipEvent_t evW[2] = {nullptr, nullptr}, evDone[2] = {nullptr, nullptr}, evStart = nullptr;
+  DevBuf w1q, w2q;                        // second set of w-partials (double buffering across stages)
+
+  Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) {
+    CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range");
+    if (env_int("CMBL_NO_SIDE_STREAM", 0) == 0) {
+      CMBL_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        CMBL_HIP(hipEventCreateWithFlags(&evW[i], hipEventDisableTiming));
+        CMBL_HIP(hipEventCreateWithFlags(&evDone[i], hipEventDisableTiming));
+      }
+      CMBL_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
+    }
+  }
+  ~Flow() {
+    if (side) {
+      (void)hipStreamSynchronize(side);
+      for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(evW[i]); (void)hipEventDestroy(evDone[i]); }
+      (void)hipEventDestroy(evStart);
+      (void)hipStreamDestroy(side);
+    }
+  }
+  Flow(const Flow&) = delete;
+  Flow& operator=(const Flow&) = delete;
 
   PhiMaps<T> ph() const {
     const size_t s = (size_t)Bphi * c->npix();
@@ -506,9 +533,12 @@ struct Flow {
     H.ensure(sizeof(cx<T>) * slices * pl); Wx.ensure(sizeof(cx<T>) * slices * pl); Wy.ensure(sizeof(cx<T>) * slices * pl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
     w1p.ensure(sizeof(T) * slices * np); w2p.ensure(sizeof(T) * slices * np);
+    if (side) { w1q.ensure(sizeof(T) * slices * np); w2q.ensure(sizeof(T) * slices * np); }
     Z0.ensure(sizeof(cx<T>) * B * pl); Z1.ensure(sizeof(cx<T>) * B * pl); Z2.ensure(sizeof(cx<T>) * B * pl);
     Pacc.ensure(sizeof(cx<T>) * B * pl);
     CMBL_HIP(hipMemsetAsync(dphi, 0, sizeof(cx<T>) * B * pl, c->stream));
+    hipStream_t sd = side ? side : c->stream;
+    if (side) { CMBL_HIP(hipEventRecord(evStart, c->stream)); CMBL_HIP(hipStreamWaitEvent(side, evStart, 0)); }
     cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
     c->y_r2c(f, a_cur, slices);
     c->template x_pass<1>(df, H.as<cx<T>>(), slices);
@@ -516,22 +546,29 @@ struct Flow {
     const long rows = slices * c->Nyh, rowsp = (long)B * c->Nyh;
     const int RX2 = c->pickRX(2, rows), RX3 = c->pickRX(3, rowsp);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
+    int it = 0;
     for (int step = 0; step < n; ++step)
-      for (int stage = 1; stage <= 4; ++stage) {
+      for (int stage = 1; stage <= 4; ++stage, ++it) {
         const bool last = step == n - 1 && stage == 4;
         const RKCoef<T> rk = coef(step, stage, t0, h, last);
+        const int buf = side ? (it & 1) : 0;
+        T* wa = buf ? w1q.as<T>() : w1p.as<T>();
+        T* wb = buf ? w2q.as<T>() : w2p.as<T>();
         c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);
+        if (side && it >= 2) CMBL_HIP(hipStreamWaitEvent(c->stream, evDone[buf], 0));   // the w buffers of stage it-2 have been consumed
         DeltaYArgs<T> d{};
         FlowYArgs<T>& a = d.f;
         a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = f; a.acc = acc.as<T>(); a.ph = ph();
         a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
         a.Nx = c->Nx; a.P = P; a.rk = rk;
-        d.H = H.as<cx<T>>(); d.Wx = Wx.as<cx<T>>(); d.Wy = Wy.as<cx<T>>(); d.w1p = w1p.as<T>(); d.w2p = w2p.as<T>();
+        d.H = H.as<cx<T>>(); d.Wx = Wx.as<cx<T>>(); d.Wy = Wy.as<cx<T>>(); d.w1p = wa; d.w2p = wb;
         c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
           constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
           CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_y<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, d);
         });
+        if (side) { CMBL_HIP(hipEventRecord(evW[buf], c->stream)); CMBL_HIP(hipStreamWaitEvent(side, evW[buf], 0)); }
         std::swap(a_cur, a_nxt);
+
         // delta-f row pass (RK update of df + next H)
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
@@ -540,23 +577,28 @@ struct Flow {
           constexpr int XNT = decltype(xnt)::value;
           CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
         });
-        // delta-phi
+        // delta-phi branch (side stream)
         DphiYArgs<T> py{};
-        py.w1p = w1p.as<T>(); py.w2p = w2p.as<T>(); py.Z0 = Z0.as<cx<T>>(); py.Z1 = Z1.as<cx<T>>(); py.Z2 = Z2.as<cx<T>>();
+        py.w1p = wa; py.w2p = wb; py.Z0 = Z0.as<cx<T>>(); py.Z1 = Z1.as<cx<T>>(); py.Z2 = Z2.as<cx<T>>();
         py.ph = ph(); py.twY = a.twY; py.ly = a.ly; py.Nx = c->Nx; py.P = P;
         py.alias_quirk = alias_quirk ? 1 : 0; py.t = rk.t;
         c->dispatch_col(tilep, [&](auto lgm, auto r, auto nt) {
           constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
-          CMBL_LAUNCH_NT(c, K_DPHI_Y, NT, (k_dphi_y<T, R, NT, LGM>), dim3(c->Nx / tilep.C, (unsigned)B), c->ldsY(tilep.C), c->stream, py);
+          CMBL_LAUNCH_NT(c, K_DPHI_Y, NT, (k_dphi_y<T, R, NT, LGM>), dim3(c->Nx / tilep.C, (unsigned)B), c->ldsY(tilep.C), sd, py);
         });
         DphiXArgs<T> px{};
         px.Z0 = Z0.as<cx<T>>(); px.Z1 = Z1.as<cx<T>>(); px.Z2 = Z2.as<cx<T>>(); px.Y0 = dphi; px.acc = Pacc.as<cx<T>>();
         px.twX = x.twX; px.lx_r = x.lx_r; px.RX = RX3; px.rows = rowsp; px.rk = rk;
         c->dispatch_row(c->pickXNT(rowsp, RX3), [&](auto lgnx, auto xnt) {
           constexpr int XNT = decltype(xnt)::value;
-          CMBL_LAUNCH_NT(c, K_DPHI_X, XNT, (k_dphi_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), c->stream, px);
+          CMBL_LAUNCH_NT(c, K_DPHI_X, XNT, (k_dphi_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), sd, px);
         });
+        if (side) CMBL_HIP(hipEventRecord(evDone[buf], side));
       }
+    if (side) {                                                              // join: dphi is complete before the caller's stream continues
+      CMBL_HIP(hipStreamWaitEvent(c->stream, evDone[0], 0));
+      CMBL_HIP(hipStreamWaitEvent(c->stream, evDone[1], 0));
+    }
   }
 
   // ---- boundary-level entry points ---------------------------------------------------------------

@@ -29,6 +29,10 @@ __device__ __forceinline__ void flow_pm(T t, T gx, T gy, T hxx, T hyx, T hyy, T&
   py = m12 * gx + m22 * gy;
 }
 
+// Register budget of the fused column kernels: aim at two resident workgroups per CU (4 waves per SIMD for 512 threads) when the
+// tile is small enough (R <= 4 single precision) that the cap costs at most a handful of spilled registers.
+template <typename T> constexpr int col_min_waves(int R, int NT) { return (sizeof(T) == 4 && R <= 4 && NT >= 256) ? 4 : 1; }
+
 template <typename T> struct PhiMaps { const T *gx, *gy, *hxx, *hyx, *hyy; int Bphi; };
 
 template <typename T> struct RKCoef { T t, cnext, h6; int stage, last; };   // stage 1..4
@@ -82,7 +86,7 @@ template <typename T> struct FlowYArgs {
 };
 
 template <typename T, int R, int NT, int LGM>
-__global__ __launch_bounds__(NT) void k_flow_y_fwd(FlowYArgs<T> a) {
+__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(FlowYArgs<T> a) {
   using G = ColTile<R, NT, LGM>;
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -147,7 +151,7 @@ template <typename T> struct AdjYArgs {
 };
 
 template <typename T, int R, int NT, int LGM>
-__global__ __launch_bounds__(NT) void k_adj_y(AdjYArgs<T> a) {
+__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<T> a) {
   using G = ColTile<R, NT, LGM>;
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -248,7 +252,7 @@ template <typename T> struct DeltaYArgs {
 };
 
 template <typename T, int R, int NT, int LGM>
-__global__ __launch_bounds__(NT) void k_delta_y(DeltaYArgs<T> d) {
+__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_y(DeltaYArgs<T> d) {
   using G = ColTile<R, NT, LGM>;
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -344,7 +348,7 @@ template <typename T> struct DphiYArgs {
 };
 
 template <typename T, int R, int NT, int LGM>
-__global__ __launch_bounds__(NT) void k_dphi_y(DphiYArgs<T> a) {
+__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_dphi_y(DphiYArgs<T> a) {
   using G = ColTile<R, NT, LGM>;
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   constexpr int RZ = G::RZ;
