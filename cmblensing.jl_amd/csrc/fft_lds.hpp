@@ -53,10 +53,11 @@ template <typename T> __device__ __forceinline__ cx<T> mul_root16c(cx<T> a, int 
 }
 
 // ---- stage schedule: levels per stage as even as possible over ceil(lgN/4) stages (9 -> 3,3,3 ; 10 -> 4,3,3 ; 5 -> 3,2)
-constexpr int stage_levels(int remaining) { return (remaining + ((remaining + 3) >> 2) - 1) / ((remaining + 3) >> 2); }
-constexpr int num_stages(int lgN) { int n = 0; while (lgN > 0) { lgN -= stage_levels(lgN); ++n; } return n; }
-constexpr int stage_lg(int lgN, int idx) { int lg = 0; for (int i = 0; i <= idx; ++i) { lg = stage_levels(lgN); lgN -= lg; } return lg; }
-constexpr int levels_after(int lgN, int idx) { int tot = 0; for (int i = 0; i <= idx; ++i) tot += stage_lg(lgN, i); return lgN - tot; }
+// MAXLG caps the radix (2^MAXLG): 4 = radix-16 (fewest barriers), 3 = radix-8 (half the registers, one more round trip).
+constexpr int stage_levels(int remaining, int maxlg = 4) { return (remaining + ((remaining + maxlg - 1) / maxlg) - 1) / ((remaining + maxlg - 1) / maxlg); }
+constexpr int num_stages(int lgN, int maxlg = 4) { int n = 0; while (lgN > 0) { lgN -= stage_levels(lgN, maxlg); ++n; } return n; }
+constexpr int stage_lg(int lgN, int idx, int maxlg = 4) { int lg = 0; for (int i = 0; i <= idx; ++i) { lg = stage_levels(lgN, maxlg); lgN -= lg; } return lg; }
+constexpr int levels_after(int lgN, int idx, int maxlg = 4) { int tot = 0; for (int i = 0; i <= idx; ++i) tot += stage_lg(lgN, i, maxlg); return lgN - tot; }
 
 // One fused DIF stage: LG radix-2 levels with spans h = 2^LGH (top) ... hmin = 2^(LGH-LG+1).
 template <typename T, int NT, int LD, int LGN, int LGNTW, int LGH, int LG>
@@ -126,24 +127,24 @@ __device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, int S, const cx
 }
 
 // ---- forward, DIF: natural -> bit-reversed -------------------------------------------------------
-template <typename T, int NT, int LD, int LGN, int LGNTW, int I = 0>
+template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, int I = 0>
 __device__ __forceinline__ void fft_dif(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
-  if constexpr (I < num_stages(LGN)) {
-    constexpr int LG = stage_lg(LGN, I);
-    constexpr int LGH = levels_after(LGN, I) + LG - 1;             // top span index of this stage
+  if constexpr (I < num_stages(LGN, MAXLG)) {
+    constexpr int LG = stage_lg(LGN, I, MAXLG);
+    constexpr int LGH = levels_after(LGN, I, MAXLG) + LG - 1;      // top span index of this stage
     dif_stage<T, NT, LD, LGN, LGNTW, LGH, LG>(s, S, tw);
-    fft_dif<T, NT, LD, LGN, LGNTW, I + 1>(s, S, tw);
+    fft_dif<T, NT, LD, LGN, LGNTW, MAXLG, I + 1>(s, S, tw);
   }
 }
 
 // ---- inverse, DIT: bit-reversed -> natural (unnormalised); the forward schedule replayed backwards ----
-template <typename T, int NT, int LD, int LGN, int LGNTW, int I = num_stages(LGN) - 1>
+template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, int I = num_stages(LGN, MAXLG) - 1>
 __device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
   if constexpr (I >= 0) {
-    constexpr int LG = stage_lg(LGN, I);
-    constexpr int LGH = levels_after(LGN, I);                      // bottom span index of this stage
+    constexpr int LG = stage_lg(LGN, I, MAXLG);
+    constexpr int LGH = levels_after(LGN, I, MAXLG);               // bottom span index of this stage
     dit_stage<T, NT, LD, LGN, LGNTW, LGH, LG>(s, S, tw);
-    fft_dit<T, NT, LD, LGN, LGNTW, I - 1>(s, S, tw);
+    fft_dit<T, NT, LD, LGN, LGNTW, MAXLG, I - 1>(s, S, tw);
   }
 }
 

@@ -10,6 +10,10 @@
 #pragma once
 #include "fft_lds.hpp"
 
+#ifndef CMBL_XLG
+#define CMBL_XLG 4      // row kernels: radix-16 stages (radix-8 = 3 measured 5 % faster for L*f alone but 3 % slower for the gradient step)
+#endif
+
 namespace cmbl {
 
 // Column tiles that are neighbours in x share 64/128-byte lines of the [ky][x] arrays.  Workgroup b is observed to run
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(NT) void k_x_fft(const cx<T>* __restrict__ in, cx<T
   for (int e = threadIdx.x; e < nr * Nx; e += NT) s[(e >> LGNX) * LD + pad(e & (Nx - 1))] = src[e];
   __syncthreads();
   const T inv = T(1) / T(Nx);
-  if (MODE == 0 || MODE == 2) fft_dif<T, NT, LD, LGNX, LGNX>(s, nr, tw);
+  if (MODE == 0 || MODE == 2) fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
   if (MODE == 2) {
     for (int e = threadIdx.x; e < nr * Nx; e += NT) {
       const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(NT) void k_x_fft(const cx<T>* __restrict__ in, cx<T
     }
     __syncthreads();
   }
-  if (MODE == 1 || MODE == 2) fft_dit<T, NT, LD, LGNX, LGNX>(s, nr, tw);
+  if (MODE == 1 || MODE == 2) fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
   cx<T>* dst = out + r0 * Nx;
   if (MODE == 1) { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = inv * s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }
   else           { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(NT) void k_adj_x(AdjXArgs<T> a) {
   }
   __syncthreads();
   // both row sets in one go: they are adjacent in LDS when nr == RX; otherwise two calls
-  if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX>(s, 2 * nr, tw);
-  else { fft_dif<T, NT, LD, LGNX, LGNX>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX>(s2, nr, tw); }
+  if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, 2 * nr, tw);
+  else { fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s2, nr, tw); }
   const T inv = T(1) / T(Nx);
   for (int e = threadIdx.x; e < n; e += NT) {
     const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NT) void k_adj_x(AdjXArgs<T> a) {
   }
   if (a.rk.last) return;
   __syncthreads();
-  fft_dit<T, NT, LD, LGNX, LGNX>(s, nr, tw);
+  fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
   for (int e = threadIdx.x; e < n; e += NT) a.Hnext[r0 * Nx + e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
 }
 
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(NT) void k_dphi_x(DphiXArgs<T> a) {
     s[si] = a.Z0[r0 * Nx + e]; s[st + si] = a.Z1[r0 * Nx + e]; s[2 * st + si] = a.Z2[r0 * Nx + e];
   }
   __syncthreads();
-  if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX>(s, 3 * nr, tw);
-  else { fft_dif<T, NT, LD, LGNX, LGNX>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX>(s + st, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX>(s + 2 * st, nr, tw); }
+  if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX, 4>(s, 3 * nr, tw);
+  else { fft_dif<T, NT, LD, LGNX, LGNX, 4>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, 4>(s + st, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, 4>(s + 2 * st, nr, tw); }
   for (int e = threadIdx.x; e < n; e += NT) {
     const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
     const T l = a.lx_r[i];
