@@ -58,6 +58,20 @@ KERNEL_SHARE = {
 }
 
 
+def measured_traffic(kernel_class, N, P, B):
+    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    separate runs, gfx950 correction applied: profiles/r01_traffic_*.json); None when no profile matches this workload."""
+    path = os.path.join(ROOT, "profiles", f"r01_traffic_{N}{'IQU'[3 - P:] if P > 1 else 'I'}.json")
+    try:
+        z = json.load(open(path))
+        w = z["workload"]
+        if (w["nside"], w["npol"], w["nbatch"]) != (N, P, B):
+            return None
+        return z["by_class"][kernel_class]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(N, pol, nsteps):
     """The NumPy oracle (kind 'port': the Julia reference cannot run here) timed on the host cores: one ∇lnP
     evaluation of the same workload (bounded sample)."""
@@ -169,8 +183,9 @@ def main():
         ab = algorithmic_bytes(N, P, B, B, nrk, 4)
         bytes_per_launch = KERNEL_SHARE[dom](P, B, B) * ab["map_pass"]
         achieved = bytes_per_launch / (ms / nl * 1e-3) / 1e9
+        traffic = measured_traffic(dom, N, P, B)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                           "traffic": None, "avg_launch_us": ms / nl * 1e3, "launches_per_step": nl / args.steps,
+                           "traffic": traffic, "avg_launch_us": ms / nl * 1e3, "launches_per_step": nl / args.steps,
                            "algorithmic_bytes_per_launch": bytes_per_launch,
                            "kernel_time_share": ms / tot,
                            "whole_step": {"algorithmic_GB": ab["grad_lnP"] / 1e9,
