@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--nbatch", type=int, default=1, help="chains per GPU (batch dim 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo lets the N>1 logic be exercised on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import torch
@@ -112,8 +114,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.dist_backend == "gloo":
+            local = local % max(torch.cuda.device_count(), 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    cdev = "cpu" if args.dist_backend == "gloo" else "cuda"          # where the (tiny) collective payloads live
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
@@ -145,11 +152,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # the trivial result gather: per-chain logpdf scalars to every rank over RCCL
-        mine = torch.tensor(lp, device="cuda", dtype=torch.float64)
+        mine = torch.tensor(lp, device=cdev, dtype=torch.float64)
         allp = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)
         lps = torch.cat(allp).cpu().numpy()
