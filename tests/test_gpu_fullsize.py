@@ -1,0 +1,92 @@
+"""GPU checks at BASELINE.json's full sizes, where the NumPy oracle is too slow: size-independent properties that the
+reference's own tests rely on (test/runtests.jl:116-131, 556-573) -- basis round trips against torch.fft, the LenseFlow
+adjoint identity, inverse round trips, and the δ-flow gradient against finite differences of the device operator."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from bench import synthetic_cls
+
+
+def _fields(C, proj, P, seed=0, B=1):
+    """CMB-like device fields from the fixture spectra: f (map), g (map), phi (map), dphi (map)"""
+    cls = synthetic_cls()["total"]
+    planes = {1: ["TT"], 2: ["EE", "BB"], 3: ["TT", "EE", "BB"]}[P]
+    Cf = np.stack([C.cl_to_2d(cls[k], proj) + (0.05 * C.cl_to_2d(cls["EE"], proj) if k == "BB" else 0) for k in planes])
+    Cp = C.cl_to_2d(cls["pp"], proj)[None]
+    rng = np.random.default_rng(seed)
+    def sim(Cx, Pp):
+        w = proj.tensor(rng.standard_normal((B, Pp, proj.Nx, proj.Ny)))
+        return C.Field(proj, proj.diag_apply(np.sqrt(Cx), proj.rfft(w), C.HARMONIC, C.HARMONIC), C.HARMONIC).to(C.MAP)
+    return sim(Cf, P), sim(Cf, P), sim(Cp, 1), sim(Cp, 1)
+
+
+@pytest.mark.parametrize("Ny,Nx,P,prec", [(1024, 1024, 2, "f32"), (1024, 1024, 3, "f32"), (2048, 2048, 2, "f64"), (4096, 512, 1, "f32"),
+                                           (512, 4096, 1, "f32"), (2048, 1024, 2, "f32")])
+def test_fullsize_properties(Ny, Nx, P, prec):
+    import cmblensing_jl_amd as C
+    T = torch.float32 if prec == "f32" else torch.float64
+    proj = C.ProjLambert(Ny, Nx, 2.0, T)
+    f, g, phi, dphi = _fields(C, proj, P)
+    eps = 3e-5 if prec == "f32" else 1e-11
+    # basis transforms against torch.fft on the same device data
+    ref = torch.fft.rfft2(f.arr.double(), dim=(-2, -1))
+    got = proj.rfft(f.arr)
+    assert float((got.to(ref.dtype) - ref).norm() / ref.norm()) < eps
+    assert float((proj.irfft(got) - f.arr).norm() / f.arr.norm()) < eps
+    h = f.to(C.HARMONIC)
+    assert float((h.to(C.MAP).arr - f.arr).norm() / f.arr.norm()) < 3 * eps
+    np.testing.assert_allclose(h.dot(h), f.dot(f), rtol=1e-5 if prec == "f32" else 1e-11)        # Parseval incl. QU<->EB rotation
+    # LenseFlow: adjoint identity, inverse round trips
+    L = C.LenseFlow(proj, 7)(phi)
+    Lg = L * g
+    lhs = f.dot(Lg)
+    rhs = (L.adjoint * f.to(C.FOURIER)).dot(g.to(C.FOURIER))
+    np.testing.assert_allclose(lhs, rhs, rtol=3e-4 if prec == "f32" else 1e-9)
+    back = L.ldiv(Lg)
+    assert float((back.arr - g.arr).norm() / g.arr.norm()) < 1e-3        # RK4 n=7 discretisation, not round-off
+    gl = g.to(C.FOURIER)
+    back = L.adjoint.ldiv(L.adjoint * gl)
+    assert float((back.arr - gl.arr).norm() / gl.arr.norm()) < 2e-2
+    if prec != "f64":
+        return
+    # δ-flow gradient vs central differences of the device operator itself: α ↦ ½‖L(ϕ+αδϕ)(f+αδf)‖², f- and ϕ-directions apart
+    # (f: exact transpose of the discrete flow -> tight; ϕ: continuous-adjoint gradient, O(h^4.6) discretisation error -> loose)
+    e = 0.01
+    fd5 = lambda fun: (fun(-2 * e) - 8 * fun(-e) + 8 * fun(e) - fun(2 * e)) / (12 * e)
+    half_norm2 = lambda y: 0.5 * float(y.dot(y)[0])
+    ft = L * f
+    dp, df, f0 = L.gradient(C.FLOW_FWD, ft, ft.to(C.FOURIER))
+    fd_f = fd5(lambda a: half_norm2(L * proj.axpby(1.0, f, a, g)))
+    an_f = float(df.dot(g.to(C.FOURIER))[0])
+    assert abs(an_f - fd_f) < 1e-7 * abs(fd_f), (an_f, fd_f)
+    fd_p = fd5(lambda a: half_norm2(C.LenseFlow(proj, 7)(proj.axpby(1.0, phi, a, dphi)) * f))
+    an_p = float(dp.dot(dphi.to(C.FOURIER))[0])
+    assert abs(an_p - fd_p) < 0.05 * abs(fd_p), (an_p, fd_p)
+    assert float((f0.arr - f.arr).norm() / f.arr.norm()) < 1e-3
+
+
+def test_fullsize_posterior_step():
+    """the bench workload itself: ∇logpdf(Mixed) at 1024² QU against central differences of the device logpdf along random
+    directions.  The f°-gradient is an exact transpose of the discrete flow and must agree tightly.  The ϕ°-gradient is the
+    reference's continuous-adjoint gradient (src/lenseflow.jl:176-214): it differs from the derivative of the discrete RK4 map
+    by an O(h^~4.6) term (measured at this size: 29 % of the directional derivative at n=7, 1.7 % at n=14), so it is checked at
+    n=14 with that tolerance, and for the expected convergence between n=7 and n=14."""
+    import cmblensing_jl_amd as C
+    err = {}
+    for n in (7, 14):
+        s = C.load_sim(2.0, 1024, "P", synthetic_cls(), T=torch.float64, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=n)
+        ds, proj = s["ds"], s["proj"]
+        fo, po = ds.mix(s["f"], s["phi"])
+        _, g, _, dphi = _fields(C, proj, 2, seed=5)
+        dphil = dphi.to(C.FOURIER)
+        lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
+        e = 1e-3
+        fd5 = lambda fun: (fun(-2 * e) - 8 * fun(-e) + 8 * fun(e) - fun(2 * e)) / (12 * e)
+        fdf = fd5(lambda a: float(ds.logpdf_mixed(proj.axpby(1.0, fo, a, g), po)[0]))
+        assert abs(float(gf.dot(g)[0]) - fdf) < 1e-6 * abs(fdf) + 1e-4, (n, float(gf.dot(g)[0]), fdf)
+        fdp = fd5(lambda a: float(ds.logpdf_mixed(fo, proj.axpby(1.0, po, a, dphil))[0]))
+        err[n] = abs(float(gp.dot(dphil)[0]) - fdp) / abs(fdp)
+    assert err[14] < 0.03 and err[14] < err[7] / 8, err
