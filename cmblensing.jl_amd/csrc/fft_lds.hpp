@@ -21,6 +21,10 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef CMBL_STAGE_SYNC
+#define CMBL_STAGE_SYNC() __syncthreads()
+#endif
+
 namespace cmbl {
 
 __device__ __host__ __forceinline__ constexpr int pad(int i) { return i + (i >> 4); }
@@ -89,7 +93,7 @@ __device__ __forceinline__ void dif_stage(cx<T>* __restrict__ s, int S, const cx
 #pragma unroll
     for (int m = 0; m < r; ++m) p[pad(m << lghmin)] = v[m];
   }
-  __syncthreads();
+  CMBL_STAGE_SYNC();
 }
 
 // One fused DIT stage: LG levels with spans hmin = 2^LGH (bottom) ... hmin * 2^(LG-1).
@@ -123,7 +127,7 @@ __device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, int S, const cx
 #pragma unroll
     for (int m = 0; m < r; ++m) p[pad(m << LGH)] = v[m];
   }
-  __syncthreads();
+  CMBL_STAGE_SYNC();
 }
 
 // ---- forward, DIF: natural -> bit-reversed -------------------------------------------------------
