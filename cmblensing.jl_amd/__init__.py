@@ -11,4 +11,4 @@ from .engine import (ProjLambert, LenseFlow, BaseDataSet, Field, MAP, FOURIER, H
 from .sim import (Cls, load_sim, noise_cls, beam_cls, lowpass, cl_to_2d, HarmOp, border_mask)   # noqa: F401
 from .chains import partition_chains, chain_seed, gather_chain_values   # noqa: F401
 from .drivers import (quadratic_estimate, MAP_joint, MAP_joint_step, hmc_step, sample_f, gibbs_step, symplectic_integrate,   # noqa: F401
-                      mass_matrix_phi, brent_minimize)
+                      mass_matrix_phi, brent_minimize, sample_joint)

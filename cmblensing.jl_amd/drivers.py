@@ -301,3 +301,38 @@ def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always
     f2, phi2 = ds.unmix(fo, po2)
     lp = ds.logpdf(f2, phi2)
     return dict(f=f2, phi=phi2, dH=dH, accept=accept, logpdf=lp, cg_hist=hist)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=None, N=25, eps=0.01, nburnin_always_accept=0,
+                 dist=None, nchains_total=None, progress=None):
+    """`sample_joint` at fixed θ (src/sampling.jl:180-335): Gibbs loop  f | ϕ  ->  mix  ->  HMC ϕ° | f°  ->  unmix  ->  logpdf.
+    The chains owned by this process are the batch slots of `ds` (`ds.d` must have len(chain_ids) slots; the reference runs
+    chains under pmap, one worker per GPU, src/sampling.jl:266,292).  Chain c draws from NumPy PCG64(base_seed + c), so results
+    do not depend on how chains are partitioned over ranks.  With `dist` (torch.distributed) the per-step scalars of all chains are
+    all-gathered (RCCL over xGMI on GPUs) -- the only communication.  Returns dict(logpdf, dH, accept [nsamps, nchains], phi, f)."""
+    from .chains import gather_chain_values, chain_seed
+    proj, P = ds.proj, ds.P
+    B = len(chain_ids)
+    assert ds.d.arr.shape[0] == B, "dataset batch size must equal the number of local chains"
+    rngs = [np.random.Generator(np.random.PCG64(chain_seed(base_seed, c))) for c in chain_ids]
+    draw = lambda Pp: np.stack([r.standard_normal((Pp, proj.Nx, proj.Ny)) for r in rngs])
+    phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER) if phi_start is None else phi_start
+    hist = dict(logpdf=[], dH=[], accept=[], ncg=[])
+    f = None
+    for step in range(nsamps_per_chain):
+        wf, wn, wp = draw(P), draw(P), draw(1)
+        logu = np.log(np.array([r.random() for r in rngs]))
+        st = gibbs_step(ds, phi, wf, wn, wp, logu, N=N, eps=eps, always_accept=(step < nburnin_always_accept))
+        phi, f = st["phi"], st["f"]
+        hist["logpdf"].append(st["logpdf"]); hist["dH"].append(st["dH"]); hist["accept"].append(st["accept"].astype(float))
+        hist["ncg"].append(np.full(B, len(st["cg_hist"]), float))
+        if progress:
+            progress(step, st)
+    out = {k: np.stack(v) for k, v in hist.items()}                     # (nsamps, B)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        n = nchains_total
+        dev = proj.device if dist.get_backend() == "nccl" else "cpu"
+        out = {k: gather_chain_values(list(chain_ids), v.T, n, dist, dev).T for k, v in out.items()}   # (nsamps, nchains_total)
+    out["phi"], out["f"] = phi, f
+    return out

@@ -143,6 +143,7 @@ def white_noise(seed, shape):
 def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T=3.0, lknee=100.0, alphaknee=3.0,
              beam_fwhm=0.0, pixel_mask=None, bandpass_lmax=3000, nsteps=7, Nbatch=1, seeds=(1, 2, 3),
              Nphi=None, Nphi_fac=2, G=None):
+    # Nphi: None / "qe" -> N⁰ of the quadratic estimator like the reference; "flat" -> cheap flat level; or an [x,ky] plane
     """`load_sim` (src/dataset.jl:186-338).  `cls`: dict group -> dict {TT,EE,BB,TE,pp} of Cls for the groups
     'unlensed_scalar', 'tensor', 'total' (e.g. decoded from the reference's dat/default_camb_Cls.jld2).
     Returns dict(f, phi, ftilde, d, ds, proj) with Fields on the device."""
@@ -161,7 +162,8 @@ def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T
     Bop = mk(Cls(bcl.ell, np.sqrt(bcl.cl)), units=1, te_zero=True)              # :300
     Mpix = border_mask(proj, **pixel_mask) if pixel_mask is not None else None
 
-    if Nphi is None:                                                            # stand-in for quadratic_estimate(ds).Nϕ (:316)
+    qe_nphi = Nphi is None or (isinstance(Nphi, str) and Nphi == "qe")
+    if qe_nphi or (isinstance(Nphi, str) and Nphi == "flat"):                   # provisional flat level until the data exist (see below)
         sel = (proj.lmag > 100) & (proj.lmag < 2000)
         Nphi = np.where(Cphi > 0, np.exp(np.mean(np.log(Cphi[sel]))), 0.0)
     Nphi = np.asarray(Nphi, float) / Nphi_fac
@@ -192,4 +194,7 @@ def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T
     x = Field(proj, proj.diag_apply(Mf.p, x.arr, HARMONIC, HARMONIC), HARMONIC)
     d = x + n
     ds.set_data(d)
+    if qe_nphi:                                                                 # ds.Nϕ = quadratic_estimate(ds).Nϕ / Nϕ_fac   (:316)
+        from .drivers import quadratic_estimate
+        ds.host["Nphi"] = quadratic_estimate(ds)["Nphi"] / Nphi_fac
     return dict(f=f, phi=phi, ftilde=ftilde, d=d, n=n, ds=ds, proj=proj)
