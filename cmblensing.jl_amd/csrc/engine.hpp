@@ -25,9 +25,9 @@ inline void raise_lds_limit(const void* fn, size_t bytes) {
   done[fn] = bytes;
 }
 // kernel classes for the optional per-launch event timing (cmbl_prof_*)
-enum KernelId { K_LAYOUT = 0, K_Y_R2C, K_Y_C2R, K_X_FFT, K_X_GRAD, K_FLOW_Y, K_ADJ_Y, K_ADJ_X, K_DELTA_Y, K_DPHI_Y, K_DPHI_X,
+enum KernelId { K_LAYOUT = 0, K_Y_R2C, K_Y_C2R, K_X_FFT, K_X_GRAD, K_FLOW_Y, K_ADJ_Y, K_ADJ_X, K_DELTA_Y, K_DELTA_ROWS, K_DPHI_Y, K_DPHI_X,
                 K_GRADHESS, K_HARM, K_LINCOMB, K_MASK, K_REDUCE, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_y",
+static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_y", "delta_rows",
                                                   "dphi_y", "dphi_x", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce"};
 
 #define CMBL_LAUNCH_NT(ctxp, kid, nthreads, kernel, grid, lds, stream, ...)            \
@@ -98,6 +98,7 @@ struct CtxBase {
 template <typename T>
 struct Ctx : CtxBase {
   DevBuf twY, twX, lx_r, ly, lam, cos2F, sin2F, red_part, red_out;
+  T dlx_over_Nx = 0;                       // dlx / Nx for the fused i*lx multiply of the d/dx row pass
   DevBuf tmpA, tmpB;                       // conversion scratch (mixed/F complex)
   static constexpr int RED_BLOCKS = 256;
 
@@ -119,6 +120,7 @@ struct Ctx : CtxBase {
     const T dx = (T)(theta / 60.0 * M_PI / 180.0);
     const T dlx = (T)(2.0 * M_PI / (double)((T)Nx * dx));
     const T dly = (T)(2.0 * M_PI / (double)((T)Ny * dx));
+    dlx_over_Nx = dlx / (T)Nx;
     std::vector<T> lx(Nx), lyv(Nyh), lamv(Nyh, (T)2);
     for (int i = 0; i < Nx; ++i) { int k = i < (Nx + 1) / 2 ? i : i - Nx; lx[i] = (T)k * dlx; }      // ifftshift(-N÷2:(N-1)÷2)
     for (int i = 0; i < Nyh; ++i) { int k = i < (Ny + 1) / 2 ? i : i - Ny; lyv[i] = (T)k * dly; }     // last entry negative
@@ -555,7 +557,7 @@ struct Flow {
         const int buf = side ? (it & 1) : 0;
         T* wa = buf ? w1q.as<T>() : w1p.as<T>();
         T* wb = buf ? w2q.as<T>() : w2p.as<T>();
-        c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);
+        if (it == 0) c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);              // later d/dx passes ride along with the previous stage's row pass
         if (side && it >= 2) CMBL_HIP(hipStreamWaitEvent(c->stream, evDone[buf], 0));   // the w buffers of stage it-2 have been consumed
         DeltaYArgs<T> d{};
         FlowYArgs<T>& a = d.f;
@@ -574,10 +576,15 @@ struct Flow {
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
         x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX2; x.rows = rows; x.rk = rk;
-        c->dispatch_row(c->pickXNT(rows, RX2), [&](auto lgnx, auto xnt) {
-          constexpr int XNT = decltype(xnt)::value;
-          CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rows + RX2 - 1) / RX2)), c->ldsX(RX2, 2), c->stream, x);
-        });
+        {
+          // one launch: delta-f row pass of this stage + d/dx pass of the next stage's f (a_cur already points at A_{s+1})
+          GradXArgs<T> gx{a_cur, Gx.as<cx<T>>(), x.twX, c->dlx_over_Nx, rows, RX2};
+          const int nb_adj = (int)((rows + RX2 - 1) / RX2), nb_grad = last ? 0 : nb_adj;
+          c->dispatch_row(c->pickXNT(rows, RX2), [&](auto lgnx, auto xnt) {
+            constexpr int XNT = decltype(xnt)::value;
+            CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, XNT, decltype(lgnx)::value>), dim3((unsigned)(nb_adj + nb_grad)), c->ldsX(RX2, 2), c->stream, x, gx, nb_adj);
+          });
+        }
         // delta-phi branch (side stream)
         DphiYArgs<T> py{};
         py.w1p = wa; py.w2p = wb; py.Z0 = Z0.as<cx<T>>(); py.Z1 = Z1.as<cx<T>>(); py.Z2 = Z2.as<cx<T>>();

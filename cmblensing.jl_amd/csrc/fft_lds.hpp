@@ -97,16 +97,19 @@ __device__ __forceinline__ void dif_stage(cx<T>* __restrict__ s, int S, const cx
 }
 
 // One fused DIT stage: LG levels with spans hmin = 2^LGH (bottom) ... hmin * 2^(LG-1).
-template <typename T, int NT, int LD, int LGN, int LGNTW, int LGH, int LG>
-__device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
+struct NoPre { template <typename V> __device__ __forceinline__ V operator()(V v, int) const { return v; } };
+
+template <typename T, int NT, int LD, int LGN, int LGNTW, int LGH, int LG, typename PRE = NoPre>
+__device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
   constexpr int r = 1 << LG, hmin = 1 << LGH, lgnb = LGN - LG;
   for (int q = threadIdx.x; q < (S << lgnb); q += NT) {
     const int seq = q >> lgnb, rr = q & ((1 << lgnb) - 1);
     const int blk = rr >> LGH, j = rr & (hmin - 1);
-    cx<T>* p = s + seq * LD + pad((blk << (LGH + LG)) + j);
+    const int b0 = (blk << (LGH + LG)) + j;                          // logical (unpadded) index of element m = 0
+    cx<T>* p = s + seq * LD + pad(b0);
     cx<T> v[r];
 #pragma unroll
-    for (int m = 0; m < r; ++m) v[m] = p[pad(m << LGH)];
+    for (int m = 0; m < r; ++m) v[m] = pre(p[pad(m << LGH)], b0 + (m << LGH));   // pre: pointwise op fused into the first stage
 #pragma unroll
     for (int t = 0; t < LG; ++t) {
       // level t: span h_t = hmin << t ; pairs (m, m + 2^t) inside groups of 2^(t+1)
@@ -142,12 +145,13 @@ __device__ __forceinline__ void fft_dif(cx<T>* __restrict__ s, int S, const cx<T
 }
 
 // ---- inverse, DIT: bit-reversed -> natural (unnormalised); the forward schedule replayed backwards ----
-template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, int I = num_stages(LGN, MAXLG) - 1>
-__device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
+template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, int I = num_stages(LGN, MAXLG) - 1, typename PRE = NoPre>
+__device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
   if constexpr (I >= 0) {
     constexpr int LG = stage_lg(LGN, I, MAXLG);
     constexpr int LGH = levels_after(LGN, I, MAXLG);               // bottom span index of this stage
-    dit_stage<T, NT, LD, LGN, LGNTW, LGH, LG>(s, S, tw);
+    if constexpr (I == num_stages(LGN, MAXLG) - 1) dit_stage<T, NT, LD, LGN, LGNTW, LGH, LG, PRE>(s, S, tw, pre);   // pre applies to the bit-reversed input
+    else dit_stage<T, NT, LD, LGN, LGNTW, LGH, LG>(s, S, tw);
     fft_dit<T, NT, LD, LGN, LGNTW, MAXLG, I - 1>(s, S, tw);
   }
 }

@@ -197,15 +197,14 @@ __global__ __launch_bounds__(NT) void k_x_fft(const cx<T>* __restrict__ in, cx<T
   const T inv = T(1) / T(Nx);
   if (MODE == 0 || MODE == 2) fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
   if (MODE == 2) {
-    for (int e = threadIdx.x; e < nr * Nx; e += NT) {
-      const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
-      const T l = lx_r[i] * inv;
-      cx<T> v = s[si];
-      s[si] = mk<T>(-l * v.y, l * v.x);
-    }
-    __syncthreads();
+    // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i); lx_r[1] = lx(kx = Nx/2) = -(Nx/2) dlx
+    const T dl = lx_r[1] * T(-2) * inv * inv;
+    fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw, [dl](cx<T> v, int i) {
+      const int kx = brevc<LGNX>(i);
+      return mk<T>(-(dl * T(kx < (Nx >> 1) ? kx : kx - Nx)) * v.y, (dl * T(kx < (Nx >> 1) ? kx : kx - Nx)) * v.x);
+    });
   }
-  if (MODE == 1 || MODE == 2) fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
+  if (MODE == 1) fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
   cx<T>* dst = out + r0 * Nx;
   if (MODE == 1) { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = inv * s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }
   else           { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }

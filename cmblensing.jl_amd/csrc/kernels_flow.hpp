@@ -206,12 +206,11 @@ template <typename T> struct AdjXArgs {
 };
 
 template <typename T, int NT, int LGNX>
-__global__ __launch_bounds__(NT) void k_adj_x(AdjXArgs<T> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* smem, long blk) {
   constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
-  const long r0 = (long)blockIdx.x * a.RX;
+  const long r0 = blk * a.RX;
   const int nr = (int)min((long)a.RX, a.rows - r0);
   cx<T>* s2 = s + (size_t)a.RX * LD;
   load_twiddles<T, NT>(tw, a.twX, Nx >> 1);
@@ -239,6 +238,46 @@ __global__ __launch_bounds__(NT) void k_adj_x(AdjXArgs<T> a) {
   __syncthreads();
   fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
   for (int e = threadIdx.x; e < n; e += NT) a.Hnext[r0 * Nx + e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
+}
+
+template <typename T, int NT, int LGNX>
+__global__ __launch_bounds__(NT) void k_adj_x(AdjXArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  adj_x_body<T, NT, LGNX>(a, smem, blockIdx.x);
+}
+
+// x-derivative row pass as a device function (same as k_x_fft<MODE 2>)
+template <typename T> struct GradXArgs { const cx<T>* in; cx<T>* out; const cx<T>* twX; T dlx_over_Nx; long rows; int RX; };
+template <typename T, int NT, int LGNX>
+__device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char* smem, long blk) {
+  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* s = tw + (Nx >> 1);
+  const long r0 = blk * g.RX;
+  const int nr = (int)min((long)g.RX, g.rows - r0);
+  load_twiddles<T, NT>(tw, g.twX, Nx >> 1);
+  const cx<T>* src = g.in + r0 * Nx;
+  for (int e = threadIdx.x; e < nr * Nx; e += NT) s[(e >> LGNX) * LD + pad(e & (Nx - 1))] = src[e];
+  __syncthreads();
+  fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
+  // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
+  const T dl = g.dlx_over_Nx;
+  fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw, [dl](cx<T> v, int i) {
+    const int kx = brevc<LGNX>(i);
+    return mul_il(v, dl * T(kx < (Nx >> 1) ? kx : kx - Nx));
+  });
+  cx<T>* dst = g.out + r0 * Nx;
+  for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
+}
+
+// One launch for the two independent row passes that follow a delta-flow column kernel: the delta-f pass of this stage
+// (blocks [0, nblk_adj)) and the d/dx pass of the NEXT stage's f (blocks [nblk_adj, ...)).  Saves a dependent launch per stage
+// and fills the tail of one pass with the other.
+template <typename T, int NT, int LGNX>
+__global__ __launch_bounds__(NT) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x < nblk_adj) adj_x_body<T, NT, LGNX>(a, smem, blockIdx.x);
+  else grad_x_body<T, NT, LGNX>(g, smem, (long)blockIdx.x - nblk_adj);
 }
 
 // ---------------------------------------------------------------------------------------------
