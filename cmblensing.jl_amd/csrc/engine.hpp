@@ -208,17 +208,13 @@ struct Ctx : CtxBase {
 #undef CMBL_X
     if (!done) fail(ERR_SHAPE, "unsupported column tile");
   }
-  // row kernels: workgroup of XNT threads (64 = one wave per row tile, no cross-wave barriers; 256 for big batches)
+  // row kernels: workgroup of XNT threads
   int pickXNT(long rows, int RX) const {
-    const int f = env_int("CMBL_TUNE_XNT", 0);
-    if (f == 64 || f == 128 || f == 256) return f;
-    return 256;                                    // one-wave workgroups measured slower (less intra-row parallelism)
+    return 256;                                    // one-wave (64/128-thread) workgroups measured slower: less intra-row parallelism
   }
   template <typename Fn> void dispatch_row(int XNT, Fn&& fn) const {
     bool done = false;
-#define CMBL_X(lgnx) if (!done && lgNx == lgnx) { if (XNT == 64) fn(std::integral_constant<int, lgnx>{}, std::integral_constant<int, 64>{}); \
-                                                  else if (XNT == 128) fn(std::integral_constant<int, lgnx>{}, std::integral_constant<int, 128>{}); \
-                                                  else fn(std::integral_constant<int, lgnx>{}, std::integral_constant<int, 256>{}); done = true; }
+#define CMBL_X(lgnx) if (!done && lgNx == lgnx) { fn(std::integral_constant<int, lgnx>{}, std::integral_constant<int, 256>{}); done = true; }
     CMBL_ROW_LIST(CMBL_X)
 #undef CMBL_X
     if (!done) fail(ERR_SHAPE, "unsupported Nx");

@@ -24,7 +24,8 @@ class CmblError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libcmblens_hip.so")
+    """In-tree library; CMBL_LIB points at an alternative build of the same sources (tile-shape experiments)."""
+    return os.environ.get("CMBL_LIB") or os.path.join(_HERE, "libcmblens_hip.so")
 
 
 def build(force=False, verbose=False):
