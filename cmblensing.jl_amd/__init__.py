@@ -12,3 +12,4 @@ from .sim import (Cls, load_sim, noise_cls, beam_cls, lowpass, cl_to_2d, HarmOp,
 from .chains import partition_chains, chain_seed, gather_chain_values   # noqa: F401
 from .drivers import (quadratic_estimate, MAP_joint, MAP_joint_step, hmc_step, sample_f, gibbs_step, symplectic_integrate,   # noqa: F401
                       mass_matrix_phi, brent_minimize, sample_joint)
+from . import rng                                                         # noqa: F401

@@ -271,6 +271,15 @@ int cmbl_map_fma(cmbl_ctx* ctx, const void* a, const void* b, double scale, void
   });
 }
 
+int cmbl_randn(cmbl_ctx* ctx, const uint64_t* seeds, int nslots, uint64_t stream, void* out, long n_per_slot) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(seeds); NOTNULL(out);
+    CMBL_REQUIRE(nslots >= 1 && n_per_slot >= 1, ERR_SHAPE, "nslots >= 1 and n_per_slot >= 1");
+    BY_DTYPE(ctx, C<float>(ctx)->randn((float*)out, seeds, nslots, stream, n_per_slot),
+             C<double>(ctx)->randn((double*)out, seeds, nslots, stream, n_per_slot));
+  });
+}
+
 // ---- dataset ---------------------------------------------------------------------------------------
 int cmbl_dataset_create(cmbl_ctx* ctx, int npol, cmbl_dataset** out) {
   return guard([&] {

@@ -335,6 +335,13 @@ struct Ctx : CtxBase {
     CMBL_LAUNCH(this, K_LINCOMB, (k_map_fma<T>), dim3(gx), 0, stream, out, a, b, (T)scale, accumulate ? 1 : 0, n);
   }
 
+  // white noise maps: slot b of `out` (n_per_slot reals) is stream `stream` of generator seeds[b]
+  void randn(T* out, const uint64_t* seeds, int nslots, uint64_t strm, long n_per_slot) {
+    const unsigned gx = (unsigned)std::min<long>(((n_per_slot + 3) / 4 + NTP - 1) / NTP, 8192);
+    for (int b = 0; b < nslots; ++b)
+      CMBL_LAUNCH(this, K_LINCOMB, (k_randn<T>), dim3(gx), 0, stream, out + (long)b * n_per_slot, n_per_slot, seeds[b], strm);
+  }
+
   // ---- basis conversion between reference-layout arrays and the internal F layout ----------------
   // to F: out_F is (P*B*plane) complex in `want` (B_FOURIER = QU Fourier, B_HARMONIC = EB Fourier)
   void to_F(int basis_in, const void* in, cx<T>* out_F, int want, int P, int B) {

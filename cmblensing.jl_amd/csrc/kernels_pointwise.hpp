@@ -197,6 +197,40 @@ __global__ __launch_bounds__(NTP) void k_map_fma(T* __restrict__ out, const T* _
   }
 }
 
+// White noise for `simulate` / `randn!` (src/specialops.jl:6,93; src/base_fields.jl:169-170): counter-based Philox4x32-10
+// (Salmon et al. 2011), key = seed, counter = (c, stream): counter c gives elements 4c..4c+3 of the slot, so the draw does not
+// depend on the launch geometry or on how chains are spread over GPUs.  Box-Muller in fp64 for both dtypes:
+//   u1 = (w0 + 0.5)/2^32, u2 = (w1 + 0.5)/2^32,  r = sqrt(-2 ln u1):  (r cos 2 pi u2, r sin 2 pi u2), same for (w2, w3).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_randn(T* __restrict__ out, long n, uint64_t seed, uint64_t stream) {
+  const long nc = (n + 3) >> 2;
+  for (long c = (long)blockIdx.x * NTP + threadIdx.x; c < nc; c += (long)gridDim.x * NTP) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    double z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double u1 = ((double)w[2 * h] + 0.5) * 0x1p-32, u2 = ((double)w[2 * h + 1] + 0.5) * 0x1p-32;
+      const double r = sqrt(-2.0 * log(u1));
+      double sn, cs;
+      sincospi(2.0 * u2, &sn, &cs);
+      z[2 * h] = r * cs; z[2 * h + 1] = r * sn;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (4 * c + j < n) out[4 * c + j] = (T)z[j];
+  }
+}
+
 // get_max_lensing_step (src/lenseflow.jl:242-256): per pixel the two roots alpha of det(I + H(phi) + alpha H(eta)) = 0,
 // minimum over the positive ones.  hp/he: [5][B][npix] maps from gradhess (gx, gy, Hxx, Hyx, Hyy); part: per-block minima.
 template <typename T>

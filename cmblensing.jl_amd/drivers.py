@@ -305,24 +305,34 @@ def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always
 
 # ---------------------------------------------------------------------------------------------------------------------
 def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=None, N=25, eps=0.01, nburnin_always_accept=0,
-                 dist=None, nchains_total=None, progress=None):
+                 dist=None, nchains_total=None, progress=None, rng="host", first_step=0):
     """`sample_joint` at fixed θ (src/sampling.jl:180-335): Gibbs loop  f | ϕ  ->  mix  ->  HMC ϕ° | f°  ->  unmix  ->  logpdf.
     The chains owned by this process are the batch slots of `ds` (`ds.d` must have len(chain_ids) slots; the reference runs
-    chains under pmap, one worker per GPU, src/sampling.jl:266,292).  Chain c draws from NumPy PCG64(base_seed + c), so results
-    do not depend on how chains are partitioned over ranks.  With `dist` (torch.distributed) the per-step scalars of all chains are
+    chains under pmap, one worker per GPU, src/sampling.jl:266,292).  Chain c draws from its own generator keyed by
+    base_seed + c, so results do not depend on how chains are partitioned over ranks: rng="host" NumPy PCG64 maps uploaded every
+    step; rng="device" Philox4x32-10 on the GPU (cmbl_randn; sequence = (draw kind, step index), so a run resumed at
+    `first_step` continues the same streams).  With `dist` (torch.distributed) the per-step scalars of all chains are
     all-gathered (RCCL over xGMI on GPUs) -- the only communication.  Returns dict(logpdf, dH, accept [nsamps, nchains], phi, f)."""
     from .chains import gather_chain_values, chain_seed
+    from . import rng as R
     proj, P = ds.proj, ds.P
     B = len(chain_ids)
     assert ds.d.arr.shape[0] == B, "dataset batch size must equal the number of local chains"
-    rngs = [np.random.Generator(np.random.PCG64(chain_seed(base_seed, c))) for c in chain_ids]
-    draw = lambda Pp: np.stack([r.standard_normal((Pp, proj.Nx, proj.Ny)) for r in rngs])
+    assert rng in ("host", "device")
+    seeds = [chain_seed(base_seed, c) for c in chain_ids]
+    rngs = [np.random.Generator(np.random.PCG64(s)) for s in seeds]
     phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER) if phi_start is None else phi_start
     hist = dict(logpdf=[], dH=[], accept=[], ncg=[])
     f = None
     for step in range(nsamps_per_chain):
-        wf, wn, wp = draw(P), draw(P), draw(1)
-        logu = np.log(np.array([r.random() for r in rngs]))
+        if rng == "device":
+            k = first_step + step
+            wf, wn, wp = (proj.randn(seeds, R.stream_id(kind, k), Pp) for kind, Pp in ((R.STREAM_F, P), (R.STREAM_N, P), (R.STREAM_P, 1)))
+            logu = np.log(np.array([R.uniform(s, R.stream_id(R.STREAM_U, k))[0] for s in seeds]))
+        else:
+            draw = lambda Pp: np.stack([r.standard_normal((Pp, proj.Nx, proj.Ny)) for r in rngs])
+            wf, wn, wp = draw(P), draw(P), draw(1)
+            logu = np.log(np.array([r.random() for r in rngs]))
         st = gibbs_step(ds, phi, wf, wn, wp, logu, N=N, eps=eps, always_accept=(step < nburnin_always_accept))
         phi, f = st["phi"], st["f"]
         hist["logpdf"].append(st["logpdf"]); hist["dH"].append(st["dH"]); hist["accept"].append(st["accept"].astype(float))

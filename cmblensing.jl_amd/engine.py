@@ -192,6 +192,15 @@ class ProjLambert:
         check(self.lib.cmbl_map_fma(self._h, _ptr(a), _ptr(b), float(scale), _ptr(out), 1 if acc else 0, P * B))
         return out
 
+    def randn(self, seeds, stream, P):
+        """White-noise maps (len(seeds), P, Nx, Ny): slot b ~ N(0,1) from Philox4x32-10 keyed by seeds[b], sequence `stream`
+        (`randn!`, src/base_fields.jl:169-170).  Generated on the device."""
+        seeds = [int(s) & 0xFFFFFFFFFFFFFFFF for s in (seeds if isinstance(seeds, (list, tuple)) else [seeds])]   # exact 64-bit ints
+        out = self.empty(MAP, P, len(seeds))
+        arr = (ctypes.c_uint64 * len(seeds))(*seeds)
+        check(self.lib.cmbl_randn(self._h, arr, len(seeds), int(stream) & 0xFFFFFFFFFFFFFFFF, _ptr(out), P * self.Nx * self.Ny))
+        return out
+
     def logdet(self, diag):
         d = self.tensor(diag)
         d = d.reshape(-1, self.Nx, self.Nyh)

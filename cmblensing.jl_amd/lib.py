@@ -13,7 +13,7 @@ SYMBOLS = [
     "cmbl_blockdiag_ieb_apply", "cmbl_dot", "cmbl_logdet", "cmbl_lenseflow_create", "cmbl_lenseflow_destroy",
     "cmbl_lenseflow_set_phi", "cmbl_lenseflow_apply", "cmbl_lenseflow_grad", "cmbl_dataset_create",
     "cmbl_dataset_destroy", "cmbl_dataset_set_op", "cmbl_dataset_set_data", "cmbl_dataset_set_logdet",
-    "cmbl_max_lensing_step", "cmbl_axpby", "cmbl_qe_leg", "cmbl_fourier_lmul", "cmbl_map_fma", "cmbl_gradientf_logpdf", "cmbl_wiener_cg", "cmbl_logpdf_mixed", "cmbl_grad_logpdf_mixed",
+    "cmbl_max_lensing_step", "cmbl_axpby", "cmbl_qe_leg", "cmbl_fourier_lmul", "cmbl_map_fma", "cmbl_randn", "cmbl_gradientf_logpdf", "cmbl_wiener_cg", "cmbl_logpdf_mixed", "cmbl_grad_logpdf_mixed",
 ]
 
 
@@ -88,6 +88,7 @@ def load_library():
         "cmbl_qe_leg": [vp, vp, ci, ci, ci, vp, ci],
         "cmbl_fourier_lmul": [vp, vp, ci, ci, ci, vp, ci],
         "cmbl_map_fma": [vp, vp, vp, cd, vp, ci, ci],
+        "cmbl_randn": [vp, ctypes.POINTER(ctypes.c_uint64), ci, ctypes.c_uint64, vp, ctypes.c_long],
         "cmbl_dataset_create": [vp, ci, ctypes.POINTER(vp)],
         "cmbl_dataset_destroy": [vp],
         "cmbl_dataset_set_op": [vp, ci, vp, ci],

@@ -142,7 +142,7 @@ def white_noise(seed, shape):
 
 def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T=3.0, lknee=100.0, alphaknee=3.0,
              beam_fwhm=0.0, pixel_mask=None, bandpass_lmax=3000, nsteps=7, Nbatch=1, seeds=(1, 2, 3),
-             Nphi=None, Nphi_fac=2, G=None):
+             Nphi=None, Nphi_fac=2, G=None, rng="host"):
     # Nphi: None / "qe" -> N⁰ of the quadratic estimator like the reference; "flat" -> cheap flat level; or an [x,ky] plane
     """`load_sim` (src/dataset.jl:186-338).  `cls`: dict group -> dict {TT,EE,BB,TE,pp} of Cls for the groups
     'unlensed_scalar', 'tensor', 'total' (e.g. decoded from the reference's dat/default_camb_Cls.jld2).
@@ -178,9 +178,13 @@ def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T
     Cft = mk(cls["total"])                                                     # Cf̃ (:270)
     ds.host = dict(Cf=Cf, Cn=Cn, Cphi=Cphi, Mf=Mf, B=Bop, D=D, Nphi=Nphi, G=Gp, Mpix=Mpix, precond=precond, Cftilde=Cft)
 
-    # simulate: x = sqrt(C)·rfft(white)   (src/specialops.jl:6), white ~ PCG64(seed)
+    # simulate: x = sqrt(C)·rfft(white)   (src/specialops.jl:6), white ~ NumPy PCG64(seed) uploaded, or with rng="device"
+    # drawn on the GPU (cmbl_randn: Philox4x32-10, batch slot b keyed by seed + 1000003*b)
     def sim(op_planes, seed, Pp):
-        w = proj.tensor(white_noise(seed, (Nbatch, Pp, Nx, Ny)))
+        if rng == "device":
+            w = proj.randn([seed + 1000003 * b for b in range(Nbatch)], 0, Pp)
+        else:
+            w = proj.tensor(white_noise(seed, (Nbatch, Pp, Nx, Ny)))
         return Field(proj, proj.diag_apply(op_planes, proj.rfft(w), HARMONIC, HARMONIC), HARMONIC)
     f = sim(Cf.sqrt().p, seeds[0], P)
     phi = sim(np.sqrt(Cphi)[None], seeds[1], 1)

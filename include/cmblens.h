@@ -24,6 +24,7 @@
 #define CMBLENS_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -123,6 +124,14 @@ int cmbl_axpby(cmbl_ctx* ctx, int basis, const double* a_host, const void* x, co
 int cmbl_qe_leg(cmbl_ctx* ctx, const void* in_fourier, int n, int p1, int p2, void* out_map, int nbatch);
 int cmbl_fourier_lmul(cmbl_ctx* ctx, const void* in_map, int p1, int p2, int take_abs, void* out_fourier, int nbatch);
 int cmbl_map_fma(cmbl_ctx* ctx, const void* a, const void* b, double scale, void* out, int accumulate, int nslices);
+
+/* ---- white noise for `simulate` / `randn!` (src/specialops.jl:6,93: sqrt(D) * randn!(rng, similar(diag(D)));
+ * src/base_fields.jl:169-170: randn! fills the Map array).  Replaces the reference's host RNG + upload
+ * (ext/CMBLensingCUDAExt.jl:72-73) / CURAND stream.  Slot b of `out` (n_per_slot reals of the context's dtype, e.g. one
+ * chain's (Ny,Nx,P) map block) is filled with N(0,1) draws of the counter-based generator Philox4x32-10 keyed by
+ * seeds_host[b]; `stream` selects an independent sequence of the same key (e.g. a running draw counter).  Element j of a slot
+ * depends only on (seed, stream, j): counter (j/4, stream), Box-Muller in fp64 on u = (w + 0.5)/2^32 of word pairs. */
+int cmbl_randn(cmbl_ctx* ctx, const uint64_t* seeds_host, int nslots, uint64_t stream, void* out, long n_per_slot);
 
 /* ---- data model, Wiener filter and posterior (src/dataset.jl:37-137, src/maximization.jl:17-42,
  *      src/numerical_algorithms.jl:73-134).  Operators are set as real planes in the reference
