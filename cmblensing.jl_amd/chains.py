@@ -43,3 +43,20 @@ def gather_chain_values(local_ids, local_vals, nchains, dist=None, device="cpu")
         m = i >= 0
         out[i[m]] = v[m]
     return out.cpu().numpy()
+
+
+def allreduce_sum(t, dist=None):
+    """Sum a (complex or real) tensor over ranks -- the mean-field average of MAP_marg over simulations that live on different
+    GPUs (`mean(pmap(...))`, src/maximization.jl:304-311).  RCCL all_reduce in place on the device for the nccl backend; the gloo
+    backend (CPU tests) stages through host memory."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    cplx = t.is_complex()
+    buf = (torch.view_as_real(t) if cplx else t).contiguous()
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(buf)
+    else:
+        host = buf.cpu()
+        dist.all_reduce(host)
+        buf = host.to(t.device)
+    return torch.view_as_complex(buf) if cplx else buf

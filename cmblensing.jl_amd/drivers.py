@@ -241,6 +241,71 @@ def MAP_joint(ds, nsteps=20, phi_start=None, **kw):
     return f, phi, hist
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+def simulate_data(ds, phi, white_f, white_n):
+    """`simulate(rng, ds; ϕ).d` (src/dataset.jl:59-66 run as a simulation): f ~ 𝒩(0,Cf), n ~ 𝒩(0,Cn), d = M·B·L(ϕ)·f + n.
+    white_*: (B,P,Nx,Ny) unit white-noise maps (device tensors from ProjLambert.randn, or host arrays).  Returns d (HARMONIC)."""
+    proj, h = ds.proj, ds.host
+    raw = lambda w, op: Field(proj, proj.diag_apply(op.sqrt().p, proj.rfft(proj.tensor(w)), HARMONIC, HARMONIC), HARMONIC)
+    return ds.mean(raw(white_f, h["Cf"]), phi) + raw(white_n, h["Cn"])
+
+
+def MAP_marg(ds, nsteps=10, nsteps_with_meanfield_update=4, alpha=0.2, Nsims=50, sims_per_batch=1, phi_start=None, cg_tol=1e-1,
+             cg_nsteps=500, base_seed=0, rng="device", whites=None, dist=None, progress=None):
+    """`MAP_marg(ds)` (src/maximization.jl:245-343) at fiducial θ: ϕ ← ϕ + α·Hϕ⁻¹·(g_data − ḡ_sims − Cϕ⁻¹ϕ) with
+    g = ∂logpdf/∂ϕ at the Wiener-filtered f, the mean field ḡ averaged over Nsims simulated data sets (re-drawn from the SAME
+    random numbers every step, `_rng = copy(rng)` :283) and refreshed during the first `nsteps_with_meanfield_update` steps.
+    Sims are independent: `sims_per_batch` of them share a launch as batch slots (1 = the reference's per-sim CG stopping),
+    and with `dist` (torch.distributed) sim i lives on rank i mod world, the mean field is one all_reduce (the `pmap` + `mean`
+    of :304-311).  Sim i draws from generator base_seed + i (device Philox, or host PCG64, or injected `whites[kind][i]`).
+    Returns (ϕ, trace)."""
+    from . import rng as R
+    from .chains import allreduce_sum
+    proj, P, h = ds.proj, ds.P, ds.host
+    assert ds.d.arr.shape[0] == 1, "MAP_marg for batched fields not implemented (src/maximization.jl:262)"
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None and dist.is_initialized() else (1, 0)
+    mine = [i for i in range(Nsims) if i % world == rank]
+    with np.errstate(divide="ignore"):
+        Hinv = 1 / (_pinv(h["Cphi"]) + _pinv(h["Nphi"]))                                          # :268
+    Hinv[~np.isfinite(Hinv)] = 0
+    phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, 1)), FOURIER) if phi_start is None else phi_start
+    batches = [mine[i:i + sims_per_batch] for i in range(0, len(mine), sims_per_batch)]
+    assert nsteps_with_meanfield_update >= 1, "the mean field must be estimated at least once"
+    f_prev_sims, f_prev, gbar, trace = [None] * len(batches), None, None, []
+
+    def draw(kind, ids):
+        if whites is not None:
+            return np.stack([whites[kind][i] for i in ids])
+        if rng == "device":
+            return proj.randn([base_seed + i for i in ids], R.stream_id(kind, 0), P)
+        return np.stack([np.random.Generator(np.random.PCG64([base_seed + i, kind])).standard_normal((P, proj.Nx, proj.Ny)) for i in ids])
+
+    def gMAP(d, fprev):                                                                           # :287-303
+        f_wf, hist = ds.argmaxf_logpdf(phi, d=d, fstart=fprev, tol=cg_tol, nsteps=cg_nsteps)
+        return ds.gradientphi_logpdf(f_wf, phi, d=d), f_wf, hist
+
+    for step in range(1, nsteps + 1):
+        g_data, f_prev, hist = gMAP(ds.d, f_prev)
+        ncg = [len(hist)]
+        if step <= nsteps_with_meanfield_update:                                                  # :305-316
+            tot = torch.zeros_like(proj.empty(FOURIER, 1, 1))
+            for k, ids in enumerate(batches):
+                d_sim = simulate_data(ds, phi, draw(R.STREAM_F, ids), draw(R.STREAM_N, ids))      # :282-286
+                g, f_prev_sims[k], hist = gMAP(d_sim, f_prev_sims[k])
+                tot += g.arr.sum(dim=0, keepdim=True)
+                ncg.append(len(hist))
+            gbar = Field(proj, allreduce_sum(tot, dist) / Nsims, FOURIER)
+        # final total posterior gradient, including gradient of the prior (:319).  g_data and every sim gradient carry the −Cϕ⁻¹ϕ of
+        # the joint logpdf at the ϕ they were evaluated at, exactly as in the reference (ḡ is frozen after the mean-field steps).
+        prior = Field(proj, proj.diag_apply(ds.ops["Cphi_inv"], phi.to(FOURIER).arr, FOURIER, FOURIER), FOURIER)
+        g = g_data - gbar - prior
+        phi = proj.axpby(1.0, phi.to(FOURIER), alpha, Field(proj, proj.diag_apply(Hinv[None], g.arr, FOURIER, FOURIER), FOURIER))   # :322
+        trace.append(dict(step=step, g_norm=float(np.sqrt(np.sum(g.dot(g)))), ncg=ncg, phi=phi))
+        if progress:
+            progress(step, trace[-1])
+    return phi, trace
+
+
 def _pinv(x):
     with np.errstate(divide="ignore", invalid="ignore"):
         r = 1.0 / np.asarray(x, float)

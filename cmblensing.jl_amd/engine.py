@@ -369,6 +369,38 @@ class BaseDataSet:
         """harmonic-basis operator `name` applied to Field f"""
         return Field(self.proj, self.proj.diag_apply(self.ops[name], f.arr, HARMONIC, f.basis, basis_out), basis_out)
 
+    def _applyT(self, name, f, basis_out=HARMONIC):
+        """transpose of the (real) harmonic-basis operator `name`: for BlockDiagIEB planes (TT,TE,ET,EE,BB) swap TE <-> ET"""
+        op = self.ops[name]
+        if op.shape[0] == 5:
+            op = op[[0, 2, 1, 3, 4]].contiguous()
+        return Field(self.proj, self.proj.diag_apply(op, f.arr, HARMONIC, f.basis, basis_out), basis_out)
+
+    def _maskT(self, f):
+        """M' = Mpix' * Mfourier' (src/dataset.jl:279-285) on a Field; returns HARMONIC"""
+        f = self._applyT("Mf", f)
+        if "Mpix" not in self.ops:
+            return f
+        m = f.to(MAP)
+        key = tuple(m.arr.shape)
+        if getattr(self, "_mask_full", (None, None))[0] != key:
+            self._mask_full = (key, self.ops["Mpix"].reshape(1, 1, self.proj.Nx, self.proj.Ny).expand(*key).contiguous())
+        return Field(self.proj, self.proj.map_fma(m.arr, self._mask_full[1]), MAP).to(HARMONIC)
+
+    def gradientphi_logpdf(self, f, phi, d=None, alias_quirk=False):
+        """∂/∂ϕ logpdf(ds; f, ϕ, d) at fixed f -- what `gradient(ϕ -> logpdf(dsθ; f=f_wf, ϕ, dsθ.d), ϕ)` evaluates in MAP_marg
+        (src/maximization.jl:301): the δ-flow pullback of L(ϕ)*f (src/flowops.jl:40-54) applied to ∂/∂f̃ = B'M'Cn⁻¹(d − MBLf),
+        minus Cϕ⁻¹ϕ.  f, d may carry B batch slots against one ϕ."""
+        d = self.d if d is None else d
+        ft = self.L(phi) * f.to(MAP)
+        z = d.to(HARMONIC) - self._mask(self._apply("B", ft))
+        w = self._applyT("B", self._maskT(self._apply("Cn_inv", z)), basis_out=FOURIER)
+        dphi, _, _ = self.L(phi).gradient(FLOW_FWD, ft, w, alias_quirk=alias_quirk)
+        prior = self.proj.diag_apply(self.ops["Cphi_inv"], phi.to(FOURIER).arr, FOURIER, FOURIER)
+        if prior.shape[0] != dphi.arr.shape[0]:
+            prior = prior.expand(dphi.arr.shape[0], -1, -1, -1).contiguous()
+        return dphi - Field(self.proj, prior, FOURIER)
+
     def _mask(self, f):
         """M = Mfourier * Mpix (src/dataset.jl:279-285) on a Field; returns HARMONIC"""
         if "Mpix" in self.ops:

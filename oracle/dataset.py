@@ -195,8 +195,7 @@ class DataSet:
     def L(self, phi_l):
         key = phi_l.tobytes()
         if self._L is None or self._L[0] != key:
-            phi = irfft2(phi_l, self.proj.Ny).astype(self.proj.T)
-            self._L = (key, LenseFlow(self.proj, phi, self.nsteps))
+            self._L = (key, LenseFlow(self.proj, None, self.nsteps, phi_l=phi_l))      # Fourier ϕ used as is (lenseflow.jl:135)
         return self._L[1]
 
     def dot(self, a, b):
@@ -240,6 +239,25 @@ class DataSet:
         y = self.B.T_()(self.Mt(r))
         g = qu_to_harm(proj, L.adj(harm_to_qu(proj, y)))
         return g - self.Cf.pinv()(fh)
+
+    def gradientphi_logpdf(self, fh, phi_l, d=None, alias_quirk=False):
+        """∂/∂ϕ logpdf(ds; f, ϕ, d) at fixed f -- `gradient(ϕ -> logpdf(dsθ; f=f_wf, ϕ, dsθ.d), ϕ)` of MAP_marg
+        (maximization.jl:307): pullback of Lϕ*f (flowops.jl:40-54) of ∂/∂f̃ = −B'M'Cn⁻¹z, plus the prior term −Cϕ⁻¹ϕ."""
+        d = self.d if d is None else d
+        proj = self.proj
+        L = self.L(phi_l)
+        ftil = L.apply(from_harm(proj, fh))
+        z = self.M(self.B(to_harm(proj, ftil))) - d
+        dtil = -self.B.T_()(self.Mt(self.Cn.pinv()(z)))
+        _, _, dphi = L.grad_apply(ftil, harm_to_qu(proj, dtil), alias_quirk)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return dphi - nan2zero(phi_l / self.Cphi)
+
+    def simulate_data(self, phi_l, white_f, white_n):
+        """`simulate(rng, ds; ϕ).d`: d = M B Lϕ f + n with f = sqrt(Cf)·rfft(white), n = sqrt(Cn)·rfft(white) (specialops.jl:6,93)"""
+        f = self.Cf.sqrt()(rfft2(white_f).astype(ctype(self.proj.T)))
+        n = self.Cn.sqrt()(rfft2(white_n).astype(ctype(self.proj.T)))
+        return self.mean(self.L(phi_l), f) + n
 
     # ---- mixing (dataset.jl:96-117) -----------------------------------------------------
     def mix(self, fh, phi_l):

@@ -39,21 +39,29 @@ def rk4(F, y0, t0, t1, nsteps):
 class LenseFlow:
     """`CachedLenseFlow` (src/lenseflow.jl:33-60,131-142).
 
-    phi : real map, shape (Bphi, 1, Nx, Ny).  Caches p(t), M⁻¹(t) at the 2n+1 times k/(2n).
+    phi : real map, shape (Bphi, 1, Nx, Ny), or `phi_l`: its half-plane Fourier coefficients (Bphi, 1, Nx, Nyh).
+    `gradhess(ϕ)` acts on ϕ in whatever basis it arrives (`∇ⁱ*f` only transforms a Map, src/specialops.jl:184-188,
+    src/lenseflow.jl:135): a Fourier ϕ whose ky = 0 / Nyquist rows are not Hermitian-consistent -- every ϕ produced by a gradient
+    step is -- is NOT projected through a map first, so ∂ϕ = irfft(iℓ·ϕ_l) sees the unprojected coefficients.
+    Caches p(t), M⁻¹(t) at the 2n+1 times k/(2n).
     """
 
-    def __init__(self, proj, phi, nsteps=7):
+    def __init__(self, proj, phi, nsteps=7, phi_l=None):
         self.proj, self.n = proj, int(nsteps)
         self.T = proj.T
-        phi = np.asarray(phi, dtype=proj.T)
-        assert phi.ndim == 4 and phi.shape[1] == 1
+        if phi_l is None:
+            phi = np.asarray(phi, dtype=proj.T)
+            assert phi.ndim == 4 and phi.shape[1] == 1
+            phi_l = rfft2(phi)
+        self.phi_l = np.asarray(phi_l)
+        assert self.phi_l.ndim == 4 and self.phi_l.shape[1] == 1
         self.phi = phi
         self._precompute()
 
     # src/lenseflow.jl:131-142
     def _precompute(self):
         T, n = self.T, self.n
-        (gx, gy), ((Hxx, Hxy), (Hyx, Hyy)) = gradhess(self.proj, rfft2(self.phi))
+        (gx, gy), ((Hxx, Hxy), (Hyx, Hyy)) = gradhess(self.proj, self.phi_l)
         gx, gy, Hxx, Hxy, Hyx, Hyy = (a.astype(T) for a in (gx, gy, Hxx, Hxy, Hyx, Hyy))
         self.p, self.Minv = {}, {}
         for k in range(2 * n + 1):
@@ -155,7 +163,7 @@ class LenseFlow:
         return self._delta(f, delta_l, 0.0, 1.0, alias_quirk)
 
     def _delta(self, f0, delta_l, t0, t1, alias_quirk):
-        B = max(f0.shape[0], self.phi.shape[0])
+        B = max(f0.shape[0], self.phi_l.shape[0])
         C = delta_l.dtype
         dp0 = np.zeros((B, 1, self.proj.Nx, self.proj.Nyh), dtype=C)
         F = lambda t, s: self._veldelta(t, s, alias_quirk)

@@ -31,6 +31,10 @@ def _worker(rank, world, port, nchains, q):
     g2 = C.gather_chain_values(ids, maps, nchains, dist)
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)             # the max-over-ranks timing reduction bench.py uses
+    # MAP_marg's mean field: simulations i mod world == rank contribute locally, one all_reduce gives the sum over all sims
+    local = sum(torch.full((1, 1, 4, 3), complex(i, -2 * i), dtype=torch.complex128) for i in range(7) if i % world == rank)
+    tot = C.allreduce_sum(local, dist)
+    assert torch.allclose(tot, torch.full((1, 1, 4, 3), complex(21, -42), dtype=torch.complex128))
     q.put((rank, ids, g1, g2, float(t.item())))
     dist.barrier()
     dist.destroy_process_group()
@@ -59,5 +63,7 @@ def test_partition_and_gather_world2():
 def test_single_process_gather():
     import cmblensing_jl_amd as C
     assert C.partition_chains(8, 8, 3) == [3] and C.partition_chains(3, 8, 5) == []
+    x = torch.ones(2, dtype=torch.complex64)
+    assert C.allreduce_sum(x, None) is x
     out = C.gather_chain_values([0, 1, 2], np.arange(3.0), 3, None)
     np.testing.assert_array_equal(out[:, 0], np.arange(3.0))
