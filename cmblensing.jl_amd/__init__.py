@@ -13,3 +13,4 @@ from .chains import partition_chains, chain_seed, gather_chain_values, allreduce
 from .drivers import (quadratic_estimate, MAP_joint, MAP_joint_step, hmc_step, sample_f, gibbs_step, symplectic_integrate,   # noqa: F401
                       mass_matrix_phi, brent_minimize, sample_joint, MAP_marg, simulate_data)
 from . import rng                                                         # noqa: F401
+from .chainfile import load_chains, Chain, Chains                         # noqa: F401

@@ -4,6 +4,7 @@ These mirror the reference's Julia drivers (src/quadratic_estimate.jl, src/maxim
 388-464): control flow on the host, every field operation a library call.
 """
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -370,30 +371,77 @@ def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always
 
 # ---------------------------------------------------------------------------------------------------------------------
 def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=None, N=25, eps=0.01, nburnin_always_accept=0,
-                 dist=None, nchains_total=None, progress=None, rng="host", first_step=0):
+                 dist=None, nchains_total=None, progress=None, rng="host", first_step=0, filename=None, nfilewrite=5, nsavemaps=1,
+                 resume=None):
     """`sample_joint` at fixed θ (src/sampling.jl:180-335): Gibbs loop  f | ϕ  ->  mix  ->  HMC ϕ° | f°  ->  unmix  ->  logpdf.
     The chains owned by this process are the batch slots of `ds` (`ds.d` must have len(chain_ids) slots; the reference runs
     chains under pmap, one worker per GPU, src/sampling.jl:266,292).  Chain c draws from its own generator keyed by
     base_seed + c, so results do not depend on how chains are partitioned over ranks: rng="host" NumPy PCG64 maps uploaded every
     step; rng="device" Philox4x32-10 on the GPU (cmbl_randn; sequence = (draw kind, step index), so a run resumed at
     `first_step` continues the same streams).  With `dist` (torch.distributed) the per-step scalars of all chains are
-    all-gathered (RCCL over xGMI on GPUs) -- the only communication.  Returns dict(logpdf, dH, accept [nsamps, nchains], phi, f)."""
+    all-gathered (RCCL over xGMI on GPUs) -- the only communication.
+    `filename` (".zip"): every `nfilewrite` steps the samples since the last write are appended as a new chunk (scalars every
+    step, ϕ and f maps every `nsavemaps` steps and at the end of each chunk; src/sampling.jl:226-228,311-320), gathered to rank
+    0 which owns the file; `resume=True` continues from the file's last sample up to `nsamps_per_chain` (:247-256), an existing
+    file needs an explicit `resume` (:239-241).  Returns dict(logpdf, dH, accept [nsamps, nchains], phi, f)."""
     from .chains import gather_chain_values, chain_seed
     from . import rng as R
+    from . import chainfile as CF
     proj, P = ds.proj, ds.P
     B = len(chain_ids)
     assert ds.d.arr.shape[0] == B, "dataset batch size must equal the number of local chains"
     assert rng in ("host", "device")
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
+    ntot = nchains_total if multi else B          # file / gather order: global chain id across ranks, position in a single process
+    fidx = list(chain_ids) if multi else list(range(B))
+    gdev = proj.device if multi and dist.get_backend() == "nccl" else "cpu"
+    CF.check_filename(filename, resume)
+    chunk_index, clobber = 1, True
+    if filename is not None and resume and os.path.isfile(filename):
+        chunk_index, first_step, last = CF.last_state(filename)
+        clobber = False
+        phi_start = Field(proj, proj.tensor(np.stack([last[c]["phi"] for c in fidx])[:, None]), FOURIER)
     seeds = [chain_seed(base_seed, c) for c in chain_ids]
-    rngs = [np.random.Generator(np.random.PCG64(s)) for s in seeds]
+    rngs = [np.random.Generator(np.random.PCG64(s if first_step == 0 else [s, first_step])) for s in seeds]
     phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER) if phi_start is None else phi_start
     hist = dict(logpdf=[], dH=[], accept=[], ncg=[])
+    chunk = [[] for _ in range(B)]
+
+    def flush():
+        nonlocal chunk_index, clobber, chunk
+        nsamp = len(chunk[0])
+        if nsamp == 0:
+            return
+        gath = lambda a: gather_chain_values(fidx, a, ntot, dist if multi else None, gdev)
+        sc = {k: gath(np.array([[s[k] for s in ch] for ch in chunk], float).reshape(B, nsamp)) for k in ("step", "logpdf", "dH", "accept", "ncg")}
+        has = [i for i, s in enumerate(chunk[0]) if "phi" in s]
+        mp = {}
+        for k in ("phi", "f"):
+            a = np.stack([np.stack([np.asarray(ch[i][k], np.complex128) for i in has]) for ch in chunk])      # (B, nmaps, ...)
+            g = gath(a.view(np.float64))
+            mp[k] = g.view(np.complex128)
+        if rank == 0:
+            out = []
+            for c in range(ntot):
+                samples = []
+                for i in range(nsamp):
+                    smp = {k: sc[k][c, i] for k in sc}
+                    smp["step"] = int(smp["step"])
+                    if i in has:
+                        smp.update({k: mp[k][c, has.index(i)] for k in mp})
+                    samples.append(smp)
+                out.append(samples)
+            CF.write_chunk(filename, chunk_index, out, rundat=dict(nchains=ntot, base_seed=base_seed, N=N, eps=eps, rng=rng, nsavemaps=nsavemaps,
+                                                                  nfilewrite=nfilewrite, Ny=proj.Ny, Nx=proj.Nx, theta_pix=proj.theta_pix, npol=P),
+                           clobber=clobber)
+        chunk_index, clobber, chunk = chunk_index + 1, False, [[] for _ in range(B)]
+
     f = None
-    for step in range(nsamps_per_chain):
+    for step in range(first_step, nsamps_per_chain) if (filename is not None and resume) else range(first_step, first_step + nsamps_per_chain):
         if rng == "device":
-            k = first_step + step
-            wf, wn, wp = (proj.randn(seeds, R.stream_id(kind, k), Pp) for kind, Pp in ((R.STREAM_F, P), (R.STREAM_N, P), (R.STREAM_P, 1)))
-            logu = np.log(np.array([R.uniform(s, R.stream_id(R.STREAM_U, k))[0] for s in seeds]))
+            wf, wn, wp = (proj.randn(seeds, R.stream_id(kind, step), Pp) for kind, Pp in ((R.STREAM_F, P), (R.STREAM_N, P), (R.STREAM_P, 1)))
+            logu = np.log(np.array([R.uniform(s, R.stream_id(R.STREAM_U, step))[0] for s in seeds]))
         else:
             draw = lambda Pp: np.stack([r.standard_normal((Pp, proj.Nx, proj.Ny)) for r in rngs])
             wf, wn, wp = draw(P), draw(P), draw(1)
@@ -402,12 +450,22 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
         phi, f = st["phi"], st["f"]
         hist["logpdf"].append(st["logpdf"]); hist["dH"].append(st["dH"]); hist["accept"].append(st["accept"].astype(float))
         hist["ncg"].append(np.full(B, len(st["cg_hist"]), float))
+        if filename is not None:
+            endchunk = (step + 1) % nfilewrite == 0
+            maps = step == 0 or (step + 1) % nsavemaps == 0 or endchunk
+            if maps:
+                ph, fh = phi.to(FOURIER).arr.cpu().numpy(), f.to(HARMONIC).arr.cpu().numpy()
+            for b in range(B):
+                smp = dict(step=step + 1, logpdf=st["logpdf"][b], dH=st["dH"][b], accept=float(st["accept"][b]), ncg=float(len(st["cg_hist"])))
+                if maps:
+                    smp.update(phi=ph[b, 0], f=fh[b])
+                chunk[b].append(smp)
+            if endchunk:
+                flush()
         if progress:
             progress(step, st)
-    out = {k: np.stack(v) for k, v in hist.items()}                     # (nsamps, B)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        n = nchains_total
-        dev = proj.device if dist.get_backend() == "nccl" else "cpu"
-        out = {k: gather_chain_values(list(chain_ids), v.T, n, dist, dev).T for k, v in out.items()}   # (nsamps, nchains_total)
+    out = {k: (np.stack(v) if v else np.zeros((0, B))) for k, v in hist.items()}                     # (nsamps, B)
+    if multi:
+        out = {k: gather_chain_values(fidx, v.T, ntot, dist, gdev).T for k, v in out.items()}   # (nsamps, nchains_total)
     out["phi"], out["f"] = phi, f
     return out

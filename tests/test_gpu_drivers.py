@@ -254,3 +254,32 @@ def test_map_marg_device_rng_converges():
     phi1, _ = C.MAP_marg(ds, nsteps=1, nsteps_with_meanfield_update=1, alpha=0.2, Nsims=8, sims_per_batch=1, base_seed=11)
     phi8, _ = C.MAP_marg(ds, nsteps=1, nsteps_with_meanfield_update=1, alpha=0.2, Nsims=8, sims_per_batch=8, base_seed=11)
     assert rel(phi1.arr.cpu().numpy(), phi8.arr.cpu().numpy()) < 0.05
+
+
+def test_sample_joint_chain_file_and_resume(tmp_path):
+    """sample_joint(filename=...) writes chunks every nfilewrite steps; a run interrupted after 4 of 6 steps and resumed from the
+    file gives the same chain as the uninterrupted run (device RNG streams are indexed by step), and load_chains reads both."""
+    import cmblensing_jl_amd as C
+    from bench import synthetic_cls
+    kw = dict(T=torch.float64, beam_fwhm=1.0, Nphi="flat")
+    s = C.load_sim(3.0, (64, 64), "P", synthetic_cls(), Nbatch=2, **kw)
+    ds = s["ds"]
+    run = dict(chain_ids=(0, 1), base_seed=7, N=3, eps=0.01, rng="device", nfilewrite=2, nsavemaps=3)
+    fa, fb = str(tmp_path / "a.zip"), str(tmp_path / "b.zip")
+    ra = C.sample_joint(ds, 6, filename=fa, **run)
+    C.sample_joint(ds, 4, filename=fb, **run)
+    with pytest.raises(ValueError):
+        C.sample_joint(ds, 6, filename=fb, **run)                        # exists: resume must be stated
+    rb = C.sample_joint(ds, 6, filename=fb, resume=True, **run)
+    assert rb["logpdf"].shape == (2, 2)                                  # only the two remaining steps were run
+    np.testing.assert_allclose(rb["logpdf"], ra["logpdf"][4:], rtol=1e-9)
+    ca, cb = C.load_chains(fa), C.load_chains(fb)
+    assert len(ca) == 2 and ca["step"].tolist() == [[1, 2, 3, 4, 5, 6]] * 2 == cb["step"].tolist()
+    np.testing.assert_allclose(ca["logpdf"], ra["logpdf"].T, rtol=1e-12)
+    np.testing.assert_allclose(cb["logpdf"], ca["logpdf"], rtol=1e-9)
+    np.testing.assert_allclose(cb["accept"], ca["accept"])
+    # maps: first step, every 3rd step, and the last step of every chunk (2, 4, 6)
+    assert [("phi" in smp) for smp in ca[0]] == [True, True, True, True, False, True]
+    np.testing.assert_allclose(cb[1, -1]["phi"], ca[1, -1]["phi"], rtol=1e-8, atol=1e-14)
+    np.testing.assert_allclose(ca[1, -1]["phi"], ra["phi"].arr[1, 0].cpu().numpy(), rtol=1e-12)
+    assert C.load_chains(fa, thin="hasmaps")["step"].tolist() == [[1, 2, 3, 4, 6]] * 2
