@@ -335,4 +335,10 @@ int cmbl_grad_logpdf_mixed(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const
   });
 }
 
+#ifdef CMBL_STAMPS
+int cmbl_debug_stamps(unsigned long long* out_host, int n) {   // phase timestamps of the last k_delta_y launch (tools/gpu_stamps.py)
+  return guard([&] { CMBL_HIP(hipDeviceSynchronize()); CMBL_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(cmbl::g_stamps), sizeof(unsigned long long) * n)); });
+}
+#endif
+
 }  // extern "C"

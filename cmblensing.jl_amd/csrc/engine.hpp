@@ -27,7 +27,7 @@ inline void raise_lds_limit(const void* fn, size_t bytes) {
 // kernel classes for the optional per-launch event timing (cmbl_prof_*)
 enum KernelId { K_LAYOUT = 0, K_Y_R2C, K_Y_C2R, K_X_FFT, K_X_GRAD, K_FLOW_Y, K_ADJ_Y, K_ADJ_X, K_DELTA_Y, K_DELTA_ROWS, K_DPHI_Y, K_DPHI_X,
                 K_GRADHESS, K_HARM, K_LINCOMB, K_MASK, K_REDUCE, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_y", "delta_rows",
+static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_cols", "delta_rows",
                                                   "dphi_y", "dphi_x", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce"};
 
 #define CMBL_LAUNCH_NT(ctxp, kid, nthreads, kernel, grid, lds, stream, ...)            \
@@ -53,7 +53,7 @@ static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x
 inline int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
 
 struct CtxBase {
-  int Ny = 0, Nx = 0, Nyh = 0, M = 0, lgM = 0, lgNx = 0, dtype = 0, device = 0;
+  int Ny = 0, Nx = 0, Nyh = 0, M = 0, lgM = 0, lgNx = 0, dtype = 0, device = 0, num_cus = 256;
   double theta = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -109,6 +109,7 @@ struct Ctx : CtxBase {
     CMBL_REQUIRE(theta > 0, ERR_ARG, "theta_pix must be positive");
     Nyh = Ny / 2 + 1; M = Ny / 2; lgM = ilog2(M); lgNx = ilog2(Nx);
     CMBL_HIP(hipSetDevice(device));
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) num_cus = n; }
     // NULL is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns when the caller has not
     // switched streams): ordered against every other blocking stream, so caller-side copies and our kernels serialise.
     stream = (hipStream_t)stream_; own_stream = false;
@@ -165,7 +166,7 @@ struct Ctx : CtxBase {
   // NT threads and R packed pairs per thread.
   // CMBL_TUNE_C forces a width, CMBL_TUNE_RX the rows per workgroup of the row kernels (tuning aids).
   struct TileY { int C, NT, R; };
-  TileY tileY(long slices, bool pair) const {
+  TileY tileY(long slices, bool pair, int preferNT = 0) const {
     static const int list[][3] = {
 #define CMBL_X(lgm, r, nt) {lgm, r, nt},
         CMBL_COL_LIST(CMBL_X)
@@ -182,7 +183,7 @@ struct Ctx : CtxBase {
       if (C > Nx || ldsY(C, pair) > 160 * 1024) continue;
       const TileY t{C, e[2], e[1]};
       if (forceC == C && (forceNT == 0 || forceNT == e[2])) return t;
-      const long score = (C >= 4 ? 1000 - C : C) * 10 + (e[2] == 512 ? 2 : (e[2] == 256 ? 1 : 0));
+      const long score = (C >= 4 ? 1000 - C : C) * 10 + (e[2] == preferNT ? 3 : (e[2] == 512 ? 2 : (e[2] == 256 ? 1 : 0)));
       if (score > bestScore) { bestScore = score; best = t; }
     }
     (void)slices;
@@ -369,44 +370,30 @@ struct Flow {
   int n;                                  // RK4 steps (src/lenseflow.jl:29 default 7)
   int Bphi = 0;
   DevBuf phimaps;                         // [5][Bphi][Nx][Ny] : gx, gy, Hxx, Hyx, Hyy
+  DevBuf pcache;                          // [2n+1][2][Bphi][Nx][Ny] : p(t_k)
+  bool use_pcache = false;
   DevBuf phiF, gh;                        // scratch for precompute
   DevBuf A, A2, Gx, y0, acc;              // forward flow state          (slices)
   DevBuf H, Wx, Wy, Y0, Yacc;             // adjoint flow state          (slices)
   DevBuf w1p, w2p, Z0, Z1, Z2, P0, Pacc;  // delta flow extras
   DevBuf cvt;                             // boundary conversion scratch
 
-  // The delta-phi branch of the gradient flow never feeds back into the f / delta-f chain, so it runs on a second stream and
-  // overlaps with the next stage's kernels (the chain itself is a strict dependency line that cannot fill the chip at B = 1).
-  hipStream_t side = nullptr;   // (a third stream for the next stage's d/dx pass was measured slower: per-stage cross-stream waits cost more than they hide)
-  hipEvent_t evW[2] = {nullptr, nullptr}, evDone[2] = {nullptr, nullptr}, evStart = nullptr;
   DevBuf w1q, w2q;                        // second set of w-partials (double buffering across stages)
 
-  Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) {
-    CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range");
-    if (env_int("CMBL_NO_SIDE_STREAM", 0) == 0) {
-      CMBL_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-      for (int i = 0; i < 2; ++i) {
-        CMBL_HIP(hipEventCreateWithFlags(&evW[i], hipEventDisableTiming));
-        CMBL_HIP(hipEventCreateWithFlags(&evDone[i], hipEventDisableTiming));
-      }
-      CMBL_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
-    }
-  }
-  ~Flow() {
-    if (side) {
-      (void)hipStreamSynchronize(side);
-      for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(evW[i]); (void)hipEventDestroy(evDone[i]); }
-      (void)hipEventDestroy(evStart);
-      (void)hipStreamDestroy(side);
-    }
-  }
+  Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) { CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range"); }
   Flow(const Flow&) = delete;
   Flow& operator=(const Flow&) = delete;
 
-  PhiMaps<T> ph() const {
+  // t < 0: no stage time (the five maps only); otherwise p(t) is also taken from the cache when it exists
+  PhiMaps<T> ph(double t = -1) const {
     const size_t s = (size_t)Bphi * c->npix();
     const T* b = phimaps.as<T>();
-    return PhiMaps<T>{b, b + s, b + 2 * s, b + 3 * s, b + 4 * s, Bphi};
+    PhiMaps<T> r{b, b + s, b + 2 * s, b + 3 * s, b + 4 * s, Bphi, nullptr, nullptr};
+    if (t >= 0 && use_pcache) {
+      const int k = (int)std::lround(t * 2 * n);
+      r.pcx = pcache.as<T>() + (size_t)(2 * k) * s; r.pcy = r.pcx + s;
+    }
+    return r;
   }
 
   // precompute! (src/lenseflow.jl:131-142): gradhess(phi) -> five maps; p(t), M^-1(t) are formed on the fly
@@ -420,6 +407,15 @@ struct Flow {
                 c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
     c->template x_pass<1>(gh.as<cx<T>>(), gh.as<cx<T>>(), 5L * nb);
     c->y_c2r(gh.as<cx<T>>(), phimaps.as<T>(), 5L * nb);
+    // p(t) at the 2n+1 stage times (the reference caches p and M^-1, src/lenseflow.jl:45-46,88-90): 2(2n+1) maps per phi slot,
+    // 120 MB at 1024^2 fp32 n = 7.  M^-1(t), needed only by the delta-phi kernel, is still formed on the fly.
+    const size_t ntot = (size_t)nb * c->npix(), bytes = sizeof(T) * 2 * (2 * n + 1) * ntot;
+    use_pcache = env_int("CMBL_NO_PCACHE", 0) == 0 && bytes <= ((size_t)env_int("CMBL_PCACHE_MAX_MB", 16384) << 20);
+    if (use_pcache) {
+      pcache.ensure(bytes);
+      const unsigned gx = (unsigned)std::min<size_t>((ntot + NTP - 1) / NTP, 16384);
+      CMBL_LAUNCH(c, K_GRADHESS, (k_pcache<T>), dim3(gx), 0, c->stream, ph(), pcache.as<T>(), (long)ntot, 2 * n);
+    }
   }
   void set_phi(int basis, const void* phi, int nb) {
     CMBL_REQUIRE(basis == B_MAP || basis == B_FOURIER || basis == B_HARMONIC, ERR_ARG, "bad basis");
@@ -484,10 +480,11 @@ struct Flow {
       for (int stage = 1; stage <= 4; ++stage) {
         c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);
         FlowYArgs<T> a{};
-        a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = y; a.acc = acc.as<T>(); a.ph = ph();
+        a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = y; a.acc = acc.as<T>();
         a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
         a.Nx = c->Nx; a.P = P;
         a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
+        a.ph = ph(a.rk.t);
         c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
           constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
           CMBL_LAUNCH_NT(c, K_FLOW_Y, NT, (k_flow_y_fwd<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, a);
@@ -512,7 +509,7 @@ struct Flow {
       for (int stage = 1; stage <= 4; ++stage) {
         const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
         AdjYArgs<T> a{};
-        a.H = H.as<cx<T>>(); a.Wx = Wx.as<cx<T>>(); a.Wy = Wy.as<cx<T>>(); a.ph = ph();
+        a.H = H.as<cx<T>>(); a.Wx = Wx.as<cx<T>>(); a.Wy = Wy.as<cx<T>>(); a.ph = ph(rk.t);
         a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
         a.Nx = c->Nx; a.P = P; a.t = rk.t;
         c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
@@ -531,6 +528,7 @@ struct Flow {
 
   // delta flow (src/flowops.jl:48,63): state (f [map], df [F, QU-Fourier], dphi [F, S0]); all updated in place.
   // forward_primal=true : pullback of L*f  -> integrate t 1->0;  false: pullback of L\f -> t 0->1.
+  // Two launches per RK stage (k_delta_cols, k_delta_rows); the delta-phi work of stage s-1 rides along with stage s.
   void flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
     check_ready(B);
     const long slices = (long)P * B, pl = c->plane(), np = c->npix();
@@ -539,77 +537,70 @@ struct Flow {
     H.ensure(sizeof(cx<T>) * slices * pl); Wx.ensure(sizeof(cx<T>) * slices * pl); Wy.ensure(sizeof(cx<T>) * slices * pl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
     w1p.ensure(sizeof(T) * slices * np); w2p.ensure(sizeof(T) * slices * np);
-    if (side) { w1q.ensure(sizeof(T) * slices * np); w2q.ensure(sizeof(T) * slices * np); }
+    w1q.ensure(sizeof(T) * slices * np); w2q.ensure(sizeof(T) * slices * np);       // partial products are double-buffered across stages
     Z0.ensure(sizeof(cx<T>) * B * pl); Z1.ensure(sizeof(cx<T>) * B * pl); Z2.ensure(sizeof(cx<T>) * B * pl);
     Pacc.ensure(sizeof(cx<T>) * B * pl);
     CMBL_HIP(hipMemsetAsync(dphi, 0, sizeof(cx<T>) * B * pl, c->stream));
-    hipStream_t sd = side ? side : c->stream;
-    if (side) { CMBL_HIP(hipEventRecord(evStart, c->stream)); CMBL_HIP(hipStreamWaitEvent(side, evStart, 0)); }
     cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
     c->y_r2c(f, a_cur, slices);
     c->template x_pass<1>(df, H.as<cx<T>>(), slices);
-    const auto tile = c->tileY(slices, true), tilep = c->tileY(B, true);
+    const auto tile = c->tileY(slices, true);
     const long rows = slices * c->Nyh, rowsp = (long)B * c->Nyh;
-    const int RX2 = c->pickRX(2, rows), RX3 = c->pickRX(3, rowsp);
+    const int RX = std::min(c->pickRX(2, rows), c->pickRX(3, rowsp));
+    const int nb_adj = (int)((rows + RX - 1) / RX), nb_dphi = (int)((rowsp + RX - 1) / RX);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
+    c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);                            // later d/dx passes ride along with the previous stage's row launch
+
+    DeltaYArgs<T> d{};
+    DphiYArgs<T> py{};
+    AdjXArgs<T> x{};
+    DphiXArgs<T> px{};
+    GradXArgs<T> gx{};
+    auto launch_cols = [&](bool with_delta, bool with_dphi) {
+      c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
+        constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+        const int sl = with_delta ? (int)slices : 0;
+        CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_cols<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)(sl + (with_dphi ? B * (R >= CMBL_DPHI_SPLIT ? CMBL_DPHI_SPLIT : 1) : 0))), c->ldsY(tile.C),
+                       c->stream, d, py, sl);
+      });
+    };
+    auto launch_rows = [&](int n_adj, int n_grad, int n_dphi) {
+      c->dispatch_row(c->pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
+        constexpr int XNT = decltype(xnt)::value;
+        CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, XNT, decltype(lgnx)::value>), dim3((unsigned)(n_adj + n_grad + n_dphi)),
+                       c->ldsX(RX, n_dphi ? 3 : 2), c->stream, x, gx, px, n_adj, n_grad);
+      });
+    };
     int it = 0;
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage, ++it) {
         const bool last = step == n - 1 && stage == 4;
         const RKCoef<T> rk = coef(step, stage, t0, h, last);
-        const int buf = side ? (it & 1) : 0;
-        T* wa = buf ? w1q.as<T>() : w1p.as<T>();
-        T* wb = buf ? w2q.as<T>() : w2p.as<T>();
-        if (it == 0) c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);              // later d/dx passes ride along with the previous stage's row pass
-        if (side && it >= 2) CMBL_HIP(hipStreamWaitEvent(c->stream, evDone[buf], 0));   // the w buffers of stage it-2 have been consumed
-        DeltaYArgs<T> d{};
+        T* wa = (it & 1) ? w1q.as<T>() : w1p.as<T>();
+        T* wb = (it & 1) ? w2q.as<T>() : w2p.as<T>();
         FlowYArgs<T>& a = d.f;
-        a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = f; a.acc = acc.as<T>(); a.ph = ph();
+        a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = f; a.acc = acc.as<T>(); a.ph = ph(rk.t);
         a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
         a.Nx = c->Nx; a.P = P; a.rk = rk;
         d.H = H.as<cx<T>>(); d.Wx = Wx.as<cx<T>>(); d.Wy = Wy.as<cx<T>>(); d.w1p = wa; d.w2p = wb;
-        c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
-          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
-          CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_y<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, d);
-        });
-        if (side) { CMBL_HIP(hipEventRecord(evW[buf], c->stream)); CMBL_HIP(hipStreamWaitEvent(side, evW[buf], 0)); }
+        launch_cols(true, it > 0);                                           // py still describes stage it-1
         std::swap(a_cur, a_nxt);
 
-        // delta-f row pass (RK update of df + next H)
-        AdjXArgs<T> x{};
+        // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_cur already points at A_{s+1}) + delta-phi rows of stage it-1
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
-        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX2; x.rows = rows; x.rk = rk;
-        {
-          // one launch: delta-f row pass of this stage + d/dx pass of the next stage's f (a_cur already points at A_{s+1})
-          GradXArgs<T> gx{a_cur, Gx.as<cx<T>>(), x.twX, c->dlx_over_Nx, rows, RX2};
-          const int nb_adj = (int)((rows + RX2 - 1) / RX2), nb_grad = last ? 0 : nb_adj;
-          c->dispatch_row(c->pickXNT(rows, RX2), [&](auto lgnx, auto xnt) {
-            constexpr int XNT = decltype(xnt)::value;
-            CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, XNT, decltype(lgnx)::value>), dim3((unsigned)(nb_adj + nb_grad)), c->ldsX(RX2, 2), c->stream, x, gx, nb_adj);
-          });
-        }
-        // delta-phi branch (side stream)
-        DphiYArgs<T> py{};
+        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.rows = rows; x.rk = rk;
+        gx = GradXArgs<T>{a_cur, Gx.as<cx<T>>(), x.twX, c->dlx_over_Nx, rows, RX};
+        launch_rows(nb_adj, last ? 0 : nb_adj, it > 0 ? nb_dphi : 0);        // px still describes stage it-1
+
+        // delta-phi work of THIS stage, launched with the next stage
         py.w1p = wa; py.w2p = wb; py.Z0 = Z0.as<cx<T>>(); py.Z1 = Z1.as<cx<T>>(); py.Z2 = Z2.as<cx<T>>();
         py.ph = ph(); py.twY = a.twY; py.ly = a.ly; py.Nx = c->Nx; py.P = P;
         py.alias_quirk = alias_quirk ? 1 : 0; py.t = rk.t;
-        c->dispatch_col(tilep, [&](auto lgm, auto r, auto nt) {
-          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
-          CMBL_LAUNCH_NT(c, K_DPHI_Y, NT, (k_dphi_y<T, R, NT, LGM>), dim3(c->Nx / tilep.C, (unsigned)B), c->ldsY(tilep.C), sd, py);
-        });
-        DphiXArgs<T> px{};
         px.Z0 = Z0.as<cx<T>>(); px.Z1 = Z1.as<cx<T>>(); px.Z2 = Z2.as<cx<T>>(); px.Y0 = dphi; px.acc = Pacc.as<cx<T>>();
-        px.twX = x.twX; px.lx_r = x.lx_r; px.RX = RX3; px.rows = rowsp; px.rk = rk;
-        c->dispatch_row(c->pickXNT(rowsp, RX3), [&](auto lgnx, auto xnt) {
-          constexpr int XNT = decltype(xnt)::value;
-          CMBL_LAUNCH_NT(c, K_DPHI_X, XNT, (k_dphi_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rowsp + RX3 - 1) / RX3)), c->ldsX(RX3, 3), sd, px);
-        });
-        if (side) CMBL_HIP(hipEventRecord(evDone[buf], side));
+        px.twX = x.twX; px.lx_r = x.lx_r; px.RX = RX; px.rows = rowsp; px.rk = rk;
       }
-    if (side) {                                                              // join: dphi is complete before the caller's stream continues
-      CMBL_HIP(hipStreamWaitEvent(c->stream, evDone[0], 0));
-      CMBL_HIP(hipStreamWaitEvent(c->stream, evDone[1], 0));
-    }
+    launch_cols(false, true);                                                // delta-phi of the last stage
+    launch_rows(0, 0, nb_dphi);
   }
 
   // ---- boundary-level entry points ---------------------------------------------------------------

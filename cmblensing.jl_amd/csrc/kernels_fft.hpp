@@ -14,6 +14,13 @@
 #define CMBL_XLG 4      // row kernels: radix-16 stages (radix-8 = 3 measured 5 % faster for L*f alone but 3 % slower for the gradient step)
 #endif
 
+#ifndef CMBL_YLGN
+#define CMBL_YLGN 4     // column kernels, N-point (pair) transforms: cap on fused radix-2 levels per LDS round trip
+#endif
+#ifndef CMBL_YLGM
+#define CMBL_YLGM 4     // column kernels, N/2-point (packed real) transforms
+#endif
+
 namespace cmbl {
 
 // Column tiles that are neighbours in x share 64/128-byte lines of the [ky][x] arrays.  Workgroup b is observed to run
@@ -73,42 +80,113 @@ template <int R, int NT, int LGM> struct ColTile {
   static_assert(C >= 1 && (C << LGM) == R * NT, "tile shape must satisfy C*M == R*NT");
 };
 
+// ---- staged global -> LDS loads -------------------------------------------------------------------------------------------
+// The compiler will not move a global load above the LDS store of an earlier loop iteration, so a plain "s[..] = g[..]" loop
+// exposes one full memory latency per iteration (measured with in-kernel timestamps: the first phase of k_delta_y took 20k
+// cycles for seven dependent round trips).  Every tile load is therefore split into issue() -- all of the thread's loads, back
+// to back, into registers -- and commit() -- the LDS stores -- so that a kernel issues EVERYTHING it needs from HBM and then
+// waits once.
+template <typename T, int NT, int NH> struct TwStage {                       // twiddle table, NH entries
+  static constexpr int K = (NH + NT - 1) / NT;
+  cx<T> v[K];
+  __device__ __forceinline__ void issue(const cx<T>* __restrict__ g) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) { const int j = threadIdx.x + i * NT; if (NH % NT == 0 || j < NH) v[i] = g[j]; }
+  }
+  __device__ __forceinline__ void commit(cx<T>* __restrict__ lds) const {
+#pragma unroll
+    for (int i = 0; i < K; ++i) { const int j = threadIdx.x + i * NT; if (NH % NT == 0 || j < NH) lds[j] = v[i]; }
+  }
+};
+
 // tile <-> mixed-layout global helpers for column kernels.  Tile: C sequences x LD slots, half-spectrum at hslot(k).
 // lanes run over c fastest so each wave touches (64/C) segments of C contiguous complex values.
-template <typename T, int NT, int LD, int LGM, int LGC, typename F>
-__device__ __forceinline__ void tile_load_mixed(cx<T>* __restrict__ s, const cx<T>* __restrict__ g /*slice base*/, int Nx, int x0, F&& f) {
-  constexpr int M = 1 << LGM, C = 1 << LGC;
-  for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
-    const int c = e & (C - 1), k = e >> LGC;
-    s[c * LD + hslot<LGM>(k)] = f(g[(size_t)k * Nx + x0 + c], k);
+template <typename T, int NT, int LGM, int LGC> struct TileStage {           // half-spectrum tile: C columns x (M+1) rows
+  static constexpr int M = 1 << LGM, C = 1 << LGC, TOT = C * (M + 1), K = (TOT + NT - 1) / NT;
+  cx<T> v[K];
+  __device__ __forceinline__ void issue(const cx<T>* __restrict__ g /*slice base*/, int Nx, int x0) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int e = threadIdx.x + i * NT;
+      if (e < TOT) v[i] = g[(size_t)(e >> LGC) * Nx + x0 + (e & (C - 1))];
+    }
   }
-}
-template <typename T, int NT, int LD, int LGM, int LGC, typename F>
-__device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int Nx, int x0, F&& f) {
+  template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int e = threadIdx.x + i * NT;
+      if (e < TOT) s[(e & (C - 1)) * LD + hslot<LGM>(e >> LGC)] = v[i];
+    }
+  }
+};
+template <typename T, int NT, int LD, int LGM, int LGC>
+__device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int Nx, int x0) {
   constexpr int M = 1 << LGM, C = 1 << LGC;
   for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
     const int c = e & (C - 1), k = e >> LGC;
-    g[(size_t)k * Nx + x0 + c] = f(s[c * LD + hslot<LGM>(k)], k);
+    g[(size_t)k * Nx + x0 + c] = s[c * LD + hslot<LGM>(k)];
   }
 }
 
 // Two real sequences per complex transform.  Z = X + iY with X, Y the (Hermitian-extended) half spectra:
 //   Z[k] = X[k] + i Y[k],  Z[N-k] = conj(X[k]) + i conj(Y[k])  (0<k<M);  Z[0], Z[M] from the real parts only (c2r semantics).
 // After the N-point DIT the tile holds N*(x[n] + i y[n]).  Frequency k sits at slot pad(brev_N(k)).
-template <typename T, int NT, int LD, int LGN, int LGC, typename FX, typename FY>
-__device__ __forceinline__ void pair_load_mixed(cx<T>* __restrict__ s, const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY,
-                                                int Nx, int x0, FX&& fX, FY&& fY) {
-  constexpr int N = 1 << LGN, M = N >> 1, C = 1 << LGC;
-  for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
-    const int c = e & (C - 1), k = e >> LGC;
-    const size_t gi = (size_t)k * Nx + x0 + c;
-    const cx<T> X = fX(gX[gi], k), Y = fY(gY[gi], k);
-    cx<T>* p = s + c * LD;
-    if (k == 0 || k == M) {
-      p[pad(brevc<LGN>(k))] = mk<T>(X.x, Y.x);
-    } else {
-      p[pad(brevc<LGN>(k))] = mk<T>(X.x - Y.y, X.y + Y.x);
-      p[pad(brevc<LGN>(N - k))] = mk<T>(X.x + Y.y, Y.x - X.y);
+// Here X = gX, Y = i*ly[k]*gY (the d/dy multiply rides along).
+template <typename T, int NT, int LGN, int LGC> struct PairStage {
+  static constexpr int N = 1 << LGN, M = N >> 1, C = 1 << LGC, TOT = C * (M + 1), K = (TOT + NT - 1) / NT;
+  cx<T> X[K], Y[K];
+  T l[K];
+  __device__ __forceinline__ void issue(const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY, const T* __restrict__ ly, int Nx, int x0) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int e = threadIdx.x + i * NT;
+      if (e < TOT) {
+        const int k = e >> LGC;
+        const size_t gi = (size_t)k * Nx + x0 + (e & (C - 1));
+        X[i] = gX[gi]; Y[i] = gY[gi]; l[i] = ly[k];
+      }
+    }
+  }
+  template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int e = threadIdx.x + i * NT;
+      if (e < TOT) {
+        const int c = e & (C - 1), k = e >> LGC;
+        const cx<T> x = X[i], y = mk<T>(-l[i] * Y[i].y, l[i] * Y[i].x);
+        cx<T>* p = s + c * LD;
+        if (k == 0 || k == M) {
+          p[pad(brevc<LGN>(k))] = mk<T>(x.x, y.x);
+        } else {
+          p[pad(brevc<LGN>(k))] = mk<T>(x.x - y.y, x.y + y.x);
+          p[pad(brevc<LGN>(N - k))] = mk<T>(x.x + y.y, y.x - x.y);
+        }
+      }
+    }
+  }
+};
+// rows of Nx contiguous values -> row tiles (row kernels): the loads of one row are issued together
+template <typename T, int NT, int LGNX, int NA>
+__device__ __forceinline__ void rows_load(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], int nr) {
+  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
+  if constexpr (Nx >= NT) {
+    constexpr int PF = Nx / NT;
+    for (int r = 0; r < nr; ++r) {
+      cx<T> v[NA][PF];
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) v[a][i] = g[a][(size_t)r * Nx + threadIdx.x + i * NT];
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) s[a][r * LD + pad(threadIdx.x + i * NT)] = v[a][i];
+    }
+  } else {
+    for (int e = threadIdx.x; e < nr * Nx; e += NT) {
+      const int si = (e >> LGNX) * LD + pad(e & (Nx - 1));
+#pragma unroll
+      for (int a = 0; a < NA; ++a) s[a][si] = g[a][e];
     }
   }
 }
@@ -140,17 +218,22 @@ __global__ __launch_bounds__(NT) void k_y_r2c(const T* __restrict__ in, cx<T>* _
   cx<T>* s = tw + M;
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
-  load_twiddles<T, NT>(tw, twY, M);
+  TwStage<T, NT, M> twr;
+  twr.issue(twY);
   const cx<T>* src = reinterpret_cast<const cx<T>*>(in) + (sl * Nx + x0) * (size_t)M;
+  cx<T> v[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) v[i] = src[threadIdx.x + i * NT];
+  twr.commit(tw);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int e = threadIdx.x + i * NT, c = e >> LGM, j = e & (M - 1);
-    s[c * LD + pad(j)] = src[e];
+    s[c * LD + pad(j)] = v[i];
   }
   __syncthreads();
-  fft_dif<T, NT, LD, LGM, LGM + 1>(s, C, tw);
+  fft_dif<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
   r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)G::Nyh * Nx, Nx, x0, [](cx<T> v, int) { return v; });
+  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)G::Nyh * Nx, Nx, x0);
 }
 
 // y pass, inverse: mixed -> map, scaled by `scale` (1/Ny; the x pass already carries 1/Nx)
@@ -163,11 +246,15 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
   cx<T>* s = tw + M;
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
-  load_twiddles<T, NT>(tw, twY, M);
-  tile_load_mixed<T, NT, LD, LGM, G::LGC>(s, in + sl * (size_t)G::Nyh * Nx, Nx, x0, [](cx<T> v, int) { return v; });
+  TwStage<T, NT, M> twr;
+  TileStage<T, NT, LGM, G::LGC> tl;
+  twr.issue(twY);
+  tl.issue(in + sl * (size_t)G::Nyh * Nx, Nx, x0);
+  twr.commit(tw);
+  tl.template commit<LD>(s);
   __syncthreads();
   c2r_pre<T, NT, LD, LGM>(s, C, tw);
-  fft_dit<T, NT, LD, LGM, LGM + 1>(s, C, tw);
+  fft_dit<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
   cx<T>* dst = reinterpret_cast<cx<T>*>(out) + (sl * Nx + x0) * (size_t)M;
 #pragma unroll
   for (int i = 0; i < R; ++i) {
@@ -190,15 +277,20 @@ __global__ __launch_bounds__(NT) void k_x_fft(const cx<T>* __restrict__ in, cx<T
   cx<T>* s = tw + (Nx >> 1);
   const long r0 = (long)blockIdx.x * RX;
   const int nr = (int)min((long)RX, rows - r0);
-  load_twiddles<T, NT>(tw, twX, Nx >> 1);
-  const cx<T>* src = in + r0 * Nx;
-  for (int e = threadIdx.x; e < nr * Nx; e += NT) s[(e >> LGNX) * LD + pad(e & (Nx - 1))] = src[e];
-  __syncthreads();
+  TwStage<T, NT, (Nx >> 1)> twr;
+  twr.issue(twX);
   const T inv = T(1) / T(Nx);
+  const T dl = MODE == 2 ? lx_r[1] * T(-2) * inv * inv : T(0);      // lx_r[1] = lx(kx = Nx/2) = -(Nx/2) dlx
+  {
+    cx<T>* const sa[1] = {s};
+    const cx<T>* const ga[1] = {in + r0 * Nx};
+    rows_load<T, NT, LGNX, 1>(sa, ga, nr);
+  }
+  twr.commit(tw);
+  __syncthreads();
   if (MODE == 0 || MODE == 2) fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
   if (MODE == 2) {
-    // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i); lx_r[1] = lx(kx = Nx/2) = -(Nx/2) dlx
-    const T dl = lx_r[1] * T(-2) * inv * inv;
+    // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i)
     fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw, [dl](cx<T> v, int i) {
       const int kx = brevc<LGNX>(i);
       return mk<T>(-(dl * T(kx < (Nx >> 1) ? kx : kx - Nx)) * v.y, (dl * T(kx < (Nx >> 1) ? kx : kx - Nx)) * v.x);

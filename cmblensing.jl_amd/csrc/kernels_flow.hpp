@@ -15,7 +15,17 @@
 #pragma once
 #include "kernels_fft.hpp"
 
+#ifndef CMBL_DPHI_SPLIT
+#define CMBL_DPHI_SPLIT 2
+#endif
 namespace cmbl {
+#ifdef CMBL_STAMPS
+__device__ unsigned long long g_stamps[8192 * 16];
+#define CMBL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = clock64(); } while (0)
+#else
+#define CMBL_STAMP(i) do {} while (0)
+#endif
+
 
 template <typename T> __device__ __forceinline__ T pinv_s(T v) { T r = T(1) / v; return isfinite(r) ? r : T(0); }
 
@@ -33,7 +43,8 @@ __device__ __forceinline__ void flow_pm(T t, T gx, T gy, T hxx, T hyx, T hyy, T&
 // tile is small enough (R <= 4 single precision) that the cap costs at most a handful of spilled registers.
 template <typename T> constexpr int col_min_waves(int R, int NT) { return (sizeof(T) == 4 && R <= 4 && NT >= 256) ? 4 : 1; }
 
-template <typename T> struct PhiMaps { const T *gx, *gy, *hxx, *hyx, *hyy; int Bphi; };
+// pcx/pcy: p(t) of the current stage time from the per-phi cache (k_pcache), or nullptr -> formed from the five maps
+template <typename T> struct PhiMaps { const T *gx, *gy, *hxx, *hyx, *hyy; int Bphi; const T *pcx, *pcy; };
 
 template <typename T> struct RKCoef { T t, cnext, h6; int stage, last; };   // stage 1..4
 
@@ -57,6 +68,29 @@ __device__ __forceinline__ void load_p_pair(const PhiMaps<T>& ph, size_t gi, T t
   const cx<T> hyy = reinterpret_cast<const cx<T>*>(ph.hyy)[gi];
   flow_pm(t, gx.x, gy.x, hxx.x, hyx.x, hyy.x, px.x, py.x, m11.x, m12.x, m22.x);
   flow_pm(t, gx.y, gy.y, hxx.y, hyx.y, hyy.y, px.y, py.y, m11.y, m12.y, m22.y);
+}
+// p(t) only (forward / adjoint / delta-f parts): two cached maps instead of five -- the phi maps are the larger part of what a
+// column workgroup requests before its first transform
+template <typename T>
+__device__ __forceinline__ void load_p_only(const PhiMaps<T>& ph, size_t gi, T t, cx<T>& px, cx<T>& py) {
+  if (ph.pcx) {
+    px = reinterpret_cast<const cx<T>*>(ph.pcx)[gi]; py = reinterpret_cast<const cx<T>*>(ph.pcy)[gi];
+  } else {
+    cx<T> m11, m12, m22;
+    load_p_pair(ph, gi, t, px, py, m11, m12, m22);
+  }
+}
+// p(t_k), k = 0..n2 (t_k = k/n2, the 2n+1 RK stage times; src/lenseflow.jl:131-142) for every pixel: out[k][2][ntot]
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_pcache(PhiMaps<T> ph, T* __restrict__ out, long ntot, int n2) {
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < ntot; i += (long)gridDim.x * NTP) {
+    const T gx = ph.gx[i], gy = ph.gy[i], hxx = ph.hxx[i], hyx = ph.hyx[i], hyy = ph.hyy[i];
+    for (int k = 0; k <= n2; ++k) {
+      T px, py, m11, m12, m22;
+      flow_pm((T)k / (T)n2, gx, gy, hxx, hyx, hyy, px, py, m11, m12, m22);
+      out[(size_t)(2 * k) * ntot + i] = px; out[(size_t)(2 * k + 1) * ntot + i] = py;
+    }
+  }
 }
 // tile of N-point complex columns after a pair DIT: slots pad(2jj), pad(2jj)+1 hold (x,y)[2jj], (x,y)[2jj+1]
 template <typename T>
@@ -97,11 +131,11 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
   const size_t moff = sl * (size_t)Nyh * Nx;
-  load_twiddles<T, NT>(tw, a.twY, M);
-  const T* ly = a.ly;
-  pair_load_mixed<T, NT, LD, LGN, LGC>(s, a.Gx + moff, a.A + moff, Nx, x0, [](cx<T> v, int) { return v; },
-                                       [ly](cx<T> v, int kk) { return mul_il(v, ly[kk]); });
-  // everything else this workgroup needs from HBM is requested before the transform starts
+  // everything this workgroup needs from HBM is requested before anything is waited for
+  TwStage<T, NT, M> twr;
+  PairStage<T, NT, LGN, LGC> ps;
+  twr.issue(a.twY);
+  ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, x0);
   const size_t pbase = ((size_t)bphi * Nx + x0) * M, mbase = (sl * Nx + x0) * (size_t)M;
   cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
   cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
@@ -109,13 +143,14 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int e = threadIdx.x + i * NT;
-    cx<T> m11, m12, m22;
-    load_p_pair(a.ph, pbase + e, a.rk.t, px[i], py[i], m11, m12, m22);
+    load_p_only(a.ph, pbase + e, a.rk.t, px[i], py[i]);
     y0[i] = y0p[e];
     acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
   }
+  twr.commit(tw);
+  ps.template commit<LD>(s);
   __syncthreads();
-  fft_dit<T, NT, LD, LGN, LGN>(s, C, tw);
+  fft_dit<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
   cx<T> fn[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
@@ -134,9 +169,9 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
     s[c * LD + pad(jj)] = fn[i];
   }
   __syncthreads();
-  fft_dif<T, NT, LD, LGM, LGN>(s, C, tw);
+  fft_dif<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
   r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0, [](cx<T> v, int) { return v; });
+  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -162,18 +197,22 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
   const size_t moff = sl * (size_t)Nyh * Nx;
-  load_twiddles<T, NT>(tw, a.twY, M);
-  tile_load_mixed<T, NT, LD, LGM, LGC>(s, a.H + moff, Nx, x0, [](cx<T> v, int) { return v; });
+  TwStage<T, NT, M> twr;
+  TileStage<T, NT, LGM, LGC> tl;
+  twr.issue(a.twY);
+  tl.issue(a.H + moff, Nx, x0);
   const size_t pbase = ((size_t)bphi * Nx + x0) * M;
   cx<T> px[R], py[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    cx<T> m11, m12, m22;
-    load_p_pair(a.ph, pbase + threadIdx.x + i * NT, a.t, px[i], py[i], m11, m12, m22);
-  }
+  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + threadIdx.x + i * NT, a.t, px[i], py[i]);
+  T lyr[G::RZ];                                               // ly of this thread's half-spectrum entries (used after the last transform)
+#pragma unroll
+  for (int i = 0; i < G::RZ; ++i) { const int e = threadIdx.x + i * NT; if (e < C * (M + 1)) lyr[i] = a.ly[e >> LGC]; }
+  twr.commit(tw);
+  tl.template commit<LD>(s);
   __syncthreads();
   c2r_pre<T, NT, LD, LGM>(s, C, tw);
-  fft_dit<T, NT, LD, LGM, LGN>(s, C, tw);
+  fft_dit<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
   cx<T> yv[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
@@ -187,12 +226,11 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
     write_pair(s + c * LD, jj, pmul(px[i], yv[i]), pmul(py[i], yv[i]));
   }
   __syncthreads();
-  fft_dif<T, NT, LD, LGN, LGN>(s, C, tw);
-  const T* ly = a.ly;
+  fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
   cx<T>* Wx = a.Wx + moff; cx<T>* Wy = a.Wy + moff;
-  pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [=](int, int k, int c, cx<T> A, cx<T> B) {
+  pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
     const size_t gi = (size_t)k * Nx + x0 + c;
-    Wx[gi] = A; Wy[gi] = mul_il(B, ly[k]);
+    Wx[gi] = A; Wy[gi] = mul_il(B, lyr[i]);
   });
 }
 
@@ -207,37 +245,65 @@ template <typename T> struct AdjXArgs {
 
 template <typename T, int NT, int LGNX>
 __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* smem, long blk) {
-  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
+  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx), PF = Nx >= NT ? Nx / NT : 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
   const long r0 = blk * a.RX;
   const int nr = (int)min((long)a.RX, a.rows - r0);
   cx<T>* s2 = s + (size_t)a.RX * LD;
-  load_twiddles<T, NT>(tw, a.twX, Nx >> 1);
-  const int n = nr * Nx;
-  for (int e = threadIdx.x; e < n; e += NT) {
-    const int si = (e >> LGNX) * LD + pad(e & (Nx - 1));
-    s[si] = a.Wx[r0 * Nx + e]; s2[si] = a.Wy[r0 * Nx + e];
+  TwStage<T, NT, (Nx >> 1)> twr;
+  twr.issue(a.twX);
+  T lxr[PF];                                                  // lx of this thread's columns (Nx >= NT: the same for every row)
+  if constexpr (Nx >= NT) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) lxr[i] = a.lx_r[threadIdx.x + i * NT];
   }
+  {
+    cx<T>* const sa[2] = {s, s2};
+    const cx<T>* const ga[2] = {a.Wx + r0 * Nx, a.Wy + r0 * Nx};
+    rows_load<T, NT, LGNX, 2>(sa, ga, nr);
+  }
+  twr.commit(tw);
   __syncthreads();
   // both row sets in one go: they are adjacent in LDS when nr == RX; otherwise two calls
   if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, 2 * nr, tw);
   else { fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s2, nr, tw); }
   const T inv = T(1) / T(Nx);
-  for (int e = threadIdx.x; e < n; e += NT) {
-    const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
-    const cx<T> kv = mul_il(s[si], a.lx_r[i]) + s2[si];
-    const long gi = r0 * Nx + e;
-    cx<T> y0 = a.Y0[gi];
-    cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
-    cx<T> fn = rk_update(a.rk, kv, y0, acc);
-    if (a.rk.stage == 4) a.Y0[gi] = y0; else a.acc[gi] = acc;
-    s[si] = inv * fn;
+  if constexpr (Nx >= NT) {
+    for (int r = 0; r < nr; ++r) {                            // per row: RK state loads first, then the stores (they may alias for the compiler)
+      const long g0 = (r0 + r) * Nx;
+      cx<T> y0[PF], acc[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const long gi = g0 + threadIdx.x + i * NT;
+        y0[i] = a.Y0[gi];
+        acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
+      }
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int e = threadIdx.x + i * NT, si = r * LD + pad(e);
+        const cx<T> kv = mul_il(s[si], lxr[i]) + s2[si];
+        const cx<T> fn = rk_update(a.rk, kv, y0[i], acc[i]);
+        if (a.rk.stage == 4) a.Y0[g0 + e] = y0[i]; else a.acc[g0 + e] = acc[i];
+        s[si] = inv * fn;
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < nr * Nx; e += NT) {
+      const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
+      const cx<T> kv = mul_il(s[si], a.lx_r[i]) + s2[si];
+      const long gi = r0 * Nx + e;
+      cx<T> y0 = a.Y0[gi];
+      cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
+      cx<T> fn = rk_update(a.rk, kv, y0, acc);
+      if (a.rk.stage == 4) a.Y0[gi] = y0; else a.acc[gi] = acc;
+      s[si] = inv * fn;
+    }
   }
   if (a.rk.last) return;
   __syncthreads();
   fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
-  for (int e = threadIdx.x; e < n; e += NT) a.Hnext[r0 * Nx + e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
+  for (int e = threadIdx.x; e < nr * Nx; e += NT) a.Hnext[r0 * Nx + e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
 }
 
 template <typename T, int NT, int LGNX>
@@ -255,9 +321,14 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
   cx<T>* s = tw + (Nx >> 1);
   const long r0 = blk * g.RX;
   const int nr = (int)min((long)g.RX, g.rows - r0);
-  load_twiddles<T, NT>(tw, g.twX, Nx >> 1);
-  const cx<T>* src = g.in + r0 * Nx;
-  for (int e = threadIdx.x; e < nr * Nx; e += NT) s[(e >> LGNX) * LD + pad(e & (Nx - 1))] = src[e];
+  TwStage<T, NT, (Nx >> 1)> twr;
+  twr.issue(g.twX);
+  {
+    cx<T>* const sa[1] = {s};
+    const cx<T>* const ga[1] = {g.in + r0 * Nx};
+    rows_load<T, NT, LGNX, 1>(sa, ga, nr);
+  }
+  twr.commit(tw);
   __syncthreads();
   fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
   // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
@@ -268,16 +339,6 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
   });
   cx<T>* dst = g.out + r0 * Nx;
   for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
-}
-
-// One launch for the two independent row passes that follow a delta-flow column kernel: the delta-f pass of this stage
-// (blocks [0, nblk_adj)) and the d/dx pass of the NEXT stage's f (blocks [nblk_adj, ...)).  Saves a dependent launch per stage
-// and fills the tail of one pass with the other.
-template <typename T, int NT, int LGNX>
-__global__ __launch_bounds__(NT) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if ((int)blockIdx.x < nblk_adj) adj_x_body<T, NT, LGNX>(a, smem, blockIdx.x);
-  else grad_x_body<T, NT, LGNX>(g, smem, (long)blockIdx.x - nblk_adj);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -291,33 +352,35 @@ template <typename T> struct DeltaYArgs {
 };
 
 template <typename T, int R, int NT, int LGM>
-__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_y(DeltaYArgs<T> d) {
+__device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned char* smem, size_t sl) {
   using G = ColTile<R, NT, LGM>;
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const FlowYArgs<T>& a = d.f;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + M;
   const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
-  const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
   const size_t moff = sl * (size_t)Nyh * Nx;
   const size_t pbase = ((size_t)bphi * Nx + x0) * M, mbase = (sl * Nx + x0) * (size_t)M;
-  load_twiddles<T, NT>(tw, a.twY, M);
-  const T* ly = a.ly;
-
-  // (d/dx f, d/dy f) from one N-point inverse transform
-  pair_load_mixed<T, NT, LD, LGN, LGC>(s, a.Gx + moff, a.A + moff, Nx, x0, [](cx<T> v, int) { return v; },
-                                       [ly](cx<T> v, int kk) { return mul_il(v, ly[kk]); });
+  CMBL_STAMP(0);
+  // requested up front: twiddles, the (Gx, A) pair tile, p(t), the delta-f tile -- one wait instead of one per loop iteration
+  TwStage<T, NT, M> twr;
+  PairStage<T, NT, LGN, LGC> ps;
+  TileStage<T, NT, LGM, LGC> th;
+  twr.issue(a.twY);
+  ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, x0);
   cx<T> px[R], py[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    cx<T> m11, m12, m22;
-    load_p_pair(a.ph, pbase + threadIdx.x + i * NT, a.rk.t, px[i], py[i], m11, m12, m22);
-  }
+  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + threadIdx.x + i * NT, a.rk.t, px[i], py[i]);
+  th.issue(d.H + moff, Nx, x0);
+  twr.commit(tw);
+  ps.template commit<LD>(s);
   __syncthreads();
-  fft_dit<T, NT, LD, LGN, LGN>(s, C, tw);
+  CMBL_STAMP(1);
+  // (d/dx f, d/dy f) from one N-point inverse transform
+  fft_dit<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
+  CMBL_STAMP(2);
   cx<T> dx[R], dy[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
@@ -325,27 +388,36 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_y(DeltaYA
     read_pair(s + c * LD, jj, invNy, dx[i], dy[i]);
   }
   __syncthreads();
+  CMBL_STAMP(3);
   // L(delta f) = irfft2(delta f)
-  tile_load_mixed<T, NT, LD, LGM, LGC>(s, d.H + moff, Nx, x0, [](cx<T> v, int) { return v; });
+  th.template commit<LD>(s);
   __syncthreads();
+  CMBL_STAMP(4);
   c2r_pre<T, NT, LD, LGM>(s, C, tw);
-  fft_dit<T, NT, LD, LGM, LGN>(s, C, tw);
+  fft_dit<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
+  CMBL_STAMP(5);
   cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
   cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
   cx<T> fn[R], ldf[R];
 #pragma unroll
+  for (int i = 0; i < R; ++i) {                               // RK state: all loads before any of the stores below
+    const int e = threadIdx.x + i * NT;
+    fn[i] = y0p[e];
+    ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
+  }
+#pragma unroll
   for (int i = 0; i < R; ++i) {
     const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    cx<T> y0 = fn[i], acc = ldf[i];
     ldf[i] = invNy * s[c * LD + pad(jj)];
     reinterpret_cast<cx<T>*>(d.w1p)[mbase + e] = pmul(ldf[i], dx[i]);
     reinterpret_cast<cx<T>*>(d.w2p)[mbase + e] = pmul(ldf[i], dy[i]);
     const cx<T> kv = pmul(px[i], dx[i]) + pmul(py[i], dy[i]);
-    cx<T> y0 = y0p[e];
-    cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
     fn[i] = rk_update(a.rk, kv, y0, acc);
     if (a.rk.stage == 4) y0p[e] = y0; else accp[e] = acc;
   }
   __syncthreads();
+  CMBL_STAMP(6);
   // (Wx, Wy') from one N-point forward transform of px*Ldf + i*py*Ldf
 #pragma unroll
   for (int i = 0; i < R; ++i) {
@@ -353,23 +425,29 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_y(DeltaYA
     write_pair(s + c * LD, jj, pmul(px[i], ldf[i]), pmul(py[i], ldf[i]));
   }
   __syncthreads();
-  fft_dif<T, NT, LD, LGN, LGN>(s, C, tw);
+  CMBL_STAMP(7);
+  fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
+  CMBL_STAMP(8);
   {
     cx<T>* Wx = d.Wx + moff; cx<T>* Wy = d.Wy + moff;
-    pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [=](int, int k, int c, cx<T> A, cx<T> B) {
+    pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
       const size_t gi = (size_t)k * Nx + x0 + c;
-      Wx[gi] = A; Wy[gi] = mul_il(B, ly[k]);
+      Wx[gi] = A; Wy[gi] = mul_il(B, ps.l[i]);                // ly[k] is still in registers from the pair load (same entry mapping)
     });
   }
+  CMBL_STAMP(9);
   if (a.rk.last) return;
   __syncthreads();
   // next-stage f : rfft_y
 #pragma unroll
   for (int i = 0; i < R; ++i) { const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1); s[c * LD + pad(jj)] = fn[i]; }
   __syncthreads();
-  fft_dif<T, NT, LD, LGM, LGN>(s, C, tw);
+  CMBL_STAMP(10);
+  fft_dif<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
   r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0, [](cx<T> v, int) { return v; });
+  CMBL_STAMP(11);
+  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0);
+  CMBL_STAMP(12);
 }
 
 // delta-phi part, column kernel (one per batch slot): w = sum_pol partials; u = M^-1 w (quirk Q1 optional);
@@ -387,29 +465,34 @@ template <typename T> struct DphiYArgs {
 };
 
 template <typename T, int R, int NT, int LGM>
-__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_dphi_y(DphiYArgs<T> a) {
+__device__ __forceinline__ void dphi_y_body(const DphiYArgs<T>& a, unsigned char* smem, size_t b, int tile, int ntiles) {
   using G = ColTile<R, NT, LGM>;
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   constexpr int RZ = G::RZ;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + M;
-  const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
-  const size_t b = blockIdx.y;
+  const int Nx = a.Nx, x0 = xcd_tile(tile, ntiles) * C;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)b;
-  load_twiddles<T, NT>(tw, a.twY, M);
+  TwStage<T, NT, M> twr;
+  twr.issue(a.twY);
   const size_t pbase = ((size_t)bphi * Nx + x0) * M;
   cx<T> u1[R], u2[R], pxr[R], pyr[R];
+  T lyr[RZ];
+#pragma unroll
+  for (int i = 0; i < RZ; ++i) { const int e = threadIdx.x + i * NT; if (e < C * (M + 1)) lyr[i] = a.ly[e >> LGC]; }
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int e = threadIdx.x + i * NT;
     cx<T> m11, m12, m22;
     load_p_pair(a.ph, pbase + e, a.t, pxr[i], pyr[i], m11, m12, m22);
     cx<T> w1 = mk<T>(0, 0), w2 = mk<T>(0, 0);
-    for (int p = 0; p < a.P; ++p) {                       // spin-adjoint product: sum over pol (src/proj_lambert.jl:423-430)
-      const size_t mi = (((size_t)b * a.P + p) * Nx + x0) * M + e;
-      w1 = w1 + reinterpret_cast<const cx<T>*>(a.w1p)[mi];
-      w2 = w2 + reinterpret_cast<const cx<T>*>(a.w2p)[mi];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {                         // spin-adjoint product: sum over pol (src/proj_lambert.jl:423-430); P <= 3,
+      if (p < a.P) {                                      // unrolled so that the loads of all pols are in flight together
+        const size_t mi = (((size_t)b * a.P + p) * Nx + x0) * M + e;
+        w1 = w1 + reinterpret_cast<const cx<T>*>(a.w1p)[mi];
+        w2 = w2 + reinterpret_cast<const cx<T>*>(a.w2p)[mi];
+      }
     }
     // u = M^-1 w   (src/field_vectors.jl:48-49; with the reference's aliasing, v[2] sees the updated v[1])
     const cx<T> v1 = pmul(m11, w1) + pmul(m12, w2);
@@ -417,8 +500,9 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_dphi_y(DphiYArg
     u1[i] = v1;
     u2[i] = pmul(m12, in1) + pmul(m22, w2);
   }
-  const T* ly = a.ly; const T t = a.t;
+  const T t = a.t;
   const size_t moff = b * (size_t)Nyh * Nx;
+  twr.commit(tw);
   // pair (u1, u2): keep Y(u1), Y(u2) of this thread's half-spectrum entries in registers
 #pragma unroll
   for (int i = 0; i < R; ++i) {
@@ -426,7 +510,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_dphi_y(DphiYArg
     write_pair(s + c * LD, jj, u1[i], u2[i]);
   }
   __syncthreads();
-  fft_dif<T, NT, LD, LGN, LGN>(s, C, tw);
+  fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
   cx<T> yu1[RZ], yu2[RZ];
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int, int, cx<T> A, cx<T> B) { yu1[i] = A; yu2[i] = B; });
   __syncthreads();
@@ -437,11 +521,11 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_dphi_y(DphiYArg
     write_pair(s + c * LD, jj, t * (pmul(pyr[i], u1[i]) + pmul(pxr[i], u2[i])), t * pmul(pyr[i], u2[i]));
   }
   __syncthreads();
-  fft_dif<T, NT, LD, LGN, LGN>(s, C, tw);
+  fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
   {
     cx<T>* Z0 = a.Z0 + moff; cx<T>* Z1 = a.Z1 + moff;
     pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> Yb, cx<T> Yc) {
-      const T l = ly[k];
+      const T l = lyr[i];
       const size_t gi = (size_t)k * Nx + x0 + c;
       Z1[gi] = yu1[i] + mul_il(Yb, l);
       Z0[gi] = mul_il(yu2[i], l) - (l * l) * Yc;
@@ -455,9 +539,9 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_dphi_y(DphiYArg
     s[c * LD + pad(jj)] = t * pmul(pxr[i], u1[i]);
   }
   __syncthreads();
-  fft_dif<T, NT, LD, LGM, LGN>(s, C, tw);
+  fft_dif<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
   r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Z2 + moff, Nx, x0, [](cx<T> v, int) { return v; });
+  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Z2 + moff, Nx, x0);
 }
 
 // delta-phi part, row kernel: k = fft_x(Z0) + i*lx*fft_x(Z1) - lx^2*fft_x(Z2) ; RK update of the S0 Fourier state
@@ -469,33 +553,89 @@ template <typename T> struct DphiXArgs {
 };
 
 template <typename T, int NT, int LGNX>
-__global__ __launch_bounds__(NT) void k_dphi_x(DphiXArgs<T> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void dphi_x_body(const DphiXArgs<T>& a, unsigned char* smem, long blk) {
   constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
-  const long r0 = (long)blockIdx.x * a.RX;
+  const long r0 = blk * a.RX;
   const int nr = (int)min((long)a.RX, a.rows - r0);
   const size_t st = (size_t)a.RX * LD;
-  load_twiddles<T, NT>(tw, a.twX, Nx >> 1);
-  const int n = nr * Nx;
-  for (int e = threadIdx.x; e < n; e += NT) {
-    const int si = (e >> LGNX) * LD + pad(e & (Nx - 1));
-    s[si] = a.Z0[r0 * Nx + e]; s[st + si] = a.Z1[r0 * Nx + e]; s[2 * st + si] = a.Z2[r0 * Nx + e];
+  constexpr int PF = Nx >= NT ? Nx / NT : 1;
+  TwStage<T, NT, (Nx >> 1)> twr;
+  twr.issue(a.twX);
+  T lxr[PF];
+  if constexpr (Nx >= NT) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) lxr[i] = a.lx_r[threadIdx.x + i * NT];
   }
+  {
+    cx<T>* const sa[3] = {s, s + st, s + 2 * st};
+    const cx<T>* const ga[3] = {a.Z0 + r0 * Nx, a.Z1 + r0 * Nx, a.Z2 + r0 * Nx};
+    rows_load<T, NT, LGNX, 3>(sa, ga, nr);
+  }
+  twr.commit(tw);
+  const int n = nr * Nx;
   __syncthreads();
   if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX, 4>(s, 3 * nr, tw);
   else { fft_dif<T, NT, LD, LGNX, LGNX, 4>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, 4>(s + st, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, 4>(s + 2 * st, nr, tw); }
-  for (int e = threadIdx.x; e < n; e += NT) {
-    const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
-    const T l = a.lx_r[i];
-    const cx<T> kv = s[si] + mul_il(s[st + si], l) - (l * l) * s[2 * st + si];
-    const long gi = r0 * Nx + e;
-    cx<T> y0 = a.Y0[gi];
-    cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
-    (void)rk_update(a.rk, kv, y0, acc);
-    if (a.rk.stage == 4) a.Y0[gi] = y0; else a.acc[gi] = acc;
+  if constexpr (Nx >= NT) {
+    for (int r = 0; r < nr; ++r) {
+      const long g0 = (r0 + r) * Nx;
+      cx<T> y0[PF], acc[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const long gi = g0 + threadIdx.x + i * NT;
+        y0[i] = a.Y0[gi];
+        acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
+      }
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int e = threadIdx.x + i * NT, si = r * LD + pad(e);
+        const T l = lxr[i];
+        const cx<T> kv = s[si] + mul_il(s[st + si], l) - (l * l) * s[2 * st + si];
+        (void)rk_update(a.rk, kv, y0[i], acc[i]);
+        if (a.rk.stage == 4) a.Y0[g0 + e] = y0[i]; else a.acc[g0 + e] = acc[i];
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < n; e += NT) {
+      const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
+      const T l = a.lx_r[i];
+      const cx<T> kv = s[si] + mul_il(s[st + si], l) - (l * l) * s[2 * st + si];
+      const long gi = r0 * Nx + e;
+      cx<T> y0 = a.Y0[gi];
+      cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
+      (void)rk_update(a.rk, kv, y0, acc);
+      if (a.rk.stage == 4) a.Y0[gi] = y0; else a.acc[gi] = acc;
+    }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The delta flow is two launches per RK stage on ONE stream.  The delta-phi branch never feeds back into the (f, delta f)
+// chain, so its kernels for stage s-1 ride along as extra workgroups of the stage-s launches: they fill the CUs while the chain's
+// workgroups sit in barriers / HBM waits, and no event or second stream is needed (cross-stream events cost ~7 us of idle
+// queue per use on this GPU: kernel trace, profiles/).
+//   column launch:  [0, slices) delta_y_body of stage s   |  [slices, slices + B) dphi_y_body of stage s-1
+//   row launch:     adj_x_body (stage s)  |  grad_x_body (d/dx of the next stage's f)  |  dphi_x_body (stage s-1)
+template <typename T, int R, int NT, int LGM>
+__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_cols(DeltaYArgs<T> d, DphiYArgs<T> p, int slices) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the delta-phi workgroups take tiles of C/CMBL_DPHI_SPLIT columns: more, shorter workgroups fill the slots the chain frees
+  constexpr int F = (R >= CMBL_DPHI_SPLIT) ? CMBL_DPHI_SPLIT : 1;
+  if ((int)blockIdx.y < slices) delta_y_body<T, R, NT, LGM>(d, smem, blockIdx.y);
+  else {
+    const int yy = (int)blockIdx.y - slices;
+    dphi_y_body<T, R / F, NT, LGM>(p, smem, yy / F, (yy % F) * (int)gridDim.x + (int)blockIdx.x, F * (int)gridDim.x);
+  }
+}
+template <typename T, int NT, int LGNX>
+__global__ __launch_bounds__(NT) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, DphiXArgs<T> p, int nblk_adj, int nblk_grad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  if (b < nblk_adj) adj_x_body<T, NT, LGNX>(a, smem, b);
+  else if (b < nblk_adj + nblk_grad) grad_x_body<T, NT, LGNX>(g, smem, (long)b - nblk_adj);
+  else dphi_x_body<T, NT, LGNX>(p, smem, (long)b - nblk_adj - nblk_grad);
 }
 
 // gradient / hessian multipliers for precompute (src/specialops.jl:184-188): F layout in, five F-layout outputs

@@ -19,7 +19,16 @@ r = [timeit(lambda: L * fm), timeit(lambda: L.adjoint * gl), timeit(lambda: L.gr
 r2 = [timeit(lambda: L.gradient(C.FLOW_FWD, ft, gl)), timeit(lambda: ds.gradient_logpdf_mixed(fo, po))]
 print("L*f %.3f  L'g %.3f  gradL %.3f/%.3f  gradlnP %.3f/%.3f ms" % (r[0], r[1], r[2], r2[0], r[3], r2[1]))
 '''
-for lib in sys.argv[1:]:
-    env = dict(os.environ, CMBL_LIB=os.path.abspath(lib))
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-    print(os.path.basename(lib), (out.stdout.strip().splitlines() or [out.stderr[-400:]])[-1], flush=True)
+import re
+rounds = int(os.environ.get("ROUNDS", "3"))
+best = {}
+for r in range(rounds):                      # interleave the variants: clocks drift by a few percent between processes
+    for lib in sys.argv[1:]:
+        env = dict(os.environ, CMBL_LIB=os.path.abspath(lib))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        line = (out.stdout.strip().splitlines() or [out.stderr[-400:]])[-1]
+        nums = [float(x) for x in re.findall(r"[0-9]+\.[0-9]+", line)]
+        best[lib] = nums if lib not in best else [min(a, b) for a, b in zip(best[lib], nums)]
+        print(r, os.path.basename(lib), line, flush=True)
+for lib, n in best.items():
+    print("MIN", os.path.basename(lib), "L*f %.3f  L'g %.3f  gradL %.3f/%.3f  gradlnP %.3f/%.3f" % tuple(n), flush=True)

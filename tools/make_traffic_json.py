@@ -13,7 +13,7 @@ import re
 import sys
 
 CLASSES = {"k_flow_y_fwd": "flow_y_fwd", "k_x_fft<float, 2": "x_grad", "k_x_fft<double, 2": "x_grad", "k_adj_y": "adj_y",
-           "k_adj_x": "adj_x", "k_delta_rows": "delta_rows", "k_delta_y": "delta_y", "k_dphi_y": "dphi_y", "k_dphi_x": "dphi_x"}
+           "k_adj_x": "adj_x", "k_delta_rows": "delta_rows", "k_delta_cols": "delta_cols"}
 
 
 def mean_per_kernel(path, counter):
