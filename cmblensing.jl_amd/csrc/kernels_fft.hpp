@@ -21,7 +21,14 @@
 #define CMBL_YLGM 4     // column kernels, N/2-point (packed real) transforms
 #endif
 
+#ifndef CMBL_ROW_WAVES
+#define CMBL_ROW_WAVES 1
+#endif
+
 namespace cmbl {
+
+// register budget of the row kernels (waves per SIMD the compiler must leave room for; fp32 only)
+template <typename T> constexpr int row_min_waves() { return sizeof(T) == 4 ? CMBL_ROW_WAVES : 1; }
 
 // Column tiles that are neighbours in x share 64/128-byte lines of the [ky][x] arrays.  Workgroup b is observed to run
 // on XCD b % 8 (speed only, never correctness), so give every XCD a contiguous range of tiles: its private L2 then sees
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
 //   MODE 1: inverse  (F -> mixed), scaled by 1/Nx
 //   MODE 2: x-derivative  (mixed -> mixed):  ifft_x( i*lx * fft_x(row) ) / Nx        (src/proj_lambert.jl:146-159, coord 1)
 template <typename T, int MODE, int NT, int LGNX>
-__global__ __launch_bounds__(NT) void k_x_fft(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
+__global__ __launch_bounds__(NT, row_min_waves<T>()) void k_x_fft(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
                                               const cx<T>* __restrict__ twX, const T* __restrict__ lx_r, long rows, int RX) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);

@@ -307,7 +307,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
 }
 
 template <typename T, int NT, int LGNX>
-__global__ __launch_bounds__(NT) void k_adj_x(AdjXArgs<T> a) {
+__global__ __launch_bounds__(NT, row_min_waves<T>()) void k_adj_x(AdjXArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   adj_x_body<T, NT, LGNX>(a, smem, blockIdx.x);
 }
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_cols(Delt
   }
 }
 template <typename T, int NT, int LGNX>
-__global__ __launch_bounds__(NT) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, DphiXArgs<T> p, int nblk_adj, int nblk_grad) {
+__global__ __launch_bounds__(NT, row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, DphiXArgs<T> p, int nblk_adj, int nblk_grad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   if (b < nblk_adj) adj_x_body<T, NT, LGNX>(a, smem, b);
