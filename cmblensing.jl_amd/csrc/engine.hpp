@@ -201,6 +201,15 @@ struct Ctx : CtxBase {
     return RX;
   }
   size_t ldsX(int RX, int nbuf) const { return ((size_t)Nx / 2 + (size_t)nbuf * RX * tile_ld(Nx)) * sizeof(cx<T>); }
+  // Row launches: rows are dealt evenly to nblk workgroups (row_range in the kernels), at most `cap` rows each.
+  // (Trimming the grid to a whole number of resident-workgroup rounds -- 1026 rows on 1024 slots -- was measured: no gain, the
+  // workgroups that take the stragglers' rows simply become the new tail.)
+  struct RowPlan { int nblk, cap; };
+  RowPlan plan_rows(int nbuf, long rows) const {
+    const int RX0 = pickRX(nbuf, rows);
+    const long nblk = (rows + RX0 - 1) / RX0;
+    return RowPlan{(int)nblk, (int)((rows + nblk - 1) / nblk)};
+  }
 
   template <typename Fn> void dispatch_col(const TileY& t, Fn&& fn) const {
     bool done = false;
@@ -248,11 +257,11 @@ struct Ctx : CtxBase {
   template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices, hipStream_t st = nullptr) {
     if (!st) st = stream;
     const long rows = slices * Nyh;
-    const int RX = pickRX(1, rows);
-    dispatch_row(pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
+    dispatch_row(pickXNT(rows, 1), [&](auto lgnx, auto xnt) {
       constexpr int LGNX = decltype(lgnx)::value, XNT = decltype(xnt)::value;
-      CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), XNT, (k_x_fft<T, MODE, XNT, LGNX>), dim3((unsigned)((rows + RX - 1) / RX)), ldsX(RX, 1), st, in, out,
-                     twX.as<cx<T>>(), lx_r.as<T>(), rows, RX);
+      const RowPlan rp = plan_rows(1, rows);
+      CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), XNT, (k_x_fft<T, MODE, XNT, LGNX>), dim3((unsigned)rp.nblk), ldsX(rp.cap, 1), st, in, out,
+                     twX.as<cx<T>>(), lx_r.as<T>(), rows, rp.nblk);
     });
   }
   // map -> F  (m_rfft, src/util_fft.jl:20)
@@ -503,7 +512,6 @@ struct Flow {
     c->template x_pass<1>(out, H.as<cx<T>>(), slices);
     const auto tile = c->tileY(slices, true);
     const long rows = slices * c->Nyh;
-    const int RX = c->pickRX(2, rows);
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
@@ -518,10 +526,12 @@ struct Flow {
         });
         AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = out; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
-        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.rows = rows; x.rk = rk;
-        c->dispatch_row(c->pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
+        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.rows = rows; x.rk = rk;
+        c->dispatch_row(c->pickXNT(rows, 1), [&](auto lgnx, auto xnt) {
           constexpr int XNT = decltype(xnt)::value;
-          CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)((rows + RX - 1) / RX)), c->ldsX(RX, 2), c->stream, x);
+          const auto rp = c->plan_rows(2, rows);
+          x.RX = rp.cap; x.nblk = rp.nblk;
+          CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)rp.nblk), c->ldsX(rp.cap, 2), c->stream, x);
         });
       }
   }
@@ -588,8 +598,8 @@ struct Flow {
 
         // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_cur already points at A_{s+1}) + delta-phi rows of stage it-1
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
-        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.rows = rows; x.rk = rk;
-        gx = GradXArgs<T>{a_cur, Gx.as<cx<T>>(), x.twX, c->dlx_over_Nx, rows, RX};
+        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.nblk = nb_adj; x.rows = rows; x.rk = rk;
+        gx = GradXArgs<T>{a_cur, Gx.as<cx<T>>(), x.twX, c->dlx_over_Nx, rows, nb_adj};
         launch_rows(nb_adj, last ? 0 : nb_adj, it > 0 ? nb_dphi : 0);        // px still describes stage it-1
 
         // delta-phi work of THIS stage, launched with the next stage
@@ -597,7 +607,7 @@ struct Flow {
         py.ph = ph(); py.twY = a.twY; py.ly = a.ly; py.Nx = c->Nx; py.P = P;
         py.alias_quirk = alias_quirk ? 1 : 0; py.t = rk.t;
         px.Z0 = Z0.as<cx<T>>(); px.Z1 = Z1.as<cx<T>>(); px.Z2 = Z2.as<cx<T>>(); px.Y0 = dphi; px.acc = Pacc.as<cx<T>>();
-        px.twX = x.twX; px.lx_r = x.lx_r; px.RX = RX; px.rows = rowsp; px.rk = rk;
+        px.twX = x.twX; px.lx_r = x.lx_r; px.RX = RX; px.nblk = nb_dphi; px.rows = rowsp; px.rk = rk;
       }
     launch_cols(false, true);                                                // delta-phi of the last stage
     launch_rows(0, 0, nb_dphi);

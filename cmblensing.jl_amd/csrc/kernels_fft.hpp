@@ -172,6 +172,13 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
     }
   }
 };
+// Row kernels: `rows` rows are dealt to `nblk` workgroups as evenly as possible (the first rows % nblk workgroups take one more).
+// LDS row capacity of a workgroup = ceil(rows / nblk).
+__device__ __forceinline__ void row_range(long rows, int nblk, long blk, long& r0, int& nr) {
+  const long base = rows / nblk, extra = rows - base * nblk;
+  r0 = blk * base + (blk < extra ? blk : extra);
+  nr = (int)base + (blk < extra ? 1 : 0);
+}
 // rows of Nx contiguous values -> row tiles (row kernels): the loads of one row are issued together
 template <typename T, int NT, int LGNX, int NA>
 __device__ __forceinline__ void rows_load(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], int nr) {
@@ -271,19 +278,19 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// x pass on contiguous rows.  `rows` = slices*Nyh rows of Nx.  grid ceil(rows/RX).  LDS: twX[Nx/2] + RX*tile_ld(Nx) cplx
+// x pass on contiguous rows.  `rows` = slices*Nyh rows of Nx.  grid nblk.  LDS: twX[Nx/2] + ceil(rows/nblk)*tile_ld(Nx) cplx
 //   MODE 0: forward  (mixed -> F)
 //   MODE 1: inverse  (F -> mixed), scaled by 1/Nx
 //   MODE 2: x-derivative  (mixed -> mixed):  ifft_x( i*lx * fft_x(row) ) / Nx        (src/proj_lambert.jl:146-159, coord 1)
 template <typename T, int MODE, int NT, int LGNX>
 __global__ __launch_bounds__(NT, row_min_waves<T>()) void k_x_fft(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
-                                              const cx<T>* __restrict__ twX, const T* __restrict__ lx_r, long rows, int RX) {
+                                              const cx<T>* __restrict__ twX, const T* __restrict__ lx_r, long rows, int nblk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
-  const long r0 = (long)blockIdx.x * RX;
-  const int nr = (int)min((long)RX, rows - r0);
+  long r0; int nr;
+  row_range(rows, nblk, blockIdx.x, r0, nr);
   TwStage<T, NT, (Nx >> 1)> twr;
   twr.issue(twX);
   const T inv = T(1) / T(Nx);

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
 template <typename T> struct AdjXArgs {
   const cx<T>* Wx; const cx<T>* Wy; cx<T>* Y0; cx<T>* acc; cx<T>* Hnext;
   const cx<T>* twX; const T* lx_r;
-  int RX; long rows;
+  int RX, nblk; long rows;          // RX = LDS row capacity of a workgroup (stride between the row sets); rows dealt to nblk workgroups
   RKCoef<T> rk;
 };
 
@@ -248,9 +248,9 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx), PF = Nx >= NT ? Nx / NT : 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
-  const long r0 = blk * a.RX;
-  const int nr = (int)min((long)a.RX, a.rows - r0);
-  cx<T>* s2 = s + (size_t)a.RX * LD;
+  long r0; int nr;
+  row_range(a.rows, a.nblk, blk, r0, nr);
+  cx<T>* s2 = s + (size_t)nr * LD;                            // the two row sets are adjacent: one transform call covers both
   TwStage<T, NT, (Nx >> 1)> twr;
   twr.issue(a.twX);
   T lxr[PF];                                                  // lx of this thread's columns (Nx >= NT: the same for every row)
@@ -265,9 +265,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   }
   twr.commit(tw);
   __syncthreads();
-  // both row sets in one go: they are adjacent in LDS when nr == RX; otherwise two calls
-  if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, 2 * nr, tw);
-  else { fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s2, nr, tw); }
+  fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, 2 * nr, tw);
   const T inv = T(1) / T(Nx);
   if constexpr (Nx >= NT) {
     for (int r = 0; r < nr; ++r) {                            // per row: RK state loads first, then the stores (they may alias for the compiler)
@@ -313,14 +311,14 @@ __global__ __launch_bounds__(NT, row_min_waves<T>()) void k_adj_x(AdjXArgs<T> a)
 }
 
 // x-derivative row pass as a device function (same as k_x_fft<MODE 2>)
-template <typename T> struct GradXArgs { const cx<T>* in; cx<T>* out; const cx<T>* twX; T dlx_over_Nx; long rows; int RX; };
+template <typename T> struct GradXArgs { const cx<T>* in; cx<T>* out; const cx<T>* twX; T dlx_over_Nx; long rows; int nblk; };
 template <typename T, int NT, int LGNX>
 __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char* smem, long blk) {
   constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
-  const long r0 = blk * g.RX;
-  const int nr = (int)min((long)g.RX, g.rows - r0);
+  long r0; int nr;
+  row_range(g.rows, g.nblk, blk, r0, nr);
   TwStage<T, NT, (Nx >> 1)> twr;
   twr.issue(g.twX);
   {
@@ -548,7 +546,7 @@ __device__ __forceinline__ void dphi_y_body(const DphiYArgs<T>& a, unsigned char
 template <typename T> struct DphiXArgs {
   const cx<T>* Z0; const cx<T>* Z1; const cx<T>* Z2; cx<T>* Y0; cx<T>* acc;
   const cx<T>* twX; const T* lx_r;
-  int RX; long rows;
+  int RX, nblk; long rows;
   RKCoef<T> rk;
 };
 
@@ -557,9 +555,9 @@ __device__ __forceinline__ void dphi_x_body(const DphiXArgs<T>& a, unsigned char
   constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + (Nx >> 1);
-  const long r0 = blk * a.RX;
-  const int nr = (int)min((long)a.RX, a.rows - r0);
-  const size_t st = (size_t)a.RX * LD;
+  long r0; int nr;
+  row_range(a.rows, a.nblk, blk, r0, nr);
+  const size_t st = (size_t)nr * LD;                          // three adjacent row sets
   constexpr int PF = Nx >= NT ? Nx / NT : 1;
   TwStage<T, NT, (Nx >> 1)> twr;
   twr.issue(a.twX);
@@ -576,8 +574,7 @@ __device__ __forceinline__ void dphi_x_body(const DphiXArgs<T>& a, unsigned char
   twr.commit(tw);
   const int n = nr * Nx;
   __syncthreads();
-  if (nr == a.RX) fft_dif<T, NT, LD, LGNX, LGNX, 4>(s, 3 * nr, tw);
-  else { fft_dif<T, NT, LD, LGNX, LGNX, 4>(s, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, 4>(s + st, nr, tw); fft_dif<T, NT, LD, LGNX, LGNX, 4>(s + 2 * st, nr, tw); }
+  fft_dif<T, NT, LD, LGNX, LGNX, 4>(s, 3 * nr, tw);
   if constexpr (Nx >= NT) {
     for (int r = 0; r < nr; ++r) {
       const long g0 = (r0 + r) * Nx;
