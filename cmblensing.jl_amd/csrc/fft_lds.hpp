@@ -27,7 +27,10 @@
 
 namespace cmbl {
 
-__device__ __host__ __forceinline__ constexpr int pad(int i) { return i + (i >> 4); }
+#ifndef CMBL_PAD_SHIFT
+#define CMBL_PAD_SHIFT 4
+#endif
+__device__ __host__ __forceinline__ constexpr int pad(int i) { return i + (i >> CMBL_PAD_SHIFT); }
 // leading dimension (in complex slots) of a tile row holding n elements (+1 spare slot for the packed-real Nyquist term)
 __device__ __host__ __forceinline__ constexpr int tile_ld(int n) { return pad(n) + 1; }
 template <int LG> __device__ __forceinline__ int brevc(int i) { return LG == 0 ? 0 : (int)(__brev((unsigned)i) >> (32 - (LG == 0 ? 1 : LG))); }
