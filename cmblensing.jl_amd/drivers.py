@@ -359,11 +359,14 @@ def sample_f(ds, phi, white_f, white_n, fstart=None, tol=1e-1, nsteps=500):
     return fs + df, hist
 
 
-def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always_accept=False):
-    """One `sample_joint` step at fixed θ (src/sampling.jl:187-193, 388-464)."""
+def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always_accept=False, theta_pass=None):
+    """One `sample_joint` step (src/sampling.jl:187-193, 388-464): f | ϕ,θ -> mix -> HMC ϕ° | f°,θ -> [θ | f°,ϕ°] -> unmix -> logpdf.
+    `theta_pass(fo, po)` runs the Gibbs θ passes in the mixed space and leaves the dataset at the new θ (theta.py)."""
     f, hist = sample_f(ds, phi, white_f, white_n)
     fo, po = ds.mix(f, phi)
     po2, dH, accept = hmc_step(ds, fo, po, white_p, log_u, N=N, eps=eps, always_accept=always_accept)
+    if theta_pass is not None:
+        theta_pass(fo, po2)
     f2, phi2 = ds.unmix(fo, po2)
     lp = ds.logpdf(f2, phi2)
     return dict(f=f2, phi=phi2, dH=dH, accept=accept, logpdf=lp, cg_hist=hist)
@@ -372,7 +375,7 @@ def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always
 # ---------------------------------------------------------------------------------------------------------------------
 def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=None, N=25, eps=0.01, nburnin_always_accept=0,
                  dist=None, nchains_total=None, progress=None, rng="host", first_step=0, filename=None, nfilewrite=5, nsavemaps=1,
-                 resume=None):
+                 resume=None, theta_ranges=None, theta_start=None):
     """`sample_joint` at fixed θ (src/sampling.jl:180-335): Gibbs loop  f | ϕ  ->  mix  ->  HMC ϕ° | f°  ->  unmix  ->  logpdf.
     The chains owned by this process are the batch slots of `ds` (`ds.d` must have len(chain_ids) slots; the reference runs
     chains under pmap, one worker per GPU, src/sampling.jl:266,292).  Chain c draws from its own generator keyed by
@@ -383,7 +386,10 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
     `filename` (".zip"): every `nfilewrite` steps the samples since the last write are appended as a new chunk (scalars every
     step, ϕ and f maps every `nsavemaps` steps and at the end of each chunk; src/sampling.jl:226-228,311-320), gathered to rank
     0 which owns the file; `resume=True` continues from the file's last sample up to `nsamps_per_chain` (:247-256), an existing
-    file needs an explicit `resume` (:239-241).  Returns dict(logpdf, dH, accept [nsamps, nchains], phi, f)."""
+    file needs an explicit `resume` (:239-241).
+    `theta_ranges` = {"Aphi": grid, "r": grid} adds the Gibbs θ passes (`gibbs_sample_slice_θ!`, :427-437) after the HMC pass; the
+    dataset's ParamDependentOps are then re-evaluated at the sampled θ for the following passes (single chain per dataset).
+    Returns dict(logpdf, dH, accept [nsamps, nchains], phi, f [, theta])."""
     from .chains import gather_chain_values, chain_seed
     from . import rng as R
     from . import chainfile as CF
@@ -437,6 +443,13 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
                            clobber=clobber)
         chunk_index, clobber, chunk = chunk_index + 1, False, [[] for _ in range(B)]
 
+    theta, theta_hist = None, []
+    if theta_ranges:
+        from . import theta as TH
+        assert B == 1, "θ sampling: one chain per dataset (the operators of a dataset carry a single θ)"
+        theta = dict(r=None, Aphi=None)
+        theta.update(theta_start or {})
+        TH.set_theta(ds, **theta)
     f = None
     for step in range(first_step, nsamps_per_chain) if (filename is not None and resume) else range(first_step, first_step + nsamps_per_chain):
         if rng == "device":
@@ -446,7 +459,17 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
             draw = lambda Pp: np.stack([r.standard_normal((Pp, proj.Nx, proj.Ny)) for r in rngs])
             wf, wn, wp = draw(P), draw(P), draw(1)
             logu = np.log(np.array([r.random() for r in rngs]))
-        st = gibbs_step(ds, phi, wf, wn, wp, logu, N=N, eps=eps, always_accept=(step < nburnin_always_accept))
+        tpass = None
+        if theta_ranges:
+            def tpass(fo_, po_, step=step):
+                for j, (key, xs) in enumerate(theta_ranges.items()):
+                    uu = R.uniform(seeds[0], R.stream_id(R.STREAM_U + 1 + j, step)) if rng == "device" else [rngs[0].random()]
+                    val, _ = TH.gibbs_sample_theta(ds, fo_, po_, theta, key, xs, uu)
+                    theta[key] = float(val[0])
+                TH.set_theta(ds, **theta)
+        st = gibbs_step(ds, phi, wf, wn, wp, logu, N=N, eps=eps, always_accept=(step < nburnin_always_accept), theta_pass=tpass)
+        if theta_ranges:
+            theta_hist.append(dict(theta))
         phi, f = st["phi"], st["f"]
         hist["logpdf"].append(st["logpdf"]); hist["dH"].append(st["dH"]); hist["accept"].append(st["accept"].astype(float))
         hist["ncg"].append(np.full(B, len(st["cg_hist"]), float))
@@ -468,4 +491,6 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
     if multi:
         out = {k: gather_chain_values(fidx, v.T, ntot, dist, gdev).T for k, v in out.items()}   # (nsamps, nchains_total)
     out["phi"], out["f"] = phi, f
+    if theta_ranges:
+        out["theta"] = theta_hist
     return out

@@ -349,6 +349,7 @@ class BaseDataSet:
         if d is not None:
             self.set_data(d)
         self.logdet_sum = float(logdet_sum)
+        self.logdet_mix = 0.0          # logdet(D,θ) + logdet(G,θ) of the mixed parametrisation (src/dataset.jl:86); 0 at fiducial θ
         check(self.lib.cmbl_dataset_set_logdet(self._h, self.logdet_sum))
 
     def __del__(self):
@@ -358,6 +359,10 @@ class BaseDataSet:
                 self._h = None
         except Exception:
             pass
+
+    def set_logdet(self, logdet_sum):
+        self.logdet_sum = float(logdet_sum)
+        check(self.lib.cmbl_dataset_set_logdet(self._h, self.logdet_sum))
 
     def set_op(self, name, planes):
         t = self.proj.tensor(planes)
@@ -464,7 +469,7 @@ class BaseDataSet:
         lp = (ctypes.c_double * B)()
         self.L.invalidate()
         check(self.lib.cmbl_logpdf_mixed(self._h, self.L._h, _ptr(fo.arr), _ptr(phio.arr), lp, B))
-        return np.array(lp[:])
+        return np.array(lp[:]) - self.logdet_mix
 
     def gradient_logpdf_mixed(self, fo, phio, alias_quirk=False):
         """(logpdf, ∇f° [MAP], ∇ϕ° [FOURIER]) — the "∇lnP" step (test/runbenchmarks.jl:120)."""
@@ -476,7 +481,7 @@ class BaseDataSet:
         self.L.invalidate()
         check(self.lib.cmbl_grad_logpdf_mixed(self._h, self.L._h, _ptr(fo.arr), _ptr(phio.arr), lp, _ptr(gfo), _ptr(gpo),
                                               B, 1 if alias_quirk else 0))
-        return np.array(lp[:]), Field(self.proj, gfo, MAP), Field(self.proj, gpo, FOURIER)
+        return np.array(lp[:]) - self.logdet_mix, Field(self.proj, gfo, MAP), Field(self.proj, gpo, FOURIER)
 
     def mix(self, f, phi, G=None):
         """f° = L(ϕ)·D·f, ϕ° = G·ϕ (src/dataset.jl:96-101)"""

@@ -155,7 +155,8 @@ def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T
     mk = lambda c, **kw: HarmOp.from_cls(pol, proj, c, **kw)
 
     Cphi = cl_to_2d(cls["total"]["pp"], proj)                                   # :267
-    Cf = mk(cls["unlensed_scalar"]) + mk(cls["tensor"])                         # :268-273 at r = r₀
+    Cfs, Cten = mk(cls["unlensed_scalar"]), mk(cls["tensor"])                  # :268-269
+    Cf = Cfs + Cten                                                             # :273 at r = r₀
     Cn = mk(ncl)                                                                # :271-272
     Mf = mk(lowpass(bandpass_lmax), units=1, te_zero=True)                      # :279
     bcl = beam_cls(beam_fwhm, lmax)
@@ -176,7 +177,8 @@ def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T
                precond_inv=precond.pinv().p, Cphi_inv=_pinv(Cphi)[None], G_inv=_pinv(Gp)[None], Mpix=Mpix)
     ds = BaseDataSet(proj, P, ops, logdet_sum=logdet_sum, nsteps=nsteps)
     Cft = mk(cls["total"])                                                     # Cf̃ (:270)
-    ds.host = dict(Cf=Cf, Cn=Cn, Cphi=Cphi, Mf=Mf, B=Bop, D=D, Nphi=Nphi, G=Gp, Mpix=Mpix, precond=precond, Cftilde=Cft)
+    ds.host = dict(Cf=Cf, Cn=Cn, Cphi=Cphi, Mf=Mf, B=Bop, D=D, Nphi=Nphi, G=Gp, Mpix=Mpix, precond=precond, Cftilde=Cft,
+                   Cfs=Cfs, Cten=Cten, r0=0.2, Aphi0=1.0, s2len=s2len)           # θ layer (theta.py): r₀ = Cℓ.params.r, Aϕ₀ = 1 (:239,250)
 
     # simulate: x = sqrt(C)·rfft(white)   (src/specialops.jl:6), white ~ NumPy PCG64(seed) uploaded, or with rng="device"
     # drawn on the GPU (cmbl_randn: Philox4x32-10, batch slot b keyed by seed + 1000003*b)

@@ -354,7 +354,8 @@ def load_sim(theta_pix, Nside, pol, T=np.float64, muK_arcmin_T=3.0, lknee=100.0,
     mk = lambda c, **kw: HarmOp.from_cls(pol, proj, c, **kw)
 
     Cphi = cl_to_2d(cls["total"]["pp"], proj)                              # :267
-    Cf = mk(cls["unlensed_scalar"]) + mk(cls["tensor"])                    # :268-273 (r = r₀)
+    Cfs, Cten = mk(cls["unlensed_scalar"]), mk(cls["tensor"])             # :268-269
+    Cf = Cfs + Cten                                                        # :273 at r = r₀
     Cft = mk(cls["total"])                                                 # :270
     Cn = mk(ncl)                                                           # :271-272
     Mf = mk(lowpass(bandpass_lmax), units=1, te_zero=True)                 # :279
@@ -388,4 +389,4 @@ def load_sim(theta_pix, Nside, pol, T=np.float64, muK_arcmin_T=3.0, lknee=100.0,
     ds.G = np.ones_like(ds.G)
     s2len = T(np.deg2rad(5 / 60) ** 2)
     ds.D = ((Cf + (Cn.scale(2) + s2len)) @ Cf.pinv()).sqrt()              # :322-328
-    return dict(f=f, phi=phi, ftilde=ftilde, d=d, n=n, ds=ds, proj=proj, cls=cls)
+    return dict(f=f, phi=phi, ftilde=ftilde, d=d, n=n, ds=ds, proj=proj, cls=cls, Cfs=Cfs, Cten=Cten)

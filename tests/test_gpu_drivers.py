@@ -283,3 +283,54 @@ def test_sample_joint_chain_file_and_resume(tmp_path):
     np.testing.assert_allclose(cb[1, -1]["phi"], ca[1, -1]["phi"], rtol=1e-8, atol=1e-14)
     np.testing.assert_allclose(ca[1, -1]["phi"], ra["phi"].arr[1, 0].cpu().numpy(), rtol=1e-12)
     assert C.load_chains(fa, thin="hasmaps")["step"].tolist() == [[1, 2, 3, 4, 6]] * 2
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_theta_layer(prec):
+    """logpdf(Mixed(ds); f°, ϕ°, θ) for θ = (r, Aϕ) (src/dataset.jl:84-87,272-274,316-328) and the Gibbs θ pass (src/sampling.jl:427-437)
+    against the oracle's ParamDependentOp layer; set_theta(ds) restores the fiducial dataset."""
+    from oracle.theta import ThetaDataSet, grid_and_sample as o_gas
+    C, so, sd = _dataset_pair(prec, "P", (64, 64), mask=True, beam=1.0)
+    ods, ds, p = so["ds"], sd["ds"], sd["proj"]
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    ds.set_data(F(so["d"], C.HARMONIC))
+    th = ThetaDataSet(ods, so["Cfs"], so["Cten"])
+    fo_o, po_o = ods.mix(so["f"], so["phi"])
+    fo, po = F(fo_o, C.MAP), F(po_o, C.FOURIER)
+    rt = 3e-5 if prec == "f32" else 1e-10
+    base = ds.logpdf_mixed(fo, po)
+    for kw in (dict(), dict(r=0.2, Aphi=1.0), dict(r=0.35), dict(Aphi=0.8), dict(r=0.1, Aphi=1.25)):
+        np.testing.assert_allclose(C.logpdf_mixed_theta(ds, fo, po, **kw), th.logpdf_mixed(fo_o, po_o, **kw), rtol=rt, err_msg=str(kw))
+    C.set_theta(ds)
+    np.testing.assert_allclose(ds.logpdf_mixed(fo, po), base, rtol=1e-12)
+    assert ds.logdet_mix == 0.0
+    # Gibbs pass over Aϕ: same conditional on the grid, same draw for the same uniform
+    xs = np.linspace(0.6, 1.6, 9)
+    val, lp_grid = C.gibbs_sample_theta(ds, fo, po, dict(r=None, Aphi=None), "Aphi", xs, [0.37])
+    lps_o = np.array([th.logpdf_mixed(fo_o, po_o, Aphi=a)[0] for a in xs])
+    want, _, lp_o = o_gas(lps_o, xs, 0.37)
+    np.testing.assert_allclose(lp_grid[0], lp_o, atol=5e-2 if prec == "f32" else 1e-6)
+    assert abs(val[0] - want) < (2e-2 if prec == "f32" else 1e-6)
+    assert xs[0] < val[0] < xs[-1]
+    # the dataset is left at the last grid point: mixing with θ-dependent D, G is consistent with the oracle's
+    C.set_theta(ds, r=0.3, Aphi=1.2)
+    dso, _, _ = th.at(r=0.3, Aphi=1.2)
+    f2_o, p2_o = dso.unmix(fo_o, po_o)
+    f2, p2 = ds.unmix(fo, po)
+    assert rel(f2.arr.cpu().numpy(), f2_o) < (2e-4 if prec == "f32" else 1e-9)
+    assert rel(p2.arr.cpu().numpy(), p2_o) < (1e-5 if prec == "f32" else 1e-12)
+    C.set_theta(ds)
+
+
+def test_sample_joint_with_theta_pass():
+    """sample_joint with a Gibbs pass over Aϕ: the chain runs, θ moves inside its grid and the dataset follows it"""
+    import cmblensing_jl_amd as C
+    from bench import synthetic_cls
+    s = C.load_sim(3.0, (64, 64), "P", synthetic_cls(), T=torch.float64, beam_fwhm=1.0, Nphi="flat")
+    ds = s["ds"]
+    xs = np.linspace(0.5, 2.0, 12)
+    out = C.sample_joint(ds, 3, chain_ids=(0,), base_seed=5, N=3, eps=0.01, rng="device", theta_ranges=dict(Aphi=xs), phi_start=s["phi"])
+    th = [t["Aphi"] for t in out["theta"]]
+    assert len(th) == 3 and all(xs[0] <= a <= xs[-1] for a in th) and len(set(th)) > 1
+    assert ds.theta["Aphi"] == th[-1] and np.all(np.isfinite(out["logpdf"]))
+    C.set_theta(ds)
