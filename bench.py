@@ -52,11 +52,11 @@ KERNEL_SHARE = {
     "x_grad": lambda P, B, Bphi: 4.5 * P * B,                      # x-halves of rfft/irfft(∂x), i·lx multiply
     "adj_y": lambda P, B, Bphi: 7.5 * P * B + 2 * Bphi,
     "adj_x": lambda P, B, Bphi: 7.5 * P * B,
-    # δ-flow stage = two launches: columns (f part 10.5 + δf part 7.5 per slice, + the δϕ column work of the previous stage: w, u,
-    # 5 products, y-halves of 5 S0 rffts = 19 per batch slot + 5 ϕ-map reads) and rows (δf row pass 7.5 + next stage's d/dx pass 4.5
-    # per slice, + δϕ x-halves / combine / RK update 11 per batch slot)
-    "delta_cols": lambda P, B, Bphi: 18.0 * P * B + 2 * Bphi + 19.0 * B + 5 * Bphi,
-    "delta_rows": lambda P, B, Bphi: 12.0 * P * B + 11.0 * B,
+    # δ-flow stage = two launches: columns (f part 10.5 + δf part 7.5 per slice) and rows (δf row pass 7.5 + next stage's d/dx pass
+    # 4.5 per slice).  The δϕ update is a quadrature over the stages and is formed once per δ-flow (dphi_reduce + 5 rffts): the
+    # ≈30·B + 5·Bϕ map-passes per stage that SURVEY §8(d) counts for it are work this design does not do.
+    "delta_cols": lambda P, B, Bphi: 18.0 * P * B + 2 * Bphi,
+    "delta_rows": lambda P, B, Bphi: 12.0 * P * B,
 }
 
 

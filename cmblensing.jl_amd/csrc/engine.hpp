@@ -28,7 +28,7 @@ inline void raise_lds_limit(const void* fn, size_t bytes) {
 enum KernelId { K_LAYOUT = 0, K_Y_R2C, K_Y_C2R, K_X_FFT, K_X_GRAD, K_FLOW_Y, K_ADJ_Y, K_ADJ_X, K_DELTA_Y, K_DELTA_ROWS, K_DPHI_Y, K_DPHI_X,
                 K_GRADHESS, K_HARM, K_LINCOMB, K_MASK, K_REDUCE, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_cols", "delta_rows",
-                                                  "dphi_y", "dphi_x", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce"};
+                                                  "dphi_reduce", "dphi_combine", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce"};
 
 #define CMBL_LAUNCH_NT(ctxp, kid, nthreads, kernel, grid, lds, stream, ...)            \
   do {                                                                                \
@@ -384,10 +384,11 @@ struct Flow {
   DevBuf phiF, gh;                        // scratch for precompute
   DevBuf A, A2, Gx, y0, acc;              // forward flow state          (slices)
   DevBuf H, Wx, Wy, Y0, Yacc;             // adjoint flow state          (slices)
-  DevBuf w1p, w2p, Z0, Z1, Z2, P0, Pacc;  // delta flow extras
+  DevBuf P0;                              // delta flow: dphi result (F layout)
   DevBuf cvt;                             // boundary conversion scratch
 
-  DevBuf w1q, w2q;                        // second set of w-partials (double buffering across stages)
+  DevBuf Wst, U5, F5, tcbuf;              // per-stage partial products, the five reduced maps and their transforms, (t_s, c_s)
+  std::vector<T> tc_host;
 
   Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) { CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range"); }
   Flow(const Flow&) = delete;
@@ -536,81 +537,67 @@ struct Flow {
       }
   }
 
-  // delta flow (src/flowops.jl:48,63): state (f [map], df [F, QU-Fourier], dphi [F, S0]); all updated in place.
+  // delta flow (src/flowops.jl:48,63): state (f [map], df [F, QU-Fourier], dphi [F, S0]); f and df updated in place, dphi written.
   // forward_primal=true : pullback of L*f  -> integrate t 1->0;  false: pullback of L\f -> t 0->1.
-  // Two launches per RK stage (k_delta_cols, k_delta_rows); the delta-phi work of stage s-1 rides along with stage s.
+  // Two launches per RK stage (k_delta_cols, k_delta_rows) for the (f, delta f) chain; the stage's partial products go to a
+  // per-stage buffer and delta-phi -- a pure quadrature over the stages -- is formed once at the end (k_dphi_reduce, 5 rffts, combine).
   void flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
     check_ready(B);
     const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    const int nst = 4 * n;
     A.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
     acc.ensure(sizeof(T) * slices * np);
     H.ensure(sizeof(cx<T>) * slices * pl); Wx.ensure(sizeof(cx<T>) * slices * pl); Wy.ensure(sizeof(cx<T>) * slices * pl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
-    w1p.ensure(sizeof(T) * slices * np); w2p.ensure(sizeof(T) * slices * np);
-    w1q.ensure(sizeof(T) * slices * np); w2q.ensure(sizeof(T) * slices * np);       // partial products are double-buffered across stages
-    Z0.ensure(sizeof(cx<T>) * B * pl); Z1.ensure(sizeof(cx<T>) * B * pl); Z2.ensure(sizeof(cx<T>) * B * pl);
-    Pacc.ensure(sizeof(cx<T>) * B * pl);
-    CMBL_HIP(hipMemsetAsync(dphi, 0, sizeof(cx<T>) * B * pl, c->stream));
+    Wst.ensure(sizeof(T) * (size_t)nst * 2 * slices * np);              // 4n x 2 maps per slice: 448 MB at 1024^2 QU fp32, n = 7
+    U5.ensure(sizeof(T) * 5 * B * np); F5.ensure(sizeof(cx<T>) * 5 * B * pl); tcbuf.ensure(sizeof(T) * 2 * nst);
     cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
     c->y_r2c(f, a_cur, slices);
     c->template x_pass<1>(df, H.as<cx<T>>(), slices);
     const auto tile = c->tileY(slices, true);
-    const long rows = slices * c->Nyh, rowsp = (long)B * c->Nyh;
-    const int RX = std::min(c->pickRX(2, rows), c->pickRX(3, rowsp));
-    const int nb_adj = (int)((rows + RX - 1) / RX), nb_dphi = (int)((rowsp + RX - 1) / RX);
+    const long rows = slices * c->Nyh;
+    const int RX = c->pickRX(2, rows);
+    const int nb_adj = (int)((rows + RX - 1) / RX);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
-    c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);                            // later d/dx passes ride along with the previous stage's row launch
-
-    DeltaYArgs<T> d{};
-    DphiYArgs<T> py{};
-    AdjXArgs<T> x{};
-    DphiXArgs<T> px{};
-    GradXArgs<T> gx{};
-    auto launch_cols = [&](bool with_delta, bool with_dphi) {
-      c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
-        constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
-        const int sl = with_delta ? (int)slices : 0;
-        CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_cols<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)(sl + (with_dphi ? B * (R >= CMBL_DPHI_SPLIT ? CMBL_DPHI_SPLIT : 1) : 0))), c->ldsY(tile.C),
-                       c->stream, d, py, sl);
-      });
-    };
-    auto launch_rows = [&](int n_adj, int n_grad, int n_dphi) {
-      c->dispatch_row(c->pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
-        constexpr int XNT = decltype(xnt)::value;
-        CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, XNT, decltype(lgnx)::value>), dim3((unsigned)(n_adj + n_grad + n_dphi)),
-                       c->ldsX(RX, n_dphi ? 3 : 2), c->stream, x, gx, px, n_adj, n_grad);
-      });
-    };
+    c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);                // later d/dx passes ride along with the previous stage's row launch
+    tc_host.resize(2 * (size_t)nst);
     int it = 0;
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage, ++it) {
         const bool last = step == n - 1 && stage == 4;
         const RKCoef<T> rk = coef(step, stage, t0, h, last);
-        T* wa = (it & 1) ? w1q.as<T>() : w1p.as<T>();
-        T* wb = (it & 1) ? w2q.as<T>() : w2p.as<T>();
+        tc_host[2 * it] = rk.t;
+        tc_host[2 * it + 1] = (T)((stage == 1 || stage == 4 ? 1.0 : 2.0) * h / 6);   // RK4 weights (src/numerical_algorithms.jl:20)
+        DeltaYArgs<T> d{};
         FlowYArgs<T>& a = d.f;
         a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = f; a.acc = acc.as<T>(); a.ph = ph(rk.t);
         a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
         a.Nx = c->Nx; a.P = P; a.rk = rk;
-        d.H = H.as<cx<T>>(); d.Wx = Wx.as<cx<T>>(); d.Wy = Wy.as<cx<T>>(); d.w1p = wa; d.w2p = wb;
-        launch_cols(true, it > 0);                                           // py still describes stage it-1
+        d.H = H.as<cx<T>>(); d.Wx = Wx.as<cx<T>>(); d.Wy = Wy.as<cx<T>>();
+        d.w1p = Wst.as<T>() + (size_t)(2 * it) * slices * np; d.w2p = d.w1p + (size_t)slices * np;
+        c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
+          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+          CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_cols<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, d);
+        });
         std::swap(a_cur, a_nxt);
-
-        // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_cur already points at A_{s+1}) + delta-phi rows of stage it-1
+        // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_cur already points at A_{s+1})
+        AdjXArgs<T> x{};
         x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
         x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.nblk = nb_adj; x.rows = rows; x.rk = rk;
-        gx = GradXArgs<T>{a_cur, Gx.as<cx<T>>(), x.twX, c->dlx_over_Nx, rows, nb_adj};
-        launch_rows(nb_adj, last ? 0 : nb_adj, it > 0 ? nb_dphi : 0);        // px still describes stage it-1
-
-        // delta-phi work of THIS stage, launched with the next stage
-        py.w1p = wa; py.w2p = wb; py.Z0 = Z0.as<cx<T>>(); py.Z1 = Z1.as<cx<T>>(); py.Z2 = Z2.as<cx<T>>();
-        py.ph = ph(); py.twY = a.twY; py.ly = a.ly; py.Nx = c->Nx; py.P = P;
-        py.alias_quirk = alias_quirk ? 1 : 0; py.t = rk.t;
-        px.Z0 = Z0.as<cx<T>>(); px.Z1 = Z1.as<cx<T>>(); px.Z2 = Z2.as<cx<T>>(); px.Y0 = dphi; px.acc = Pacc.as<cx<T>>();
-        px.twX = x.twX; px.lx_r = x.lx_r; px.RX = RX; px.nblk = nb_dphi; px.rows = rowsp; px.rk = rk;
+        GradXArgs<T> gx{a_cur, Gx.as<cx<T>>(), x.twX, c->dlx_over_Nx, rows, nb_adj};
+        c->dispatch_row(c->pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
+          constexpr int XNT = decltype(xnt)::value;
+          CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, XNT, decltype(lgnx)::value>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))),
+                         c->ldsX(RX, 2), c->stream, x, gx, nb_adj);
+        });
       }
-    launch_cols(false, true);                                                // delta-phi of the last stage
-    launch_rows(0, 0, nb_dphi);
+    // delta-phi: quadrature over the stages, then five real transforms and the l-multipliers
+    CMBL_HIP(hipMemcpyAsync(tcbuf.p, tc_host.data(), sizeof(T) * 2 * nst, hipMemcpyHostToDevice, c->stream));
+    CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T>), dim3((unsigned)std::min<long>((np + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
+                tcbuf.as<T>(), U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
+    c->rfft2_F(U5.as<T>(), F5.as<cx<T>>(), 5L * B);
+    CMBL_LAUNCH(c, K_DPHI_X, (k_dphi_combine<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, F5.as<cx<T>>(), dphi, c->lx_r.template as<T>(),
+                c->ly.template as<T>(), c->lgNx, pl, B);
   }
 
   // ---- boundary-level entry points ---------------------------------------------------------------

@@ -15,9 +15,6 @@
 #pragma once
 #include "kernels_fft.hpp"
 
-#ifndef CMBL_DPHI_SPLIT
-#define CMBL_DPHI_SPLIT 2
-#endif
 namespace cmbl {
 #ifdef CMBL_STAMPS
 __device__ unsigned long long g_stamps[8192 * 16];
@@ -448,191 +445,77 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   CMBL_STAMP(12);
 }
 
-// delta-phi part, column kernel (one per batch slot): w = sum_pol partials; u = M^-1 w (quirk Q1 optional);
-//   Z0 = i*ly*Y(u2) - ly^2*Y(t*py*u2) ; Z1 = Y(u1) + i*ly*Y(t*(py*u1 + px*u2)) ; Z2 = Y(t*px*u1)   (mixed, S0)
-// so that d(dphi)/dt = fft_x(Z0) + i*lx*fft_x(Z1) - lx^2*fft_x(Z2)        (src/lenseflow.jl:198-206).
-// Five real transforms = two N-point complex transforms, (u1, u2) and (bb, cc) -- sequences of like magnitude are paired so
-// neither loses precision to the other -- and one packed transform (aa).
-template <typename T> struct DphiYArgs {
-  const T* w1p; const T* w2p;   // (B*P, Nx, Ny)
-  cx<T>* Z0; cx<T>* Z1; cx<T>* Z2;   // (B, Nyh, Nx) mixed
-  PhiMaps<T> ph;
-  const cx<T>* twY; const T* ly;
-  int Nx, P, alias_quirk;
-  T t;
-};
-
-template <typename T, int R, int NT, int LGM>
-__device__ __forceinline__ void dphi_y_body(const DphiYArgs<T>& a, unsigned char* smem, size_t b, int tile, int ntiles) {
-  using G = ColTile<R, NT, LGM>;
-  constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
-  constexpr int RZ = G::RZ;
-  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + M;
-  const int Nx = a.Nx, x0 = xcd_tile(tile, ntiles) * C;
-  const int bphi = a.ph.Bphi == 1 ? 0 : (int)b;
-  TwStage<T, NT, M> twr;
-  twr.issue(a.twY);
-  const size_t pbase = ((size_t)bphi * Nx + x0) * M;
-  cx<T> u1[R], u2[R], pxr[R], pyr[R];
-  T lyr[RZ];
-#pragma unroll
-  for (int i = 0; i < RZ; ++i) { const int e = threadIdx.x + i * NT; if (e < C * (M + 1)) lyr[i] = a.ly[e >> LGC]; }
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT;
-    cx<T> m11, m12, m22;
-    load_p_pair(a.ph, pbase + e, a.t, pxr[i], pyr[i], m11, m12, m22);
-    cx<T> w1 = mk<T>(0, 0), w2 = mk<T>(0, 0);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {                         // spin-adjoint product: sum over pol (src/proj_lambert.jl:423-430); P <= 3,
-      if (p < a.P) {                                      // unrolled so that the loads of all pols are in flight together
-        const size_t mi = (((size_t)b * a.P + p) * Nx + x0) * M + e;
-        w1 = w1 + reinterpret_cast<const cx<T>*>(a.w1p)[mi];
-        w2 = w2 + reinterpret_cast<const cx<T>*>(a.w2p)[mi];
+// ---------------------------------------------------------------------------------------------
+// delta-phi.  Its velocity (src/lenseflow.jl:198-206),
+//     d(dphi)/dt = i lx F(u1) + i ly F(u2) - lx^2 F(a) - lx ly F(b) - ly^2 F(c),   F = rfft2,
+//     w = sum_pol L(df) * grad f   (spin-adjoint product, src/proj_lambert.jl:423-430),   u = M^-1(t) w   (Q1 switch),
+//     a = t px u1,  b = t (py u1 + px u2),  c = t py u2,
+// depends on (f, df, t) only -- never on dphi itself -- so the RK4 update of dphi is a pure quadrature: dphi(end) = sum over all
+// stages of c_s * velocity_s with c_s = h/6 * (1, 2, 2, 1).  Transforms and l-multipliers are linear and the same for every stage,
+// hence  dphi(end) = i lx F(sum c_s u1_s) + i ly F(sum c_s u2_s) - lx^2 F(sum c_s a_s) - ...:  the column kernel only stores the
+// partial products w of each stage (two maps per slice, which it wrote before as well), ONE pointwise pass reduces them over
+// stages and pols into five maps, and five real transforms per delta flow replace five per STAGE (4n times fewer).
+// Identical to the reference's stage-by-stage update up to the order of floating-point summation.
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __restrict__ W /*[nst][2][slices][npix]*/,
+                                                    const T* __restrict__ tc /*[nst][2] = (t_s, c_s)*/, T* __restrict__ out /*[5][B][npix]*/,
+                                                    long npix, int P, int B, int nst, int alias_quirk) {
+  const int b = blockIdx.y;
+  const size_t slices = (size_t)P * B, pb = (size_t)(ph.Bphi == 1 ? 0 : b) * npix;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
+    const T gx = ph.gx[pb + i], gy = ph.gy[pb + i], hxx = ph.hxx[pb + i], hyx = ph.hyx[pb + i], hyy = ph.hyy[pb + i];
+    double U1 = 0, U2 = 0, A = 0, Bb = 0, Cc = 0;
+#pragma unroll 4
+    for (int s = 0; s < nst; ++s) {                           // unrolled: the loads of several stages in flight
+      const T t = tc[2 * s], c = tc[2 * s + 1];
+      T w1 = 0, w2 = 0;
+      for (int p = 0; p < P; ++p) {
+        w1 += W[((size_t)(2 * s) * slices + (size_t)b * P + p) * npix + i];
+        w2 += W[((size_t)(2 * s + 1) * slices + (size_t)b * P + p) * npix + i];
       }
+      T px, py, m11, m12, m22;
+      flow_pm(t, gx, gy, hxx, hyx, hyy, px, py, m11, m12, m22);
+      // u = M^-1 w   (src/field_vectors.jl:48-49; with the reference's aliasing, v[2] sees the updated v[1])
+      const T v1 = m11 * w1 + m12 * w2;
+      const T u2 = m12 * (alias_quirk ? v1 : w1) + m22 * w2;
+      U1 += (double)(c * v1); U2 += (double)(c * u2);
+      A += (double)(c * t * px * v1); Bb += (double)(c * t * (py * v1 + px * u2)); Cc += (double)(c * t * py * u2);
     }
-    // u = M^-1 w   (src/field_vectors.jl:48-49; with the reference's aliasing, v[2] sees the updated v[1])
-    const cx<T> v1 = pmul(m11, w1) + pmul(m12, w2);
-    const cx<T> in1 = a.alias_quirk ? v1 : w1;
-    u1[i] = v1;
-    u2[i] = pmul(m12, in1) + pmul(m22, w2);
+    const size_t o = (size_t)b * npix + i, cs = (size_t)B * npix;
+    out[o] = (T)U1; out[cs + o] = (T)U2; out[2 * cs + o] = (T)A; out[3 * cs + o] = (T)Bb; out[4 * cs + o] = (T)Cc;
   }
-  const T t = a.t;
-  const size_t moff = b * (size_t)Nyh * Nx;
-  twr.commit(tw);
-  // pair (u1, u2): keep Y(u1), Y(u2) of this thread's half-spectrum entries in registers
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
-    write_pair(s + c * LD, jj, u1[i], u2[i]);
-  }
-  __syncthreads();
-  fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
-  cx<T> yu1[RZ], yu2[RZ];
-  pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int, int, cx<T> A, cx<T> B) { yu1[i] = A; yu2[i] = B; });
-  __syncthreads();
-  // pair (bb, cc) = (t*(py*u1 + px*u2), t*py*u2):  Z1 = Y(u1) + i*ly*Y(bb) ;  Z0 = i*ly*Y(u2) - ly^2*Y(cc)
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
-    write_pair(s + c * LD, jj, t * (pmul(pyr[i], u1[i]) + pmul(pxr[i], u2[i])), t * pmul(pyr[i], u2[i]));
-  }
-  __syncthreads();
-  fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
-  {
-    cx<T>* Z0 = a.Z0 + moff; cx<T>* Z1 = a.Z1 + moff;
-    pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> Yb, cx<T> Yc) {
-      const T l = lyr[i];
-      const size_t gi = (size_t)k * Nx + x0 + c;
-      Z1[gi] = yu1[i] + mul_il(Yb, l);
-      Z0[gi] = mul_il(yu2[i], l) - (l * l) * Yc;
-    });
-  }
-  __syncthreads();
-  // aa = t*px*u1  ->  Z2 = Y(aa)   (packed single transform)
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
-    s[c * LD + pad(jj)] = t * pmul(pxr[i], u1[i]);
-  }
-  __syncthreads();
-  fft_dif<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
-  r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Z2 + moff, Nx, x0);
 }
-
-// delta-phi part, row kernel: k = fft_x(Z0) + i*lx*fft_x(Z1) - lx^2*fft_x(Z2) ; RK update of the S0 Fourier state
-template <typename T> struct DphiXArgs {
-  const cx<T>* Z0; const cx<T>* Z1; const cx<T>* Z2; cx<T>* Y0; cx<T>* acc;
-  const cx<T>* twX; const T* lx_r;
-  int RX, nblk; long rows;
-  RKCoef<T> rk;
-};
-
-template <typename T, int NT, int LGNX>
-__device__ __forceinline__ void dphi_x_body(const DphiXArgs<T>& a, unsigned char* smem, long blk) {
-  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
-  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + (Nx >> 1);
-  long r0; int nr;
-  row_range(a.rows, a.nblk, blk, r0, nr);
-  const size_t st = (size_t)nr * LD;                          // three adjacent row sets
-  constexpr int PF = Nx >= NT ? Nx / NT : 1;
-  TwStage<T, NT, (Nx >> 1)> twr;
-  twr.issue(a.twX);
-  T lxr[PF];
-  if constexpr (Nx >= NT) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i) lxr[i] = a.lx_r[threadIdx.x + i * NT];
-  }
-  {
-    cx<T>* const sa[3] = {s, s + st, s + 2 * st};
-    const cx<T>* const ga[3] = {a.Z0 + r0 * Nx, a.Z1 + r0 * Nx, a.Z2 + r0 * Nx};
-    rows_load<T, NT, LGNX, 3>(sa, ga, nr);
-  }
-  twr.commit(tw);
-  const int n = nr * Nx;
-  __syncthreads();
-  fft_dif<T, NT, LD, LGNX, LGNX, 4>(s, 3 * nr, tw);
-  if constexpr (Nx >= NT) {
-    for (int r = 0; r < nr; ++r) {
-      const long g0 = (r0 + r) * Nx;
-      cx<T> y0[PF], acc[PF];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const long gi = g0 + threadIdx.x + i * NT;
-        y0[i] = a.Y0[gi];
-        acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
-      }
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int e = threadIdx.x + i * NT, si = r * LD + pad(e);
-        const T l = lxr[i];
-        const cx<T> kv = s[si] + mul_il(s[st + si], l) - (l * l) * s[2 * st + si];
-        (void)rk_update(a.rk, kv, y0[i], acc[i]);
-        if (a.rk.stage == 4) a.Y0[g0 + e] = y0[i]; else a.acc[g0 + e] = acc[i];
-      }
-    }
-  } else {
-    for (int e = threadIdx.x; e < n; e += NT) {
-      const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
-      const T l = a.lx_r[i];
-      const cx<T> kv = s[si] + mul_il(s[st + si], l) - (l * l) * s[2 * st + si];
-      const long gi = r0 * Nx + e;
-      cx<T> y0 = a.Y0[gi];
-      cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
-      (void)rk_update(a.rk, kv, y0, acc);
-      if (a.rk.stage == 4) a.Y0[gi] = y0; else a.acc[gi] = acc;
-    }
+// dphi = i lx F1 + i ly F2 - lx^2 FA - lx ly FB - ly^2 FC   (F layout, [5][B][plane] in, [B][plane] out)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_dphi_combine(const cx<T>* __restrict__ F5, cx<T>* __restrict__ out, const T* __restrict__ lx_r,
+                                                     const T* __restrict__ ly, int lgNx, long plane, int B) {
+  const long i = (long)blockIdx.x * NTP + threadIdx.x;
+  if (i >= plane) return;
+  const T lx = lx_r[i & ((1 << lgNx) - 1)], l_y = ly[i >> lgNx];
+  const long cs = (long)B * plane;
+  for (int b = 0; b < B; ++b) {
+    const cx<T>* f = F5 + (long)b * plane + i;
+    const cx<T> f1 = f[0], f2 = f[cs], fa = f[2 * cs], fb = f[3 * cs], fc = f[4 * cs];
+    const T re = -lx * f1.y - l_y * f2.y - lx * lx * fa.x - lx * l_y * fb.x - l_y * l_y * fc.x;
+    const T im = lx * f1.x + l_y * f2.x - lx * lx * fa.y - lx * l_y * fb.y - l_y * l_y * fc.y;
+    out[(long)b * plane + i] = mk<T>(re, im);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// The delta flow is two launches per RK stage on ONE stream.  The delta-phi branch never feeds back into the (f, delta f)
-// chain, so its kernels for stage s-1 ride along as extra workgroups of the stage-s launches: they fill the CUs while the chain's
-// workgroups sit in barriers / HBM waits, and no event or second stream is needed (cross-stream events cost ~7 us of idle
-// queue per use on this GPU: kernel trace, profiles/).
-//   column launch:  [0, slices) delta_y_body of stage s   |  [slices, slices + B) dphi_y_body of stage s-1
-//   row launch:     adj_x_body (stage s)  |  grad_x_body (d/dx of the next stage's f)  |  dphi_x_body (stage s-1)
+// The delta flow is two launches per RK stage: the column kernel (delta_y_body per slice) and ONE row launch for the delta-f
+// row pass of this stage (adj_x_body) and the d/dx pass of the NEXT stage's f (grad_x_body), which are independent.
 template <typename T, int R, int NT, int LGM>
-__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_cols(DeltaYArgs<T> d, DphiYArgs<T> p, int slices) {
+__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_cols(DeltaYArgs<T> d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // the delta-phi workgroups take tiles of C/CMBL_DPHI_SPLIT columns: more, shorter workgroups fill the slots the chain frees
-  constexpr int F = (R >= CMBL_DPHI_SPLIT) ? CMBL_DPHI_SPLIT : 1;
-  if ((int)blockIdx.y < slices) delta_y_body<T, R, NT, LGM>(d, smem, blockIdx.y);
-  else {
-    const int yy = (int)blockIdx.y - slices;
-    dphi_y_body<T, R / F, NT, LGM>(p, smem, yy / F, (yy % F) * (int)gridDim.x + (int)blockIdx.x, F * (int)gridDim.x);
-  }
+  delta_y_body<T, R, NT, LGM>(d, smem, blockIdx.y);
 }
 template <typename T, int NT, int LGNX>
-__global__ __launch_bounds__(NT, row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, DphiXArgs<T> p, int nblk_adj, int nblk_grad) {
+__global__ __launch_bounds__(NT, row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   if (b < nblk_adj) adj_x_body<T, NT, LGNX>(a, smem, b);
-  else if (b < nblk_adj + nblk_grad) grad_x_body<T, NT, LGNX>(g, smem, (long)b - nblk_adj);
-  else dphi_x_body<T, NT, LGNX>(p, smem, (long)b - nblk_adj - nblk_grad);
+  else grad_x_body<T, NT, LGNX>(g, smem, (long)b - nblk_adj);
 }
 
 // gradient / hessian multipliers for precompute (src/specialops.jl:184-188): F layout in, five F-layout outputs
