@@ -593,7 +593,7 @@ struct Flow {
       }
     // delta-phi: quadrature over the stages, then five real transforms and the l-multipliers
     CMBL_HIP(hipMemcpyAsync(tcbuf.p, tc_host.data(), sizeof(T) * 2 * nst, hipMemcpyHostToDevice, c->stream));
-    CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T>), dim3((unsigned)std::min<long>((np + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
+    CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T>), dim3((unsigned)std::min<long>((np / (16 / (long)sizeof(T)) + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
                 tcbuf.as<T>(), U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
     c->rfft2_F(U5.as<T>(), F5.as<cx<T>>(), 5L * B);
     CMBL_LAUNCH(c, K_DPHI_X, (k_dphi_combine<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, F5.as<cx<T>>(), dphi, c->lx_r.template as<T>(),

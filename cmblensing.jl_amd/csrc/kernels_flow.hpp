@@ -460,29 +460,54 @@ template <typename T>
 __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __restrict__ W /*[nst][2][slices][npix]*/,
                                                     const T* __restrict__ tc /*[nst][2] = (t_s, c_s)*/, T* __restrict__ out /*[5][B][npix]*/,
                                                     long npix, int P, int B, int nst, int alias_quirk) {
+  constexpr int V = 16 / sizeof(T);                            // pixels per thread: 16-byte loads
+  struct alignas(16) Vec { T v[V]; };
   const int b = blockIdx.y;
   const size_t slices = (size_t)P * B, pb = (size_t)(ph.Bphi == 1 ? 0 : b) * npix;
-  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
-    const T gx = ph.gx[pb + i], gy = ph.gy[pb + i], hxx = ph.hxx[pb + i], hyx = ph.hyx[pb + i], hyy = ph.hyy[pb + i];
-    double U1 = 0, U2 = 0, A = 0, Bb = 0, Cc = 0;
-#pragma unroll 4
-    for (int s = 0; s < nst; ++s) {                           // unrolled: the loads of several stages in flight
+  const long nv = npix / V;
+  for (long iv = (long)blockIdx.x * NTP + threadIdx.x; iv < nv; iv += (long)gridDim.x * NTP) {
+    const long i = iv * V;
+    const Vec gx = *reinterpret_cast<const Vec*>(ph.gx + pb + i), gy = *reinterpret_cast<const Vec*>(ph.gy + pb + i);
+    const Vec hxx = *reinterpret_cast<const Vec*>(ph.hxx + pb + i), hyx = *reinterpret_cast<const Vec*>(ph.hyx + pb + i);
+    const Vec hyy = *reinterpret_cast<const Vec*>(ph.hyy + pb + i);
+    double U1[V] = {}, U2[V] = {}, A[V] = {}, Bb[V] = {}, Cc[V] = {};
+    for (int s = 0; s < nst; ++s) {
       const T t = tc[2 * s], c = tc[2 * s + 1];
-      T w1 = 0, w2 = 0;
+      Vec w1 = {}, w2 = {};
       for (int p = 0; p < P; ++p) {
-        w1 += W[((size_t)(2 * s) * slices + (size_t)b * P + p) * npix + i];
-        w2 += W[((size_t)(2 * s + 1) * slices + (size_t)b * P + p) * npix + i];
+        const Vec a1 = *reinterpret_cast<const Vec*>(W + ((size_t)(2 * s) * slices + (size_t)b * P + p) * npix + i);
+        const Vec a2 = *reinterpret_cast<const Vec*>(W + ((size_t)(2 * s + 1) * slices + (size_t)b * P + p) * npix + i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { w1.v[k] += a1.v[k]; w2.v[k] += a2.v[k]; }
       }
-      T px, py, m11, m12, m22;
-      flow_pm(t, gx, gy, hxx, hyx, hyy, px, py, m11, m12, m22);
-      // u = M^-1 w   (src/field_vectors.jl:48-49; with the reference's aliasing, v[2] sees the updated v[1])
-      const T v1 = m11 * w1 + m12 * w2;
-      const T u2 = m12 * (alias_quirk ? v1 : w1) + m22 * w2;
-      U1 += (double)(c * v1); U2 += (double)(c * u2);
-      A += (double)(c * t * px * v1); Bb += (double)(c * t * (py * v1 + px * u2)); Cc += (double)(c * t * py * u2);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        T px, py, m11, m12, m22;
+        flow_pm(t, gx.v[k], gy.v[k], hxx.v[k], hyx.v[k], hyy.v[k], px, py, m11, m12, m22);
+        // u = M^-1 w   (src/field_vectors.jl:48-49; with the reference's aliasing, v[2] sees the updated v[1])
+        const T v1 = m11 * w1.v[k] + m12 * w2.v[k];
+        const T u2 = m12 * (alias_quirk ? v1 : w1.v[k]) + m22 * w2.v[k];
+        U1[k] += (double)(c * v1); U2[k] += (double)(c * u2);
+        A[k] += (double)(c * t * px * v1); Bb[k] += (double)(c * t * (py * v1 + px * u2)); Cc[k] += (double)(c * t * py * u2);
+      }
     }
     const size_t o = (size_t)b * npix + i, cs = (size_t)B * npix;
-    out[o] = (T)U1; out[cs + o] = (T)U2; out[2 * cs + o] = (T)A; out[3 * cs + o] = (T)Bb; out[4 * cs + o] = (T)Cc;
+    Vec r;
+#pragma unroll
+    for (int k = 0; k < V; ++k) r.v[k] = (T)U1[k];
+    *reinterpret_cast<Vec*>(out + o) = r;
+#pragma unroll
+    for (int k = 0; k < V; ++k) r.v[k] = (T)U2[k];
+    *reinterpret_cast<Vec*>(out + cs + o) = r;
+#pragma unroll
+    for (int k = 0; k < V; ++k) r.v[k] = (T)A[k];
+    *reinterpret_cast<Vec*>(out + 2 * cs + o) = r;
+#pragma unroll
+    for (int k = 0; k < V; ++k) r.v[k] = (T)Bb[k];
+    *reinterpret_cast<Vec*>(out + 3 * cs + o) = r;
+#pragma unroll
+    for (int k = 0; k < V; ++k) r.v[k] = (T)Cc[k];
+    *reinterpret_cast<Vec*>(out + 4 * cs + o) = r;
   }
 }
 // dphi = i lx F1 + i ly F2 - lx^2 FA - lx ly FB - ly^2 FC   (F layout, [5][B][plane] in, [B][plane] out)
