@@ -27,6 +27,19 @@
 
 namespace cmbl {
 
+// debug builds (-DCMBL_STAMPS): per-workgroup phase timestamps, read back with cmbl_debug_stamps (tools/gpu_stamps.py)
+#ifdef CMBL_STAMPS
+__device__ unsigned long long g_stamps[8192 * 16];
+#define CMBL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = clock64(); } while (0)
+#else
+#define CMBL_STAMP(i) do {} while (0)
+#endif
+#ifdef CMBL_STAMPS_X
+#define CMBL_XSTAMP(i) CMBL_STAMP(i)
+#else
+#define CMBL_XSTAMP(i) do {} while (0)
+#endif
+
 // register budget of the row kernels (waves per SIMD the compiler must leave room for; fp32 only)
 template <typename T> constexpr int row_min_waves() { return sizeof(T) == 4 ? CMBL_ROW_WAVES : 1; }
 
@@ -291,6 +304,7 @@ __global__ __launch_bounds__(NT, row_min_waves<T>()) void k_x_fft(const cx<T>* _
   cx<T>* s = tw + (Nx >> 1);
   long r0; int nr;
   row_range(rows, nblk, blockIdx.x, r0, nr);
+  CMBL_XSTAMP(0);
   TwStage<T, NT, (Nx >> 1)> twr;
   twr.issue(twX);
   const T inv = T(1) / T(Nx);
@@ -302,7 +316,9 @@ __global__ __launch_bounds__(NT, row_min_waves<T>()) void k_x_fft(const cx<T>* _
   }
   twr.commit(tw);
   __syncthreads();
+  CMBL_XSTAMP(1);
   if (MODE == 0 || MODE == 2) fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
+  CMBL_XSTAMP(2);
   if (MODE == 2) {
     // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i)
     fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw, [dl](cx<T> v, int i) {
@@ -311,9 +327,11 @@ __global__ __launch_bounds__(NT, row_min_waves<T>()) void k_x_fft(const cx<T>* _
     });
   }
   if (MODE == 1) fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
+  CMBL_XSTAMP(3);
   cx<T>* dst = out + r0 * Nx;
   if (MODE == 1) { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = inv * s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }
   else           { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }
+  CMBL_XSTAMP(4);
 }
 
 }  // namespace cmbl

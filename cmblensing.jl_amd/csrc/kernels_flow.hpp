@@ -16,12 +16,6 @@
 #include "kernels_fft.hpp"
 
 namespace cmbl {
-#ifdef CMBL_STAMPS
-__device__ unsigned long long g_stamps[8192 * 16];
-#define CMBL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = clock64(); } while (0)
-#else
-#define CMBL_STAMP(i) do {} while (0)
-#endif
 
 
 template <typename T> __device__ __forceinline__ T pinv_s(T v) { T r = T(1) / v; return isfinite(r) ? r : T(0); }
