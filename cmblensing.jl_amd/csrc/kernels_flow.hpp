@@ -333,7 +333,7 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
 // ---------------------------------------------------------------------------------------------
 // delta flow (src/lenseflow.jl:176-214), per-(pol,batch) column kernel: does the f part (== k_flow_y_fwd),
 // the delta-f part (== k_adj_y) and writes the spin-adjoint partial products
-//   w1p = L(df) * d/dx f,  w2p = L(df) * d/dy f     (maps, one pair per pol; summed over pol by k_dphi_y)
+//   w1p = L(df) * d/dx f,  w2p = L(df) * d/dy f     (maps, one pair per pol and stage; reduced over pols and stages by k_dphi_reduce)
 template <typename T> struct DeltaYArgs {
   FlowYArgs<T> f;           // f part
   const cx<T>* H; cx<T>* Wx; cx<T>* Wy;   // delta-f part
