@@ -390,7 +390,46 @@ struct Flow {
   DevBuf Wst, U5, F5, tcbuf;              // per-stage partial products, the five reduced maps and their transforms, (t_s, c_s)
   std::vector<T> tc_host;
 
-  Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) { CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range"); }
+  // Slice groups.  At B = 1 a launch over the P pol slices is a single residency wave of workgroups, so it lasts as long as one
+  // workgroup's dependent chain.  The slices' chains are independent until the flow ends, so each slice runs as its own launch
+  // chain on its own stream (slice 0 on the context's stream): the chains drift apart and one's HBM burst overlaps the other's
+  // transforms (measured: L*f 0.82 -> 0.72 ms at 1024^2 QU).  One fork and one join event per flow, none per stage.
+  static constexpr int MAXG = 4;
+  hipStream_t sub[MAXG - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t evFork = nullptr, evJoin[MAXG - 1] = {nullptr, nullptr, nullptr};
+  int max_groups = 1;
+
+  Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) {
+    CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range");
+    max_groups = std::max(1, std::min(MAXG, env_int("CMBL_SLICE_STREAMS", MAXG)));
+    if (max_groups > 1) {
+      CMBL_HIP(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
+      for (int i = 0; i < max_groups - 1; ++i) {
+        CMBL_HIP(hipStreamCreateWithFlags(&sub[i], hipStreamNonBlocking));
+        CMBL_HIP(hipEventCreateWithFlags(&evJoin[i], hipEventDisableTiming));
+      }
+    }
+  }
+  ~Flow() {
+    for (int i = 0; i < MAXG - 1; ++i) {
+      if (sub[i]) { (void)hipStreamSynchronize(sub[i]); (void)hipStreamDestroy(sub[i]); }
+      if (evJoin[i]) (void)hipEventDestroy(evJoin[i]);
+    }
+    if (evFork) (void)hipEventDestroy(evFork);
+  }
+  int groups(int P, int B) const { return (B == 1 && Bphi == 1) ? std::min(P, max_groups) : 1; }   // one slice per group
+  hipStream_t gstream(int g) const { return g == 0 ? c->stream : sub[g - 1]; }
+  void fork(int K) {
+    if (K <= 1) return;
+    CMBL_HIP(hipEventRecord(evFork, c->stream));
+    for (int g = 1; g < K; ++g) CMBL_HIP(hipStreamWaitEvent(sub[g - 1], evFork, 0));
+  }
+  void join(int K) {
+    for (int g = 1; g < K; ++g) {
+      CMBL_HIP(hipEventRecord(evJoin[g - 1], sub[g - 1]));
+      CMBL_HIP(hipStreamWaitEvent(c->stream, evJoin[g - 1], 0));
+    }
+  }
   Flow(const Flow&) = delete;
   Flow& operator=(const Flow&) = delete;
 
@@ -484,23 +523,31 @@ struct Flow {
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
     cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
     c->y_r2c(y, a_cur, slices);
-    const auto tile = c->tileY(slices, true);
+    const int K = groups(P, B);
+    const long gs = slices / K;                                            // slices per group
+    const auto tile = c->tileY(gs, true);
     const double t0 = inverse ? 1.0 : 0.0, h = (inverse ? -1.0 : 1.0) / n;
+    fork(K);
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
-        c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);
-        FlowYArgs<T> a{};
-        a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = y; a.acc = acc.as<T>();
-        a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
-        a.Nx = c->Nx; a.P = P;
-        a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
-        a.ph = ph(a.rk.t);
-        c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
-          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
-          CMBL_LAUNCH_NT(c, K_FLOW_Y, NT, (k_flow_y_fwd<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, a);
-        });
+        for (int g = 0; g < K; ++g) {
+          hipStream_t st = gstream(g);
+          const long so = g * gs;
+          c->template x_pass<2>(a_cur + so * pl, Gx.as<cx<T>>() + so * pl, gs, st);
+          FlowYArgs<T> a{};
+          a.A = a_cur + so * pl; a.Gx = Gx.as<cx<T>>() + so * pl; a.Anext = a_nxt + so * pl; a.y0 = y + so * np; a.acc = acc.as<T>() + so * np;
+          a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
+          a.Nx = c->Nx; a.P = P;
+          a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
+          a.ph = ph(a.rk.t);
+          c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
+            constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+            CMBL_LAUNCH_NT(c, K_FLOW_Y, NT, (k_flow_y_fwd<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)gs), c->ldsY(tile.C), st, a);
+          });
+        }
         std::swap(a_cur, a_nxt);
       }
+    join(K);
   }
 
   // L'*g (inverse=false, t 1->0) or L'\g (inverse=true, t 0->1); F layout, QU-Fourier basis; out may alias in
@@ -511,30 +558,38 @@ struct Flow {
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     c->template x_pass<1>(out, H.as<cx<T>>(), slices);
-    const auto tile = c->tileY(slices, true);
-    const long rows = slices * c->Nyh;
+    const int K = groups(P, B);
+    const long gs = slices / K;
+    const auto tile = c->tileY(gs, true);
+    const long rows = gs * c->Nyh;
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
+    fork(K);
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
         const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
-        AdjYArgs<T> a{};
-        a.H = H.as<cx<T>>(); a.Wx = Wx.as<cx<T>>(); a.Wy = Wy.as<cx<T>>(); a.ph = ph(rk.t);
-        a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
-        a.Nx = c->Nx; a.P = P; a.t = rk.t;
-        c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
-          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
-          CMBL_LAUNCH_NT(c, K_ADJ_Y, NT, (k_adj_y<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, a);
-        });
-        AdjXArgs<T> x{};
-        x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = out; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
-        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.rows = rows; x.rk = rk;
-        c->dispatch_row(c->pickXNT(rows, 1), [&](auto lgnx, auto xnt) {
-          constexpr int XNT = decltype(xnt)::value;
-          const auto rp = c->plan_rows(2, rows);
-          x.RX = rp.cap; x.nblk = rp.nblk;
-          CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)rp.nblk), c->ldsX(rp.cap, 2), c->stream, x);
-        });
+        for (int g = 0; g < K; ++g) {
+          hipStream_t st = gstream(g);
+          const long so = g * gs * pl;
+          AdjYArgs<T> a{};
+          a.H = H.as<cx<T>>() + so; a.Wx = Wx.as<cx<T>>() + so; a.Wy = Wy.as<cx<T>>() + so; a.ph = ph(rk.t);
+          a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
+          a.Nx = c->Nx; a.P = P; a.t = rk.t;
+          c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
+            constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+            CMBL_LAUNCH_NT(c, K_ADJ_Y, NT, (k_adj_y<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)gs), c->ldsY(tile.C), st, a);
+          });
+          AdjXArgs<T> x{};
+          x.Wx = a.Wx; x.Wy = a.Wy; x.Y0 = out + so; x.acc = Yacc.as<cx<T>>() + so; x.Hnext = H.as<cx<T>>() + so;
+          x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.rows = rows; x.rk = rk;
+          c->dispatch_row(c->pickXNT(rows, 1), [&](auto lgnx, auto xnt) {
+            constexpr int XNT = decltype(xnt)::value;
+            const auto rp = c->plan_rows(2, rows);
+            x.RX = rp.cap; x.nblk = rp.nblk;
+            CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)rp.nblk), c->ldsX(rp.cap, 2), st, x);
+          });
+        }
       }
+    join(K);
   }
 
   // delta flow (src/flowops.jl:48,63): state (f [map], df [F, QU-Fourier], dphi [F, S0]); f and df updated in place, dphi written.
@@ -554,13 +609,16 @@ struct Flow {
     cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
     c->y_r2c(f, a_cur, slices);
     c->template x_pass<1>(df, H.as<cx<T>>(), slices);
-    const auto tile = c->tileY(slices, true);
-    const long rows = slices * c->Nyh;
+    const int K = groups(P, B);
+    const long gs = slices / K;
+    const auto tile = c->tileY(gs, true);
+    const long rows = gs * c->Nyh;
     const int RX = c->pickRX(2, rows);
     const int nb_adj = (int)((rows + RX - 1) / RX);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
     c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);                // later d/dx passes ride along with the previous stage's row launch
     tc_host.resize(2 * (size_t)nst);
+    fork(K);
     int it = 0;
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage, ++it) {
@@ -568,29 +626,34 @@ struct Flow {
         const RKCoef<T> rk = coef(step, stage, t0, h, last);
         tc_host[2 * it] = rk.t;
         tc_host[2 * it + 1] = (T)((stage == 1 || stage == 4 ? 1.0 : 2.0) * h / 6);   // RK4 weights (src/numerical_algorithms.jl:20)
-        DeltaYArgs<T> d{};
-        FlowYArgs<T>& a = d.f;
-        a.A = a_cur; a.Gx = Gx.as<cx<T>>(); a.Anext = a_nxt; a.y0 = f; a.acc = acc.as<T>(); a.ph = ph(rk.t);
-        a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
-        a.Nx = c->Nx; a.P = P; a.rk = rk;
-        d.H = H.as<cx<T>>(); d.Wx = Wx.as<cx<T>>(); d.Wy = Wy.as<cx<T>>();
-        d.w1p = Wst.as<T>() + (size_t)(2 * it) * slices * np; d.w2p = d.w1p + (size_t)slices * np;
-        c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
-          constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
-          CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_cols<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)slices), c->ldsY(tile.C), c->stream, d);
-        });
+        for (int g = 0; g < K; ++g) {
+          hipStream_t st = gstream(g);
+          const long so = g * gs, sp = so * pl, sm = so * np;
+          DeltaYArgs<T> d{};
+          FlowYArgs<T>& a = d.f;
+          a.A = a_cur + sp; a.Gx = Gx.as<cx<T>>() + sp; a.Anext = a_nxt + sp; a.y0 = f + sm; a.acc = acc.as<T>() + sm; a.ph = ph(rk.t);
+          a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
+          a.Nx = c->Nx; a.P = P; a.rk = rk;
+          d.H = H.as<cx<T>>() + sp; d.Wx = Wx.as<cx<T>>() + sp; d.Wy = Wy.as<cx<T>>() + sp;
+          d.w1p = Wst.as<T>() + ((size_t)(2 * it) * slices + so) * np; d.w2p = d.w1p + (size_t)slices * np;
+          c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
+            constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+            CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_cols<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)gs), c->ldsY(tile.C), st, d);
+          });
+          // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_nxt holds A_{s+1} after this column launch)
+          AdjXArgs<T> x{};
+          x.Wx = d.Wx; x.Wy = d.Wy; x.Y0 = df + sp; x.acc = Yacc.as<cx<T>>() + sp; x.Hnext = H.as<cx<T>>() + sp;
+          x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.nblk = nb_adj; x.rows = rows; x.rk = rk;
+          GradXArgs<T> gx{a_nxt + sp, Gx.as<cx<T>>() + sp, x.twX, c->dlx_over_Nx, rows, nb_adj};
+          c->dispatch_row(c->pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
+            constexpr int XNT = decltype(xnt)::value;
+            CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, XNT, decltype(lgnx)::value>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))),
+                           c->ldsX(RX, 2), st, x, gx, nb_adj);
+          });
+        }
         std::swap(a_cur, a_nxt);
-        // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_cur already points at A_{s+1})
-        AdjXArgs<T> x{};
-        x.Wx = Wx.as<cx<T>>(); x.Wy = Wy.as<cx<T>>(); x.Y0 = df; x.acc = Yacc.as<cx<T>>(); x.Hnext = H.as<cx<T>>();
-        x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.nblk = nb_adj; x.rows = rows; x.rk = rk;
-        GradXArgs<T> gx{a_cur, Gx.as<cx<T>>(), x.twX, c->dlx_over_Nx, rows, nb_adj};
-        c->dispatch_row(c->pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
-          constexpr int XNT = decltype(xnt)::value;
-          CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, XNT, decltype(lgnx)::value>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))),
-                         c->ldsX(RX, 2), c->stream, x, gx, nb_adj);
-        });
       }
+    join(K);
     // delta-phi: quadrature over the stages, then five real transforms and the l-multipliers
     CMBL_HIP(hipMemcpyAsync(tcbuf.p, tc_host.data(), sizeof(T) * 2 * nst, hipMemcpyHostToDevice, c->stream));
     CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T>), dim3((unsigned)std::min<long>((np / (16 / (long)sizeof(T)) + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
