@@ -180,7 +180,10 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        # roofline of the dominant kernel: per-launch HIP events on the library's stream over a re-run of the same K steps
+        # roofline of the dominant kernel: per-launch HIP events on the library's stream over a re-run of the same K steps.
+        # The timed region above runs each pol slice as its own launch chain on its own stream (concurrent half-size launches have
+        # no individual bandwidth), so this leg switches that off: one launch over all slices, the same kernels.
+        os.environ["CMBL_SLICE_STREAMS"] = "1"
         proj.prof_reset(); proj.prof_enable(True)
         for _ in range(args.steps):
             step()
@@ -195,6 +198,8 @@ def main():
         traffic = measured_traffic(dom, N, P, B)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                            "traffic": traffic, "avg_launch_us": ms / nl * 1e3, "launches_per_step": nl / args.steps,
+                           "note": "per-kernel figures from a re-run with CMBL_SLICE_STREAMS=1 (one launch over all pol slices); "
+                                   "value / ms_per_step / whole_step are the timed region with one launch chain per pol slice",
                            "algorithmic_bytes_per_launch": bytes_per_launch,
                            "kernel_time_share": ms / tot,
                            "whole_step": {"algorithmic_GB": ab["grad_lnP"] / 1e9,

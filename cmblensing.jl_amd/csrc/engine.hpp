@@ -401,7 +401,7 @@ struct Flow {
 
   Flow(Ctx<T>* ctx, int nsteps) : c(ctx), n(nsteps) {
     CMBL_REQUIRE(nsteps >= 1 && nsteps <= 512, ERR_ARG, "nsteps out of range");
-    max_groups = std::max(1, std::min(MAXG, env_int("CMBL_SLICE_STREAMS", MAXG)));
+    max_groups = MAXG;
     if (max_groups > 1) {
       CMBL_HIP(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
       for (int i = 0; i < max_groups - 1; ++i) {
@@ -417,7 +417,8 @@ struct Flow {
     }
     if (evFork) (void)hipEventDestroy(evFork);
   }
-  int groups(int P, int B) const { return (B == 1 && Bphi == 1) ? std::min(P, max_groups) : 1; }   // one slice per group
+  // one slice per group; CMBL_SLICE_STREAMS is re-read per call so a profiler can switch the splitting off (bench.py roofline leg)
+  int groups(int P, int B) const { return (B == 1 && Bphi == 1) ? std::min(P, std::min(max_groups, env_int("CMBL_SLICE_STREAMS", MAXG))) : 1; }
   hipStream_t gstream(int g) const { return g == 0 ? c->stream : sub[g - 1]; }
   void fork(int K) {
     if (K <= 1) return;
