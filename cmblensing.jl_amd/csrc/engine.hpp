@@ -166,7 +166,10 @@ struct Ctx : CtxBase {
   // NT threads and R packed pairs per thread.
   // CMBL_TUNE_C forces a width, CMBL_TUNE_RX the rows per workgroup of the row kernels (tuning aids).
   struct TileY { int C, NT, R; };
+  mutable TileY tile_cache[2] = {{0, 0, 0}, {0, 0, 0}};       // the choice does not depend on `slices`: made once (host launch path)
+  const int tuneC = env_int("CMBL_TUNE_C", 0), tuneNT = env_int("CMBL_TUNE_NT", 0), tuneRX = env_int("CMBL_TUNE_RX", 0);
   TileY tileY(long slices, bool pair, int preferNT = 0) const {
+    if (preferNT == 0 && tile_cache[pair].C > 0) return tile_cache[pair];
     static const int list[][3] = {
 #define CMBL_X(lgm, r, nt) {lgm, r, nt},
         CMBL_COL_LIST(CMBL_X)
@@ -174,7 +177,7 @@ struct Ctx : CtxBase {
     };
     // Measured on MI355X (1024^2, B = 1..8): the kernels are bound by resident waves per CU (register file), not by segment
     // width, so the narrowest tile with C >= 4 wins, 512 threads when compiled (more waves per tile, fewer registers per thread).
-    const int forceC = env_int("CMBL_TUNE_C", 0), forceNT = env_int("CMBL_TUNE_NT", 0);
+    const int forceC = tuneC, forceNT = tuneNT;
     TileY best{0, 0, 0};
     long bestScore = -1;
     for (const auto& e : list) {
@@ -182,18 +185,19 @@ struct Ctx : CtxBase {
       const int C = (int)(((long)e[1] * e[2]) >> lgM);
       if (C > Nx || ldsY(C, pair) > 160 * 1024) continue;
       const TileY t{C, e[2], e[1]};
-      if (forceC == C && (forceNT == 0 || forceNT == e[2])) return t;
+      if (forceC == C && (forceNT == 0 || forceNT == e[2])) { if (preferNT == 0) tile_cache[pair] = t; return t; }
       const long score = (C >= 4 ? 1000 - C : C) * 10 + (e[2] == preferNT ? 3 : (e[2] == 512 ? 2 : (e[2] == 256 ? 1 : 0)));
       if (score > bestScore) { bestScore = score; best = t; }
     }
     (void)slices;
     CMBL_REQUIRE(best.C > 0, ERR_SHAPE, "no compiled column-tile shape fits this Ny / precision");
+    if (preferNT == 0) tile_cache[pair] = best;
     return best;
   }
   // column tile: twiddles + C columns of an N-point (pair) or M-point (packed) transform, padded rows
   size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
   int pickRX(int nbuf, long rows) const {
-    int RX = env_int("CMBL_TUNE_RX", 0);
+    int RX = tuneRX;
     if (RX <= 0) RX = (int)std::max<long>(1, std::min<long>(4096 / ((long)nbuf * Nx), rows / 1024));
     RX = std::max(RX, (int)((64 * 4 + Nx - 1) / Nx));                   // keep every lane of a wave busy in a radix-4 stage
     while (RX > 1 && ldsX(RX, nbuf) > 160 * 1024) RX >>= 1;
@@ -418,7 +422,12 @@ struct Flow {
     if (evFork) (void)hipEventDestroy(evFork);
   }
   // one slice per group; CMBL_SLICE_STREAMS is re-read per call so a profiler can switch the splitting off (bench.py roofline leg)
-  int groups(int P, int B) const { return (B == 1 && Bphi == 1) ? std::min(P, std::min(max_groups, env_int("CMBL_SLICE_STREAMS", MAXG))) : 1; }
+  // Only where a launch is long enough (>= ~10 us: 2^20 pixels) for the host to keep several chains fed -- a launch costs the host
+  // ~4 us, and at 512^2 the kernels last 7 us, so splitting there makes the flow host-bound (measured: 512^2 L*f 0.41 -> 0.52 ms).
+  int groups(int P, int B) const {
+    if (B != 1 || Bphi != 1 || c->npix() < env_int("CMBL_SLICE_STREAMS_MIN_PIX", 1 << 20)) return 1;
+    return std::min(P, std::min(max_groups, env_int("CMBL_SLICE_STREAMS", MAXG)));
+  }
   hipStream_t gstream(int g) const { return g == 0 ? c->stream : sub[g - 1]; }
   void fork(int K) {
     if (K <= 1) return;

@@ -44,7 +44,7 @@ s3 = C.load_sim(2.0, 1024, "IP", cls, T=torch.float32, pixel_mask=dict(pad_deg=1
 ds3 = s3["ds"]
 ds3.host["Nphi"] = C.quadratic_estimate(ds3, "EB")["Nphi"] / 2
 fo, po = ds3.mix(s3["f"], s3["phi"])
-t_g = timeit(lambda: ds3.gradient_logpdf_mixed(fo, po), 3)
+t_g = timeit(lambda: ds3.gradient_logpdf_mixed(fo, po), 10, 3)
 ab = algorithmic_bytes(1024, 3, 1, 1, 7, 4)
 t = time.time(); st = C.MAP_joint_step(ds3, C.Field(s3["proj"], torch.zeros_like(s3["phi"].arr), C.FOURIER), cg_nsteps=100); torch.cuda.synchronize(); dt = time.time() - t
 print(f"config 3 (1024² IQU fp32): ∇lnP {t_g:.3f} ms ({ab['grad_lnP']/t_g/1e6:.0f} GB/s alg.); one MAP_joint step (CG {len(st['cg_hist'])} its, line search {st['linesearch_evals']} evals): {dt*1e3:.0f} ms")
