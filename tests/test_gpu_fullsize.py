@@ -90,3 +90,37 @@ def test_fullsize_posterior_step():
         fdp = fd5(lambda a: float(ds.logpdf_mixed(fo, proj.axpby(1.0, po, a, dphil))[0]))
         err[n] = abs(float(gp.dot(dphil)[0]) - fdp) / abs(fdp)
     assert err[14] < 0.03 and err[14] < err[7] / 8, err
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_slice_streams_give_identical_results(P):
+    """At B = 1 each pol slice runs as its own launch chain on its own stream (Flow::groups); the slices are independent, so the
+    results must be bit-identical to one launch over all slices (CMBL_SLICE_STREAMS=1) -- any difference would be a race."""
+    import os
+    import cmblensing_jl_amd as C
+    proj = C.ProjLambert(1024, 1024, 2.0, torch.float32, 0)
+    f, g, phi, _ = _fields(C, proj, P)
+    L = C.LenseFlow(proj, 7)
+    L(phi)
+    gl = g.to(C.FOURIER)
+    def run():
+        a = L * f
+        b = L.ldiv(f)
+        c = L.adjoint * gl
+        dphi, df, fs = L.gradient(C.FLOW_FWD, a, gl)
+        torch.cuda.synchronize()
+        return [x.arr.clone() for x in (a, b, c, dphi, df, fs)]
+    old = os.environ.get("CMBL_SLICE_STREAMS")
+    try:
+        os.environ.pop("CMBL_SLICE_STREAMS", None)
+        r_split = [run() for _ in range(3)]
+        os.environ["CMBL_SLICE_STREAMS"] = "1"
+        r_one = run()
+    finally:
+        if old is None:
+            os.environ.pop("CMBL_SLICE_STREAMS", None)
+        else:
+            os.environ["CMBL_SLICE_STREAMS"] = old
+    for r in r_split:
+        for x, y in zip(r, r_one):
+            assert torch.equal(x, y)
