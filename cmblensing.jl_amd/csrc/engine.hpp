@@ -258,6 +258,15 @@ struct Ctx : CtxBase {
       CMBL_LAUNCH_NT(this, K_Y_C2R, NT, (k_y_c2r<T, R, NT, LGM>), dim3(Nx / t.C, (unsigned)slices), ldsY(t.C, false), stream, mixed, map, twY.as<cx<T>>(), Nx, (T)(1.0 / Ny));
     });
   }
+  // mixed -> (map x mask) -> mixed, for the pixel-mask sandwich (in place allowed)
+  void y_mask(const cx<T>* in, cx<T>* out, const T* mask, long slices) {
+    const TileY t = tileY(slices, false);
+    dispatch_col(t, [&](auto lgm, auto r, auto nt) {
+      constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+      CMBL_LAUNCH_NT(this, K_MASK, NT, (k_y_mask<T, R, NT, LGM>), dim3(Nx / t.C, (unsigned)slices), ldsY(t.C, false), stream, in, out, mask, twY.as<cx<T>>(), Nx,
+                     (T)(1.0 / Ny));
+    });
+  }
   template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices, hipStream_t st = nullptr) {
     if (!st) st = stream;
     const long rows = slices * Nyh;
@@ -767,18 +776,13 @@ struct Dataset {
   void apply_M(cx<T>* x, int B, bool transpose) {
     const long sl = (long)P * B;
     if (!has(OP_MPIX)) { apply(OP_MF, x, x, B, transpose); return; }
-    mp.ensure(sizeof(T) * sl * c->npix());
     if (!transpose) {
       c->harm(x, x, P, B, 0, nullptr, false, false, true);                 // -> QU Fourier
-      c->template x_pass<1>(x, x, sl); c->y_c2r(x, mp.template as<T>(), sl);
-      c->mask_mul(mp.template as<T>(), mp.template as<T>(), ops[OP_MPIX].d[0], sl);
-      c->rfft2_F(mp.template as<T>(), x, sl);
+      c->template x_pass<1>(x, x, sl); c->y_mask(x, x, ops[OP_MPIX].d[0], sl); c->template x_pass<0>(x, x, sl);
       apply(OP_MF, x, x, B, false, true, false);
     } else {
       apply(OP_MF, x, x, B, true, false, true);
-      c->template x_pass<1>(x, x, sl); c->y_c2r(x, mp.template as<T>(), sl);
-      c->mask_mul(mp.template as<T>(), mp.template as<T>(), ops[OP_MPIX].d[0], sl);
-      c->rfft2_F(mp.template as<T>(), x, sl);
+      c->template x_pass<1>(x, x, sl); c->y_mask(x, x, ops[OP_MPIX].d[0], sl); c->template x_pass<0>(x, x, sl);
       c->harm(x, x, P, B, 0, nullptr, false, true, false);
     }
   }

@@ -290,6 +290,43 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
   }
 }
 
+// y pass of the pixel-mask sandwich  rfft2( m .* irfft2(x) )  (M = Mfourier * Mpix, src/dataset.jl:279-285): mixed -> map (in LDS /
+// registers only) -> x mask -> mixed.  One launch and no HBM round trip for the map instead of y_c2r, mask multiply, y_r2c.
+template <typename T, int R, int NT, int LGM>
+__global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, const T* __restrict__ mask,
+                                               const cx<T>* __restrict__ twY, int Nx, T scale) {
+  using G = ColTile<R, NT, LGM>;
+  constexpr int M = G::M, LD = G::LDM, C = G::C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* s = tw + M;
+  const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
+  const size_t sl = blockIdx.y;
+  TwStage<T, NT, M> twr;
+  TileStage<T, NT, LGM, G::LGC> tl;
+  twr.issue(twY);
+  tl.issue(in + sl * (size_t)G::Nyh * Nx, Nx, x0);
+  const cx<T>* mk2 = reinterpret_cast<const cx<T>*>(mask) + (size_t)x0 * M;       // the mask is one (Nx, Ny) map for all slices
+  cx<T> mv[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) mv[i] = mk2[threadIdx.x + i * NT];
+  twr.commit(tw);
+  tl.template commit<LD>(s);
+  __syncthreads();
+  c2r_pre<T, NT, LD, LGM>(s, C, tw);
+  fft_dit<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
+#pragma unroll
+  for (int i = 0; i < R; ++i) {                       // each thread scales the packed pairs it owns: same slots read and written
+    const int e = threadIdx.x + i * NT, c = e >> LGM, j = e & (M - 1);
+    const cx<T> v = s[c * LD + pad(j)];
+    s[c * LD + pad(j)] = mk<T>(scale * mv[i].x * v.x, scale * mv[i].y * v.y);
+  }
+  __syncthreads();
+  fft_dif<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
+  r2c_post<T, NT, LD, LGM>(s, C, tw);
+  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)G::Nyh * Nx, Nx, x0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // x pass on contiguous rows.  `rows` = slices*Nyh rows of Nx.  grid nblk.  LDS: twX[Nx/2] + ceil(rows/nblk)*tile_ld(Nx) cplx
 //   MODE 0: forward  (mixed -> F)
