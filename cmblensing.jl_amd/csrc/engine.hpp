@@ -808,12 +808,12 @@ struct Dataset {
     if (f_h) {
       mean(L, f_h, r, B);
       if (dd) c->lincomb1((T*)r, (const T*)dd, (const T*)r, 1.0, -1.0, 2 * n / B, B);
-      else c->lincomb1((T*)r, (const T*)r, nullptr, -1.0, 0.0, 2 * n / B, B);
     } else {
       CMBL_REQUIRE(dd != nullptr, ERR_ARG, "gradientf with f = 0 and d = 0 is identically zero");
       CMBL_HIP(hipMemcpyAsync(r, dd, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
     }
-    apply(OP_CN_INV, r, r, B);
+    if (f_h && !dd) apply(OP_CN_INV, r, r, B, false, false, false, nullptr, 0, (T)-1);       // d = 0: the sign of -(M B L f) rides along
+    else apply(OP_CN_INV, r, r, B);
     apply_M(r, B, true);
     apply(OP_B, r, r, B, true, false, true);                               // -> QU Fourier
     L.flow_adj_F(r, r, P, B, false);
