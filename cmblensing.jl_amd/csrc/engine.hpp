@@ -433,10 +433,18 @@ struct Flow {
   // one slice per group; CMBL_SLICE_STREAMS is re-read per call so a profiler can switch the splitting off (bench.py roofline leg)
   // Only where a launch is long enough (>= ~10 us: 2^20 pixels) for the host to keep several chains fed -- a launch costs the host
   // ~4 us, and at 512^2 the kernels last 7 us, so splitting there makes the flow host-bound (measured: 512^2 L*f 0.41 -> 0.52 ms).
+  // B = 1: one pol slice per group.  B > 1: groups of whole batch slots (K = the largest divisor of B that fits), so that a group's
+  // phi slots are contiguous (phi_off) -- fewer, larger launches per chain, still several chains in flight.
   int groups(int P, int B) const {
-    if (B != 1 || Bphi != 1 || c->npix() < env_int("CMBL_SLICE_STREAMS_MIN_PIX", 1 << 20)) return 1;
-    return std::min(P, std::min(max_groups, env_int("CMBL_SLICE_STREAMS", MAXG)));
+    if (c->npix() < env_int("CMBL_SLICE_STREAMS_MIN_PIX", 1 << 20)) return 1;
+    const int cap = std::min(max_groups, env_int("CMBL_SLICE_STREAMS", MAXG));
+    if (B == 1) return Bphi == 1 ? std::min(P, cap) : 1;
+    // measured at 1024^2 QU: B = 2 -> 2 chains +6 %; B = 4: 2 chains 262 evaluations/s, 4 chains 240, 1 chain 247; B = 8: 266 vs 258
+    for (int k = std::min(cap, B >= 4 ? 2 : B); k > 1; --k) if (B % k == 0) return k;
+    return 1;
   }
+  // batch-slot offset of group g's phi maps (0 when one phi is shared by all slots)
+  long phi_off(int g, int K, int B) const { return (B > 1 && Bphi > 1) ? (long)g * (B / K) : 0; }
   hipStream_t gstream(int g) const { return g == 0 ? c->stream : sub[g - 1]; }
   void fork(int K) {
     if (K <= 1) return;
@@ -453,13 +461,13 @@ struct Flow {
   Flow& operator=(const Flow&) = delete;
 
   // t < 0: no stage time (the five maps only); otherwise p(t) is also taken from the cache when it exists
-  PhiMaps<T> ph(double t = -1) const {
-    const size_t s = (size_t)Bphi * c->npix();
-    const T* b = phimaps.as<T>();
+  PhiMaps<T> ph(double t = -1, long boff = 0) const {
+    const size_t s = (size_t)Bphi * c->npix(), o = (size_t)boff * c->npix();
+    const T* b = phimaps.as<T>() + o;
     PhiMaps<T> r{b, b + s, b + 2 * s, b + 3 * s, b + 4 * s, Bphi, nullptr, nullptr};
     if (t >= 0 && use_pcache) {
       const int k = (int)std::lround(t * 2 * n);
-      r.pcx = pcache.as<T>() + (size_t)(2 * k) * s; r.pcy = r.pcx + s;
+      r.pcx = pcache.as<T>() + (size_t)(2 * k) * s + o; r.pcy = r.pcx + s;
     }
     return r;
   }
@@ -558,7 +566,7 @@ struct Flow {
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
           a.Nx = c->Nx; a.P = P;
           a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
-          a.ph = ph(a.rk.t);
+          a.ph = ph(a.rk.t, phi_off(g, K, B));
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
             constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
             CMBL_LAUNCH_NT(c, K_FLOW_Y, NT, (k_flow_y_fwd<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)gs), c->ldsY(tile.C), st, a);
@@ -590,7 +598,7 @@ struct Flow {
           hipStream_t st = gstream(g);
           const long so = g * gs * pl;
           AdjYArgs<T> a{};
-          a.H = H.as<cx<T>>() + so; a.Wx = Wx.as<cx<T>>() + so; a.Wy = Wy.as<cx<T>>() + so; a.ph = ph(rk.t);
+          a.H = H.as<cx<T>>() + so; a.Wx = Wx.as<cx<T>>() + so; a.Wy = Wy.as<cx<T>>() + so; a.ph = ph(rk.t, phi_off(g, K, B));
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
           a.Nx = c->Nx; a.P = P; a.t = rk.t;
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
@@ -650,7 +658,7 @@ struct Flow {
           const long so = g * gs, sp = so * pl, sm = so * np;
           DeltaYArgs<T> d{};
           FlowYArgs<T>& a = d.f;
-          a.A = a_cur + sp; a.Gx = Gx.as<cx<T>>() + sp; a.Anext = a_nxt + sp; a.y0 = f + sm; a.acc = acc.as<T>() + sm; a.ph = ph(rk.t);
+          a.A = a_cur + sp; a.Gx = Gx.as<cx<T>>() + sp; a.Anext = a_nxt + sp; a.y0 = f + sm; a.acc = acc.as<T>() + sm; a.ph = ph(rk.t, phi_off(g, K, B));
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
           a.Nx = c->Nx; a.P = P; a.rk = rk;
           d.H = H.as<cx<T>>() + sp; d.Wx = Wx.as<cx<T>>() + sp; d.Wy = Wy.as<cx<T>>() + sp;

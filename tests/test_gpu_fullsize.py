@@ -92,14 +92,17 @@ def test_fullsize_posterior_step():
     assert err[14] < 0.03 and err[14] < err[7] / 8, err
 
 
-@pytest.mark.parametrize("P", [2, 3])
-def test_slice_streams_give_identical_results(P):
-    """At B = 1 each pol slice runs as its own launch chain on its own stream (Flow::groups); the slices are independent, so the
-    results must be bit-identical to one launch over all slices (CMBL_SLICE_STREAMS=1) -- any difference would be a race."""
+@pytest.mark.parametrize("P,B,Bphi", [(2, 1, 1), (3, 1, 1), (2, 2, 2), (1, 4, 1), (2, 3, 3)])
+def test_slice_streams_give_identical_results(P, B, Bphi):
+    """Pol slices (B = 1) or groups of batch slots (B > 1) run as separate launch chains on separate streams (Flow::groups); they are
+    independent, so the results must be bit-identical to one launch over all slices (CMBL_SLICE_STREAMS=1) -- any difference would
+    be a race or a wrong phi-slot offset."""
     import os
     import cmblensing_jl_amd as C
     proj = C.ProjLambert(1024, 1024, 2.0, torch.float32, 0)
-    f, g, phi, _ = _fields(C, proj, P)
+    f, g, phi, _ = _fields(C, proj, P, B=B)
+    if Bphi != B:
+        phi = C.Field(proj, phi.arr[:Bphi].contiguous(), phi.basis)
     L = C.LenseFlow(proj, 7)
     L(phi)
     gl = g.to(C.FOURIER)
