@@ -438,7 +438,7 @@ struct Flow {
   int groups(int P, int B) const {
     if (c->npix() < env_int("CMBL_SLICE_STREAMS_MIN_PIX", 1 << 20)) return 1;
     const int cap = std::min(max_groups, env_int("CMBL_SLICE_STREAMS", MAXG));
-    if (B == 1) return Bphi == 1 ? std::min(P, cap) : 1;
+    if (B == 1) { if (Bphi == 1) for (int k = std::min(P, cap); k > 1; --k) if (P % k == 0) return k; return 1; }
     // measured at 1024^2 QU: B = 2 -> 2 chains +6 %; B = 4: 2 chains 262 evaluations/s, 4 chains 240, 1 chain 247; B = 8: 266 vs 258
     for (int k = std::min(cap, B >= 4 ? 2 : B); k > 1; --k) if (B % k == 0) return k;
     return 1;
