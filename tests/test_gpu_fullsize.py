@@ -127,3 +127,29 @@ def test_slice_streams_give_identical_results(P, B, Bphi):
     for r in r_split:
         for x, y in zip(r, r_one):
             assert torch.equal(x, y)
+
+
+def test_p_cache_matches_on_the_fly_p():
+    """p(t) from the per-phi cache (k_pcache) against p(t) formed in the kernels from the five phi maps: the same formula (the
+    compiler contracts multiply-adds differently in the two kernels, so agreement is to rounding, not to the bit)"""
+    import os
+    import cmblensing_jl_amd as C
+    proj = C.ProjLambert(256, 512, 2.0, torch.float32, 0)
+    f, g, phi, _ = _fields(C, proj, 2)
+    gl = g.to(C.FOURIER)
+    def run():
+        L = C.LenseFlow(proj, 7)
+        L(phi)
+        a = L * f
+        dphi, df, fs = L.gradient(C.FLOW_FWD, a, gl)
+        c = L.adjoint * gl
+        torch.cuda.synchronize()
+        return [x.arr.clone() for x in (a, c, dphi, df, fs)]
+    try:
+        os.environ["CMBL_NO_PCACHE"] = "1"
+        r0 = run()
+    finally:
+        os.environ.pop("CMBL_NO_PCACHE", None)
+    r1 = run()
+    for x, y in zip(r0, r1):
+        assert float((x - y).abs().max() / y.abs().max()) < 2e-6
