@@ -60,6 +60,19 @@ template <typename T> static void do_dot(cmbl_ctx* ctx, int basis, const void* a
   c->ref2F((const cx<T>*)a, Fa, sl); c->ref2F((const cx<T>*)b, Fb, sl);
   c->dot_F(Fa, Fb, P, B, out);
 }
+// logdet / tr of Diagonal(field): which = 0 logdet, 1 tr
+template <typename T> static void do_diag_reduce(cmbl_ctx* ctx, int which, int basis, const void* d, int P, int B, double* out) {
+  Ctx<T>* c = C<T>(ctx);
+  if (basis == B_MAP) {
+    if (which == 0) c->logdet_map((const T*)d, P, B, out); else c->tr_map((const T*)d, P, B, out);
+    return;
+  }
+  const long sl = (long)P * B;
+  c->tmpA.ensure(sizeof(cx<T>) * sl * c->plane());
+  cx<T>* F = c->tmpA.template as<cx<T>>();
+  c->ref2F((const cx<T>*)d, F, sl);                    // the lam-weighted sums are invariant under the internal permutation of x
+  if (which == 0) c->logdet_Fc(F, P, B, out); else c->tr_Fc(F, P, B, out);
+}
 template <typename T> static void do_logdet(cmbl_ctx* ctx, const void* d, int nplanes, double* out) {
   Ctx<T>* c = C<T>(ctx);
   c->tmpB.ensure(sizeof(T) * nplanes * c->plane());
@@ -145,6 +158,40 @@ int cmbl_prof_get(cmbl_ctx* ctx, int k, double* total_ms, long* launches) {
   });
 }
 
+int cmbl_timer_report(cmbl_ctx* ctx, char* buf, size_t buflen) {
+  int need = 0;
+  const int rc = guard([&] {
+    NOTNULL(ctx);
+    ctx->p->prof_collect();
+    std::string r = "kernel_class launches total_ms mean_us\n";
+    for (int k = 0; k < K_COUNT; ++k) {
+      if (!ctx->p->prof_n[k]) continue;
+      char line[160];
+      std::snprintf(line, sizeof line, "%s %ld %.6f %.3f\n", kKernelNames[k], ctx->p->prof_n[k], ctx->p->prof_ms[k], 1e3 * ctx->p->prof_ms[k] / ctx->p->prof_n[k]);
+      r += line;
+    }
+    need = (int)r.size();
+    if (buf && buflen) { const size_t m = std::min(buflen - 1, r.size()); std::memcpy(buf, r.data(), m); buf[m] = 0; }
+  });
+  return rc == CMBL_OK ? need : -rc;
+}
+int cmbl_device_malloc(size_t bytes, void** out) {
+  return guard([&] { NOTNULL(out); hipError_t e = hipMalloc(out, bytes); if (e != hipSuccess) { *out = nullptr; fail(ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e)); } });
+}
+int cmbl_device_free(void* p) { return guard([&] { if (p) CMBL_HIP(hipFree(p)); }); }
+int cmbl_copy_to_device(cmbl_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(dst); NOTNULL(src);
+    CMBL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->p->stream)); CMBL_HIP(hipStreamSynchronize(ctx->p->stream));
+  });
+}
+int cmbl_copy_to_host(cmbl_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(dst); NOTNULL(src);
+    CMBL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->p->stream)); CMBL_HIP(hipStreamSynchronize(ctx->p->stream));
+  });
+}
+
 int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out, size_t n) {
   return guard([&] {
     NOTNULL(ctx); NOTNULL(out);
@@ -188,6 +235,30 @@ int cmbl_dot(cmbl_ctx* ctx, int basis, const void* a, const void* b, int P, int 
   return guard([&] {
     NOTNULL(ctx); NOTNULL(a); NOTNULL(b); NOTNULL(out); BASIS_OK(basis); POLB_OK(P, B);
     BY_DTYPE(ctx, do_dot<float>(ctx, basis, a, b, P, B, out), do_dot<double>(ctx, basis, a, b, P, B, out));
+  });
+}
+int cmbl_norm(cmbl_ctx* ctx, int basis, const void* a, int P, int B, double* out) {
+  const int rc = cmbl_dot(ctx, basis, a, a, P, B, out);
+  if (rc == CMBL_OK) for (int i = 0; i < B; ++i) out[i] = std::sqrt(out[i]);
+  return rc;
+}
+int cmbl_logdet_diag(cmbl_ctx* ctx, int basis, const void* d, int P, int B, double* out) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(d); NOTNULL(out); BASIS_OK(basis); POLB_OK(P, B);
+    BY_DTYPE(ctx, do_diag_reduce<float>(ctx, 0, basis, d, P, B, out), do_diag_reduce<double>(ctx, 0, basis, d, P, B, out));
+  });
+}
+int cmbl_tr_diag(cmbl_ctx* ctx, int basis, const void* d, int P, int B, double* out) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(d); NOTNULL(out); BASIS_OK(basis); POLB_OK(P, B);
+    BY_DTYPE(ctx, do_diag_reduce<float>(ctx, 1, basis, d, P, B, out), do_diag_reduce<double>(ctx, 1, basis, d, P, B, out));
+  });
+}
+int cmbl_set_sum_accuracy_mode(cmbl_ctx* ctx, int mode) {
+  return guard([&] {
+    NOTNULL(ctx);
+    CMBL_REQUIRE(mode == CMBL_SUM_WORKING || mode == CMBL_SUM_FLOAT64 || mode == CMBL_SUM_KAHAN, ERR_ARG, "mode must be CMBL_SUM_WORKING, _FLOAT64 or _KAHAN");
+    ctx->p->sum_mode = mode;
   });
 }
 int cmbl_logdet(cmbl_ctx* ctx, const void* d, int nplanes, double* out) {

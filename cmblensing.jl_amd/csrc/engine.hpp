@@ -5,6 +5,7 @@
 #include <cmath>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <type_traits>
 #include <cstdlib>
 #include "kernels_fft.hpp"
@@ -16,9 +17,13 @@ namespace cmbl {
 enum Basis { B_MAP = 0, B_FOURIER = 1, B_HARMONIC = 2 };
 enum FlowMode { F_FWD = 0, F_INV = 1, F_ADJ = 2, F_INVADJ = 3 };
 
+// hipFuncSetAttribute is per function, process-wide: the table is shared by all contexts, hence the lock (independent contexts
+// may be driven from different host threads)
 inline void raise_lds_limit(const void* fn, size_t bytes) {
   static std::map<const void*, size_t> done;
+  static std::mutex mtx;
   if (bytes <= 48 * 1024) return;
+  std::lock_guard<std::mutex> lock(mtx);
   auto it = done.find(fn);
   if (it != done.end() && it->second >= bytes) return;
   CMBL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -54,6 +59,7 @@ inline int env_int(const char* name, int dflt) { const char* v = std::getenv(nam
 
 struct CtxBase {
   int Ny = 0, Nx = 0, Nyh = 0, M = 0, lgM = 0, lgNx = 0, dtype = 0, device = 0, num_cus = 256;
+  int sum_mode = 1;                       // SUM_FLOAT64 (see kernels_pointwise.hpp; the reference's default is SUM_WORKING)
   double theta = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -152,7 +158,7 @@ struct Ctx : CtxBase {
     for (int k = 0; k < M; ++k) { double a = -2.0 * M_PI * k / Ny; ty[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
     for (int k = 0; k < Nx / 2; ++k) { double a = -2.0 * M_PI * k / Nx; tx[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
     upload(twY, ty); upload(twX, tx); upload(lx_r, lxr); upload(ly, lyv); upload(lam, lamv); upload(cos2F, c2F); upload(sin2F, s2F);
-    red_part.ensure(sizeof(double) * RED_BLOCKS * 64);
+    red_part.ensure(sizeof(double) * RED_BLOCKS * 64 * 2);
     red_out.ensure(sizeof(double) * 64);
   }
   template <typename V> void upload(DevBuf& b, const std::vector<V>& v) {
@@ -315,25 +321,60 @@ struct Ctx : CtxBase {
     CMBL_LAUNCH(this, K_MASK, (k_mask_mul<T>), dim3(gx, (unsigned)slices), 0, stream, out, in, m, npix());
   }
 
-  // per-batch reductions -> host doubles (synchronises the stream)
-  void finish_reduce(int B, double scale, double* out_host) {
-    CMBL_LAUNCH(this, K_REDUCE, k_reduce_final, dim3(B), 0, stream, red_part.as<double>(), red_out.as<double>(), RED_BLOCKS, scale);
-    CMBL_HIP(hipMemcpyAsync(out_host, red_out.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream));
+  // ---- per-batch reductions (src/proj_lambert.jl:318-353) ----------------------------------------------------------------
+  // reduce_dev: two launches, the B results land in `out_dev` (device doubles); nothing synchronises.  `sum_mode` selects the
+  // accumulation (set_sum_accuracy_mode!, src/util.jl:288-316).
+  template <typename F> void reduce_dev(const F& f, long n, int B, double scale, double* out_dev) {
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    switch (sum_mode) {
+#define CMBL_X(M)                                                                                                                     \
+      case M:                                                                                                                         \
+        CMBL_LAUNCH(this, K_REDUCE, (k_reduce_terms<T, M, F>), dim3(RED_BLOCKS, B), 0, stream, f, red_part.as<double>(), n);           \
+        CMBL_LAUNCH(this, K_REDUCE, (k_reduce_final<T, M>), dim3(B), 0, stream, red_part.as<double>(), out_dev, RED_BLOCKS, scale);    \
+        break;
+      CMBL_X(SUM_WORKING) CMBL_X(SUM_FLOAT64) CMBL_X(SUM_KAHAN)
+#undef CMBL_X
+      default: fail(ERR_ARG, "bad sum accuracy mode");
+    }
+  }
+  void fetch(double* out_host, const double* dev, int B) {
+    CMBL_HIP(hipMemcpyAsync(out_host, dev, sizeof(double) * B, hipMemcpyDeviceToHost, stream));
     CMBL_HIP(hipStreamSynchronize(stream));
   }
+  void dot_F_dev(const cx<T>* a, const cx<T>* b, int P, int B, double* out_dev) {
+    reduce_dev(TermDotF<T>{a, b, lam.as<T>(), (long)P * plane(), lgNx, Nyh}, (long)P * plane(), B, 1.0 / ((double)Ny * Nx), out_dev);
+  }
   void dot_F(const cx<T>* a, const cx<T>* b, int P, int B, double* out_host) {
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
-    CMBL_LAUNCH(this, K_REDUCE, (k_dot_F<T>), dim3(RED_BLOCKS, B), 0, stream, a, b, lam.as<T>(), red_part.as<double>(), (long)P * plane(), lgNx, Nyh);
-    finish_reduce(B, 1.0 / ((double)Ny * Nx), out_host);
+    dot_F_dev(a, b, P, B, red_out.as<double>()); fetch(out_host, red_out.as<double>(), B);
   }
   void dot_map(const T* a, const T* b, int P, int B, double* out_host) {
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
-    CMBL_LAUNCH(this, K_REDUCE, (k_dot_map<T>), dim3(RED_BLOCKS, B), 0, stream, a, b, red_part.as<double>(), (long)P * npix());
-    finish_reduce(B, 1.0, out_host);
+    reduce_dev(TermDotMap<T>{a, b, (long)P * npix()}, (long)P * npix(), B, 1.0, red_out.as<double>());
+    fetch(out_host, red_out.as<double>(), B);
   }
+  // logdet of real operator planes in F layout (all planes of one operator: one "batch slot")
   void logdet_F(const T* d, int nplanes, double* out_host) {
-    CMBL_LAUNCH(this, K_REDUCE, (k_logdet_F<T>), dim3(RED_BLOCKS, 1), 0, stream, d, lam.as<T>(), red_part.as<double>(), (long)nplanes * plane(), lgNx, Nyh);
-    finish_reduce(1, 1.0, out_host);
+    reduce_dev(TermLogdetF<T>{d, lam.as<T>(), (long)nplanes * plane(), lgNx, Nyh}, (long)nplanes * plane(), 1, 1.0, red_out.as<double>());
+    fetch(out_host, red_out.as<double>(), 1);
+  }
+  // logdet / tr of Diagonal(field): complex Fourier field in F layout, or real map
+  void logdet_Fc(const cx<T>* d, int P, int B, double* out_host) {
+    reduce_dev(TermLogdetFc<T>{d, lam.as<T>(), (long)P * plane(), lgNx, Nyh}, (long)P * plane(), B, 1.0, red_out.as<double>());
+    fetch(out_host, red_out.as<double>(), B);
+  }
+  void tr_Fc(const cx<T>* d, int P, int B, double* out_host) {
+    reduce_dev(TermTrFc<T>{d, lam.as<T>(), (long)P * plane(), lgNx, Nyh}, (long)P * plane(), B, 1.0, red_out.as<double>());
+    fetch(out_host, red_out.as<double>(), B);
+  }
+  void tr_map(const T* d, int P, int B, double* out_host) {
+    reduce_dev(TermTrMap<T>{d, (long)P * npix()}, (long)P * npix(), B, 1.0, red_out.as<double>());
+    fetch(out_host, red_out.as<double>(), B);
+  }
+  void logdet_map(const T* d, int P, int B, double* out_host) {
+    const long n = (long)P * npix();
+    reduce_dev(TermLogAbsMap<T>{d, n}, n, B, 1.0, red_out.as<double>());
+    CMBL_LAUNCH(this, K_REDUCE, (k_sign_map<T>), dim3(RED_BLOCKS, B), 0, stream, d, red_part.as<unsigned long long>(), n);
+    CMBL_LAUNCH(this, K_REDUCE, k_sign_final, dim3(B), 0, stream, red_part.as<unsigned long long>(), red_out.as<double>(), RED_BLOCKS);
+    fetch(out_host, red_out.as<double>(), B);
   }
 
   // ---- quadratic-estimate / line-search helpers --------------------------------------------------
@@ -399,6 +440,7 @@ struct Flow {
   DevBuf H, Wx, Wy, Y0, Yacc;             // adjoint flow state          (slices)
   DevBuf P0;                              // delta flow: dphi result (F layout)
   DevBuf cvt;                             // boundary conversion scratch
+  DevBuf mls_p, mls_e, mls_f;             // max_lensing_step scratch
 
   DevBuf Wst, U5, F5, tcbuf;              // per-stage partial products, the five reduced maps and their transforms, (t_s, c_s)
   std::vector<T> tc_host;
@@ -513,7 +555,7 @@ struct Flow {
   void max_lensing_step(int basis, const void* phi, const void* eta, int nb, double* out_host) {
     CMBL_REQUIRE(nb <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
     const long np = c->npix();
-    DevBuf mp, me, pf;
+    DevBuf &mp = mls_p, &me = mls_e, &pf = mls_f;                           // pooled: called once per line-search evaluation
     mp.ensure(sizeof(T) * 5 * nb * np); me.ensure(sizeof(T) * 5 * nb * np); pf.ensure(sizeof(cx<T>) * nb * c->plane());
     c->to_F(basis, phi, pf.as<cx<T>>(), B_FOURIER, 1, nb); gradhess_maps(pf.as<cx<T>>(), mp.as<T>(), nb);
     c->to_F(basis, eta, pf.as<cx<T>>(), B_FOURIER, 1, nb); gradhess_maps(pf.as<cx<T>>(), me.as<T>(), nb);
@@ -835,52 +877,86 @@ struct Dataset {
 
   // conjugate_gradient (src/numerical_algorithms.jl:73-134) driving argmaxf_logpdf (src/maximization.jl:17-42).
   // a0 = gradientf(f=0,d=0) is identically zero for this linear model (all operators finite), so it is not evaluated.
+  // The scalars (res, alpha, beta, best residual, history, stop flag) live on the device (CgState): an iteration is enqueued
+  // without waiting for its reductions; the host reads the stop flag of iteration i-1 while iteration i runs.
+  DevBuf cg_scal, cg_hist;
+  int* cg_flag_host = nullptr;                 // pinned: [slot][done, nan]
+  hipEvent_t cg_ev[2] = {nullptr, nullptr};
+  ~Dataset() {
+    if (cg_flag_host) (void)hipHostFree(cg_flag_host);
+    for (auto& e : cg_ev) if (e) (void)hipEventDestroy(e);
+  }
   int wiener_cg(Flow<T>& L, const cx<T>* dd, const cx<T>* fstart, double tol, int maxit, cx<T>* f_out, double* hist, int B) {
     const long n = fsize(B), nr = 2 * n / B;
     xs.ensure(sizeof(cx<T>) * n); rs.ensure(sizeof(cx<T>) * n); zs.ensure(sizeof(cx<T>) * n); ps.ensure(sizeof(cx<T>) * n);
     aps.ensure(sizeof(cx<T>) * n); best.ensure(sizeof(cx<T>) * n); bb.ensure(sizeof(cx<T>) * n);
     cx<T>*x = xs.template as<cx<T>>(), *r = rs.template as<cx<T>>(), *z = zs.template as<cx<T>>(), *p = ps.template as<cx<T>>();
     cx<T>*Ap = aps.template as<cx<T>>(), *bx = best.template as<cx<T>>(), *b = bb.template as<cx<T>>();
-    std::vector<double> res(B), res2(B), pAp(B), bestres(B), al(B), be(B), one(B, 1.0), mone(B, -1.0);
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    cg_scal.ensure(sizeof(double) * 6 * 64 + sizeof(int) * 8);
+    cg_hist.ensure(sizeof(double) * (size_t)maxit * B);
+    if (!cg_flag_host) {
+      CMBL_HIP(hipHostMalloc((void**)&cg_flag_host, sizeof(int) * 4, hipHostMallocDefault));
+      for (auto& e : cg_ev) CMBL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    CgState st;
+    double* sd = cg_scal.template as<double>();
+    st.res = sd; st.pAp = sd + 64; st.res2 = sd + 128; st.alpha = sd + 192; st.beta = sd + 256; st.best = sd + 320;
+    st.hist = cg_hist.template as<double>();
+    int* si = reinterpret_cast<int*>(sd + 384);
+    st.done = si; st.nan = si + 1; st.nh = si + 2; st.better = si + 3;
+    hipStream_t sm = c->stream;
+    const unsigned gx = (unsigned)std::min<long>((nr + NTP - 1) / NTP, 2048);
+    std::vector<double> one(B, 1.0), mone(B, -1.0);
     // b = -gradientf(f=0, d) = -L'B'M'Cn^-1 d
     gradientf(L, nullptr, dd, b, B);
     c->lincomb((T*)b, (T*)b, nullptr, mone.data(), nullptr, nr, B);
     if (fstart) {
-      CMBL_HIP(hipMemcpyAsync(x, fstart, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+      CMBL_HIP(hipMemcpyAsync(x, fstart, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, sm));
       gradientf(L, x, nullptr, Ap, B);                                      // A x
       c->lincomb((T*)r, (T*)b, (T*)Ap, one.data(), mone.data(), nr, B);     // r = b - A x
     } else {
-      CMBL_HIP(hipMemsetAsync(x, 0, sizeof(cx<T>) * n, c->stream));
-      CMBL_HIP(hipMemcpyAsync(r, b, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+      CMBL_HIP(hipMemsetAsync(x, 0, sizeof(cx<T>) * n, sm));
+      CMBL_HIP(hipMemcpyAsync(r, b, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, sm));
     }
     apply(OP_PRECOND_INV, r, z, B);
-    CMBL_HIP(hipMemcpyAsync(p, z, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
-    c->dot_F(r, z, P, B, res.data());
-    for (int i = 0; i < B; ++i) CMBL_REQUIRE(!std::isnan(res[i]), ERR_NAN, "NaN residual in conjugate gradient");
-    bestres = res;
-    CMBL_HIP(hipMemcpyAsync(bx, x, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
-    int nh = 0;
-    for (int i = 0; i < B; ++i) hist[(size_t)nh * B + i] = res[i];
-    ++nh;
-    for (int it = 2; it <= maxit; ++it) {
-      gradientf(L, p, nullptr, Ap, B);
-      c->dot_F(p, Ap, P, B, pAp.data());
-      for (int i = 0; i < B; ++i) { al[i] = res[i] / pAp[i]; be[i] = -al[i]; }
-      c->lincomb((T*)x, (T*)x, (T*)p, one.data(), al.data(), nr, B);
-      c->lincomb((T*)r, (T*)r, (T*)Ap, one.data(), be.data(), nr, B);
-      apply(OP_PRECOND_INV, r, z, B);
-      c->dot_F(r, z, P, B, res2.data());
-      for (int i = 0; i < B; ++i) { CMBL_REQUIRE(!std::isnan(res2[i]), ERR_NAN, "NaN residual in conjugate gradient"); be[i] = res2[i] / res[i]; }
-      c->lincomb((T*)p, (T*)z, (T*)p, one.data(), be.data(), nr, B);
-      res = res2;
-      bool better = true, done = true;
-      for (int i = 0; i < B; ++i) { better = better && (res[i] < bestres[i]); done = done && (res[i] < tol); }
-      if (better) { bestres = res; CMBL_HIP(hipMemcpyAsync(bx, x, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream)); }
-      for (int i = 0; i < B; ++i) hist[(size_t)nh * B + i] = res[i];
-      ++nh;
-      if (done) break;
+    CMBL_HIP(hipMemcpyAsync(p, z, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, sm));
+    c->dot_F_dev(r, z, P, B, st.res);
+    hipLaunchKernelGGL(k_cg_start, dim3(1), dim3(64), 0, sm, st, B);
+    CMBL_HIP(hipMemcpyAsync(bx, x, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, sm));
+    auto post_flags = [&](int slot) {
+      CMBL_HIP(hipMemcpyAsync(cg_flag_host + 2 * slot, st.done, sizeof(int) * 2, hipMemcpyDeviceToHost, sm));
+      CMBL_HIP(hipEventRecord(cg_ev[slot], sm));
+    };
+    auto stopped = [&](int slot) {                                          // waits for the flags posted in `slot`
+      CMBL_HIP(hipEventSynchronize(cg_ev[slot]));
+      return cg_flag_host[2 * slot] != 0;
+    };
+    post_flags(0);
+    (void)stopped(0);
+    if (cg_flag_host[1] == 0) {                                             // a NaN start residual is reported below
+      for (int it = 2; it <= maxit; ++it) {
+        gradientf(L, p, nullptr, Ap, B);
+        c->dot_F_dev(p, Ap, P, B, st.pAp);
+        hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(64), 0, sm, st, B);
+        hipLaunchKernelGGL((k_cg_xr<T>), dim3(gx, B), dim3(NTP), 0, sm, (T*)x, (T*)r, (const T*)p, (const T*)Ap, st, nr);
+        apply(OP_PRECOND_INV, r, z, B);
+        c->dot_F_dev(r, z, P, B, st.res2);
+        hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(64), 0, sm, st, B, tol);
+        hipLaunchKernelGGL((k_cg_p<T>), dim3(gx, B), dim3(NTP), 0, sm, (T*)p, (const T*)z, st, nr);
+        hipLaunchKernelGGL((k_cg_keep_best<T>), dim3(gx), dim3(NTP), 0, sm, (T*)bx, (const T*)x, st, 2 * n);
+        CMBL_HIP(hipGetLastError());
+        post_flags(it & 1);
+        if (it > 2 && stopped((it - 1) & 1)) break;                         // flags of the previous iteration
+      }
     }
-    CMBL_HIP(hipMemcpyAsync(f_out, bx, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, c->stream));
+    CMBL_HIP(hipMemcpyAsync(f_out, bx, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, sm));
+    int fl[4];
+    CMBL_HIP(hipMemcpyAsync(fl, st.done, sizeof(int) * 4, hipMemcpyDeviceToHost, sm));
+    CMBL_HIP(hipStreamSynchronize(sm));
+    const int nh = fl[2];
+    CMBL_HIP(hipMemcpy(hist, st.hist, sizeof(double) * (size_t)nh * B, hipMemcpyDeviceToHost));
+    CMBL_REQUIRE(fl[1] == 0, ERR_NAN, "NaN residual in conjugate gradient");
     return nh;
   }
 
@@ -912,10 +988,9 @@ struct Dataset {
     cx<T>* cpip = gphi.template as<cx<T>>();
     apply(OP_CPHI_INV, phi, cpip, B, false, false, false, nullptr, 0, 1, 1);
     c->dot_F(phi, cpip, 1, B, q2.data());
-    for (int i = 0; i < B; ++i) {
-      lp[i] = -0.5 * (q1[i] + q2[i] + q3[i] + logdet_sum);
-      CMBL_REQUIRE(!std::isnan(lp[i]), ERR_NAN, "logpdf is NaN");
-    }
+    // A NaN logpdf is a VALUE, not an error: MAP_joint's line search penalises it (src/maximization.jl:194-199) and hmc_step
+    // rejects the proposal (log(rand()) < NaN is false, src/sampling.jl:414), so it must reach the caller.
+    for (int i = 0; i < B; ++i) lp[i] = -0.5 * (q1[i] + q2[i] + q3[i] + logdet_sum);
     if (!gfo) return;
     // d/df~ = -B'M'Cn^-1 z  -> QU Fourier
     apply_M(w, B, true);

@@ -97,71 +97,208 @@ __global__ __launch_bounds__(NTP) void k_mask_mul(T* __restrict__ out, const T* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Reductions, deterministic two-pass (fixed partition, fixed tree), accumulated in double.
-template <int DUMMY = 0>
-__device__ __forceinline__ double block_sum(double v) {
-  __shared__ double red[NTP / 64];
+// Reductions: per-batch-slot sums, deterministic two-pass (fixed partition, fixed tree).
+//
+// `sum_dropdims` (src/util.jl:297-316) sums the already-broadcast array -- every term is formed in the working precision T --
+// in one of three ways selected by `set_sum_accuracy_mode!` (src/util.jl:288-292):
+//   SUM_WORKING : plain `sum` in T (the reference's default)          -> per-thread running sum, tree and final sum in T
+//   SUM_FLOAT64 : `sum(T64.(A))`                                      -> accumulation in double  (the engine's default)
+//   SUM_KAHAN   : `sum_kbn`, compensated summation in T               -> per-thread Kahan-Babuska-Neumaier in T, the (sum,
+//                 compensation) pairs combined in double and the result rounded to T: within one ulp(T) of the exact sum
+// The summation ORDER of the reference (Julia's pairwise sum on the CPU, a tree on the GPU) is not reproducible in any mode.
+enum SumMode { SUM_WORKING = 0, SUM_FLOAT64 = 1, SUM_KAHAN = 2 };
+
+template <typename T, int MODE> struct SumAcc;
+template <typename T> struct SumAcc<T, SUM_WORKING> {
+  using P = T; T s = 0;
+  __device__ __forceinline__ void add(T x) { s += x; }
+  __device__ __forceinline__ P partial() const { return s; }
+};
+template <typename T> struct SumAcc<T, SUM_FLOAT64> {
+  using P = double; double s = 0;
+  __device__ __forceinline__ void add(T x) { s += (double)x; }
+  __device__ __forceinline__ P partial() const { return s; }
+};
+template <typename T> struct SumAcc<T, SUM_KAHAN> {
+  using P = double; T s = 0, c = 0;
+  __device__ __forceinline__ void add(T x) {
+    const T t = s + x;
+    c += (fabs(s) >= fabs(x)) ? ((s - t) + x) : ((x - t) + s);
+    s = t;
+  }
+  __device__ __forceinline__ P partial() const { return (double)s + (double)c; }
+};
+
+template <typename A>
+__device__ __forceinline__ A block_sum(A v) {
+  __shared__ A red[NTP / 64];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  double r = 0;
+  A r = 0;
   if (threadIdx.x == 0) { for (int w = 0; w < NTP / 64; ++w) r += red[w]; }
   __syncthreads();
   return r;
 }
 
-// Fourier dot in F layout: sum lam[ky] * Re(conj(a) b)   (src/proj_lambert.jl:322-325); n = P*Nyh*Nx per batch
-template <typename T>
-__global__ __launch_bounds__(NTP) void k_dot_F(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
-                                              const T* __restrict__ lam, double* __restrict__ part,
-                                              long n, int lgNx, int Nyh) {
-  const int bt = blockIdx.y;
-  const long off = (long)bt * n;
-  double acc = 0;
-  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) {
-    const int ky = (int)((i >> lgNx) % Nyh);
-    cx<T> u = a[off + i], v = b[off + i];
-    acc += (double)lam[ky] * ((double)u.x * (double)v.x + (double)u.y * (double)v.y);
+// Element functors: value of term i of batch slot bt, formed in T exactly like the reference's broadcast.
+//   Fourier dot  z = real(conj(a) b) .* lam   (src/proj_lambert.jl:322-325; the 1/(Ny Nx) is applied to the sum)
+template <typename T> struct TermDotF {
+  const cx<T>* a; const cx<T>* b; const T* lam; long n; int lgNx, Nyh;
+  __device__ __forceinline__ T operator()(int bt, long i) const {
+    const cx<T> u = a[(long)bt * n + i], v = b[(long)bt * n + i];
+    return (u.x * v.x + u.y * v.y) * lam[(int)((i >> lgNx) % Nyh)];
   }
-  double r = block_sum(acc);
-  if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = r;
-}
-
-// Map dot: sum a*b  (src/proj_lambert.jl:318-321)
-template <typename T>
-__global__ __launch_bounds__(NTP) void k_dot_map(const T* __restrict__ a, const T* __restrict__ b, double* __restrict__ part, long n) {
-  const int bt = blockIdx.y;
-  const long off = (long)bt * n;
-  double acc = 0;
-  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP)
-    acc += (double)a[off + i] * (double)b[off + i];
-  double r = block_sum(acc);
-  if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = r;
-}
-
-// logdet of a real diagonal in F layout: sum lam * log|d|, non-finite -> 0  (src/proj_lambert.jl:331-336)
-template <typename T>
-__global__ __launch_bounds__(NTP) void k_logdet_F(const T* __restrict__ d, const T* __restrict__ lam, double* __restrict__ part,
-                                                 long n, int lgNx, int Nyh) {
-  const int bt = blockIdx.y;
-  const long off = (long)bt * n;
-  double acc = 0;
-  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) {
-    const int ky = (int)((i >> lgNx) % Nyh);
-    double v = log(fabs((double)d[off + i])) * (double)lam[ky];
-    acc += isfinite(v) ? v : 0.0;
+};
+//   Map dot  z = a .* b   (src/proj_lambert.jl:318-321)
+template <typename T> struct TermDotMap {
+  const T* a; const T* b; long n;
+  __device__ __forceinline__ T operator()(int bt, long i) const { return a[(long)bt * n + i] * b[(long)bt * n + i]; }
+};
+//   logdet of a Fourier diagonal, real planes or complex field: nan2zero(log|d| * lam)   (src/proj_lambert.jl:331-336)
+template <typename T> struct TermLogdetF {
+  const T* d; const T* lam; long n; int lgNx, Nyh;
+  __device__ __forceinline__ T operator()(int bt, long i) const {
+    const T v = log(fabs(d[(long)bt * n + i])) * lam[(int)((i >> lgNx) % Nyh)];
+    return isfinite(v) ? v : T(0);
   }
-  double r = block_sum(acc);
-  if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = r;
-}
+};
+template <typename T> struct TermLogdetFc {
+  const cx<T>* d; const T* lam; long n; int lgNx, Nyh;
+  __device__ __forceinline__ T operator()(int bt, long i) const {
+    const cx<T> z = d[(long)bt * n + i];
+    const T v = log(hypot(z.x, z.y)) * lam[(int)((i >> lgNx) % Nyh)];
+    return isfinite(v) ? v : T(0);
+  }
+};
+//   tr of a Fourier diagonal: real(d .* lam)   (src/proj_lambert.jl:346-350)
+template <typename T> struct TermTrFc {
+  const cx<T>* d; const T* lam; long n; int lgNx, Nyh;
+  __device__ __forceinline__ T operator()(int bt, long i) const { return d[(long)bt * n + i].x * lam[(int)((i >> lgNx) % Nyh)]; }
+};
+//   tr / logdet of a Map diagonal (src/proj_lambert.jl:337-342,351-353): d, and log|d| (the sign term is k_sign_map's)
+template <typename T> struct TermTrMap {
+  const T* d; long n;
+  __device__ __forceinline__ T operator()(int bt, long i) const { return d[(long)bt * n + i]; }
+};
+template <typename T> struct TermLogAbsMap {
+  const T* d; long n;
+  __device__ __forceinline__ T operator()(int bt, long i) const { return log(fabs(d[(long)bt * n + i])); }
+};
 
+// pass 1: grid (nblk, B).  part[bt][blk] holds the block's partial sum (a T value in SUM_WORKING)
+template <typename T, int MODE, typename F>
+__global__ __launch_bounds__(NTP) void k_reduce_terms(F f, double* __restrict__ part, long n) {
+  const int bt = blockIdx.y;
+  SumAcc<T, MODE> acc;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) acc.add(f(bt, i));
+  const auto r = block_sum<typename SumAcc<T, MODE>::P>(acc.partial());
+  if (threadIdx.x == 0) part[(long)bt * gridDim.x + blockIdx.x] = (double)r;
+}
+// pass 2: grid (B).  out[bt] = scale * sum of the partials; in SUM_WORKING the sum and the scaling are done in T
+template <typename T, int MODE>
 __global__ __launch_bounds__(NTP) void k_reduce_final(const double* __restrict__ part, double* __restrict__ out, int nblk, double scale) {
   const int bt = blockIdx.x;
-  double acc = 0;
-  for (int i = threadIdx.x; i < nblk; i += NTP) acc += part[(long)bt * nblk + i];
-  double r = block_sum(acc);
-  if (threadIdx.x == 0) out[bt] = r * scale;
+  using P = typename SumAcc<T, MODE>::P;
+  P acc = 0;
+  for (int i = threadIdx.x; i < nblk; i += NTP) acc += (P)part[(long)bt * nblk + i];
+  const P r = block_sum<P>(acc);
+  if (threadIdx.x == 0) {
+    if (MODE == SUM_WORKING) out[bt] = (double)((T)r * (T)scale);
+    else if (MODE == SUM_KAHAN) out[bt] = (double)((T)(r * scale));
+    else out[bt] = (double)r * scale;
+  }
+}
+// sign bookkeeping of logdet(Diagonal(::Map)): log(prod(sign.(d))) -- 0 for an even number of negative entries, NaN for an odd
+// number (Julia's log(-1.0) throws; here the slot's result is NaN), -Inf when an entry is zero.  part2[bt][blk] = (#neg, #zero)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_sign_map(const T* __restrict__ d, unsigned long long* __restrict__ part2, long n) {
+  const int bt = blockIdx.y;
+  unsigned long long neg = 0, zero = 0;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) {
+    const T v = d[(long)bt * n + i];
+    neg += v < T(0); zero += v == T(0);
+  }
+  neg = block_sum<unsigned long long>(neg); zero = block_sum<unsigned long long>(zero);
+  if (threadIdx.x == 0) { part2[2 * ((long)bt * gridDim.x + blockIdx.x)] = neg; part2[2 * ((long)bt * gridDim.x + blockIdx.x) + 1] = zero; }
+}
+__global__ __launch_bounds__(NTP) void k_sign_final(const unsigned long long* __restrict__ part2, double* __restrict__ inout, int nblk) {
+  const int bt = blockIdx.x;
+  unsigned long long neg = 0, zero = 0;
+  for (int i = threadIdx.x; i < nblk; i += NTP) { neg += part2[2 * ((long)bt * nblk + i)]; zero += part2[2 * ((long)bt * nblk + i) + 1]; }
+  neg = block_sum<unsigned long long>(neg); zero = block_sum<unsigned long long>(zero);
+  if (threadIdx.x == 0) {
+    if (zero) inout[bt] = -INFINITY;                           // log|0| already made the sum -Inf; log(prod sign) = log(0) = -Inf
+    else if (neg & 1ull) inout[bt] = NAN;                      // log(-1)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conjugate_gradient (src/numerical_algorithms.jl:73-134) with its scalars resident on the device: the host enqueues iterations
+// without waiting for any reduction.  `done` latches when every batch slot has res < tol; from then on the state-updating kernels
+// below are no-ops, so an iteration the host enqueued before it saw the flag changes nothing (same iterates, same history as
+// a loop that tests the residual on the host after every iteration).
+struct CgState {
+  double *res, *pAp, *res2, *alpha, *beta, *best, *hist;       // [B] each; hist [maxit][B]
+  int *done, *nan, *nh, *better;
+};
+// after res = dot(r, z) of the start vector
+__global__ void k_cg_start(CgState s, int B) {
+  if (threadIdx.x != 0) return;
+  int nanf = 0;
+  for (int b = 0; b < B; ++b) { s.best[b] = s.res[b]; s.hist[b] = s.res[b]; nanf |= isnan(s.res[b]); }
+  *s.nh = 1; *s.done = 0; *s.better = 1; *s.nan = nanf;
+}
+// alpha = res / pAp  (:102)
+__global__ void k_cg_alpha(CgState s, int B) {
+  if (threadIdx.x != 0 || *s.done) return;
+  for (int b = 0; b < B; ++b) s.alpha[b] = s.res[b] / s.pAp[b];
+}
+// x += alpha p ; r -= alpha Ap  (:103-104), complex arrays viewed as reals; grid (blocks, B)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_cg_xr(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p, const T* __restrict__ Ap,
+                                              CgState s, long n) {
+  if (*s.done) return;
+  const int b = blockIdx.y;
+  const T al = (T)s.alpha[b];
+  const long off = (long)b * n;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) {
+    const T pv = p[off + i], av = Ap[off + i];
+    x[off + i] += al * pv;
+    r[off + i] -= al * av;
+  }
+}
+// beta = res' / res ; res = res' ; best-iterate bookkeeping, history, stop test  (:106-125)
+__global__ void k_cg_beta(CgState s, int B, double tol) {
+  if (threadIdx.x != 0) return;
+  if (*s.done) { *s.better = 0; return; }
+  int better = 1, done = 1, nanf = 0;
+  for (int b = 0; b < B; ++b) {
+    const double r2 = s.res2[b];
+    nanf |= isnan(r2);
+    s.beta[b] = r2 / s.res[b];
+    s.res[b] = r2;
+    better &= (r2 < s.best[b]); done &= (r2 < tol);
+    s.hist[(long)(*s.nh) * B + b] = r2;
+  }
+  if (better) for (int b = 0; b < B; ++b) s.best[b] = s.res[b];
+  *s.nh += 1; *s.better = better; *s.nan |= nanf;
+  *s.done = done || nanf;
+}
+// p = z + beta p  (:107)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_cg_p(T* __restrict__ p, const T* __restrict__ z, CgState s, long n) {
+  const int b = blockIdx.y;
+  const T be = (T)s.beta[b];
+  const long off = (long)b * n;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < n; i += (long)gridDim.x * NTP) p[off + i] = z[off + i] + be * p[off + i];
+}
+// bestx = x when this iteration improved on the best residual (:111-114)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_cg_keep_best(T* __restrict__ bx, const T* __restrict__ x, CgState s, long ntot) {
+  if (!*s.better) return;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < ntot; i += (long)gridDim.x * NTP) bx[i] = x[i];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -105,14 +105,16 @@ def quadratic_estimate(ds, which=None, wiener_filtered=True, AL=None):
         a = a[None, None] if a.ndim == 2 else a
         return proj.tensor(a.astype(np.complex128))
 
-    with np.errstate(divide="ignore", invalid="ignore"):
-        def filt(k, extra=1.0):                       # extra * (Σtot \ (TF * d[k]))   host-side diagonal algebra, device data
-            TFk = plane(h["Mf"], k) * plane(h["B"], k)
-            S = TFk ** 2 * plane(h["Cftilde"], k) + plane(h["Cn"], k)
+    def filt(k, extra=1.0):                           # extra * (Σtot \ (TF * d[k]))   host-side diagonal algebra, device data
+        TFk = plane(h["Mf"], k) * plane(h["B"], k)
+        S = TFk ** 2 * plane(h["Cftilde"], k) + plane(h["Cn"], k)
+        with np.errstate(divide="ignore", invalid="ignore"):
             w = TFk / S * extra
-            w[~np.isfinite(w)] = 0
-            dk = ds.d.arr[:, dof[k]:dof[k] + 1].contiguous()
-            return dk * proj.tensor(w)[None, None].to(dk.dtype)
+        w[~np.isfinite(w)] = 0
+        dk = ds.d.arr[:, dof[k]:dof[k] + 1].contiguous()
+        return proj.diag_apply(w[None], dk, FOURIER, FOURIER)           # DiagOp * field on the device (cmbl_diag_apply)
+
+    with np.errstate(divide="ignore", invalid="ignore"):
         W = {}
         for k in off:
             TFk = plane(h["Mf"], k) * plane(h["B"], k)
@@ -201,15 +203,18 @@ def quadratic_estimate(ds, which=None, wiener_filtered=True, AL=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def MAP_joint_step(ds, phi, fstart=None, alpha_prev=1.0, alpha_tol=1e-4, alpha_max=None, cg_tol=1e-1, cg_nsteps=500):
-    """One iteration of the `MAP_joint` loop body (src/maximization.jl:160-206) at fiducial θ with G = I (:146)."""
+def MAP_joint_step(ds, phi, fstart=None, alpha_prev=1.0, alpha_tol=1e-4, alpha_max=None, cg_tol=1e-1, cg_nsteps=500, alias_quirk=None):
+    """One iteration of the `MAP_joint` loop body (src/maximization.jl:160-206) at fiducial θ with G = I (:146).
+    The line search runs in the field precision T like the reference's `optimize(T(0), T(αmax), Brent(); abs_tol=T(αtol))`:
+    Brent's relative tolerance is sqrt(eps(T)) and a NaN logpdf is replaced by (α/αmax)·prevfloat(T(Inf)) (:194-199)."""
     proj, h = ds.proj, ds.host
+    fin = np.finfo(np.float32 if proj.T == torch.float32 else np.float64)
     Ginv_saved = ds.ops["G_inv"]
     ds.set_op("G_inv", np.ones_like(h["Cphi"])[None])
     try:
         f, hist = ds.argmaxf_logpdf(phi, fstart=fstart, tol=cg_tol, nsteps=cg_nsteps)              # :164-169
         fo, po = ds.mix(f, phi, G=np.ones_like(h["Cphi"]))                                         # :176
-        lp0, gfo, gpo = ds.gradient_logpdf_mixed(fo, po)                                           # :178
+        lp0, gfo, gpo = ds.gradient_logpdf_mixed(fo, po, alias_quirk=alias_quirk)                  # :178
         with np.errstate(divide="ignore"):
             Hinv = 1 / (_pinv(h["Cphi"]) + _pinv(h["Nphi"]))                                       # dataset.jl:134-137
         Hinv[~np.isfinite(Hinv)] = 0
@@ -217,8 +222,8 @@ def MAP_joint_step(ds, phi, fstart=None, alpha_prev=1.0, alpha_tol=1e-4, alpha_m
         amax = 2 * alpha_prev if alpha_max is None else alpha_max                                  # :193
         def neg(a):
             v = -float(np.sum(ds.logpdf_mixed(fo, proj.axpby(1.0, po, a, dphi))))
-            return v if np.isfinite(v) else (a / amax) * np.finfo(np.float64).max                  # :198
-        alpha, _, nls = brent_minimize(neg, 0.0, amax, abs_tol=alpha_tol)                          # :194-199
+            return (a / amax) * float(fin.max) if np.isnan(v) else v                               # :198
+        alpha, _, nls = brent_minimize(neg, 0.0, amax, abs_tol=alpha_tol, rel_tol=float(np.sqrt(fin.eps)))   # :194-199
         po2 = proj.axpby(1.0, po, alpha, dphi)                                                     # :201
         lp = ds.logpdf_mixed(fo, po2)                                                              # :205
         f2, phi2 = ds.unmix(fo, po2, G=np.ones_like(h["Cphi"]))                                    # :206
@@ -252,7 +257,7 @@ def simulate_data(ds, phi, white_f, white_n):
 
 
 def MAP_marg(ds, nsteps=10, nsteps_with_meanfield_update=4, alpha=0.2, Nsims=50, sims_per_batch=1, phi_start=None, cg_tol=1e-1,
-             cg_nsteps=500, base_seed=0, rng="device", whites=None, dist=None, progress=None):
+             cg_nsteps=500, base_seed=0, rng="device", whites=None, dist=None, progress=None, alias_quirk=None):
     """`MAP_marg(ds)` (src/maximization.jl:245-343) at fiducial θ: ϕ ← ϕ + α·Hϕ⁻¹·(g_data − ḡ_sims − Cϕ⁻¹ϕ) with
     g = ∂logpdf/∂ϕ at the Wiener-filtered f, the mean field ḡ averaged over Nsims simulated data sets (re-drawn from the SAME
     random numbers every step, `_rng = copy(rng)` :283) and refreshed during the first `nsteps_with_meanfield_update` steps.
@@ -283,7 +288,7 @@ def MAP_marg(ds, nsteps=10, nsteps_with_meanfield_update=4, alpha=0.2, Nsims=50,
 
     def gMAP(d, fprev):                                                                           # :287-303
         f_wf, hist = ds.argmaxf_logpdf(phi, d=d, fstart=fprev, tol=cg_tol, nsteps=cg_nsteps)
-        return ds.gradientphi_logpdf(f_wf, phi, d=d), f_wf, hist
+        return ds.gradientphi_logpdf(f_wf, phi, d=d, alias_quirk=alias_quirk), f_wf, hist
 
     for step in range(1, nsteps + 1):
         g_data, f_prev, hist = gMAP(ds.d, f_prev)
@@ -336,7 +341,7 @@ def symplectic_integrate(proj, x0, p0, Lam, U, dUdx, N=50, eps=0.1):
     return H(x, p) - H(x0, p0), x, p
 
 
-def hmc_step(ds, fo, po, white_p, log_u, N=25, eps=0.01, always_accept=False, alias_quirk=False):
+def hmc_step(ds, fo, po, white_p, log_u, N=25, eps=0.01, always_accept=False, alias_quirk=None):
     """`hmc_step` (src/sampling.jl:405-418) over ϕ° with U = logpdf(Mixed(ds)); white_p / log_u are the injected draws."""
     proj = ds.proj
     Lam = mass_matrix_phi(ds)
@@ -344,7 +349,7 @@ def hmc_step(ds, fo, po, white_p, log_u, N=25, eps=0.01, always_accept=False, al
     U = lambda x: ds.logpdf_mixed(fo, x)
     dU = lambda x: ds.gradient_logpdf_mixed(fo, x, alias_quirk=alias_quirk)[2]
     dH, xt, _ = symplectic_integrate(proj, po, p0, Lam, U, dU, N=N, eps=eps)
-    accept = np.logical_or(always_accept, np.asarray(log_u) < dH)
+    accept = np.logical_or(always_accept, np.asarray(log_u) < dH)                 # a NaN ΔH (diverged trajectory) compares false: rejected
     x = proj.axpby(accept.astype(float), xt, 1.0 - accept.astype(float), po)      # x = accept*xtest + (1-accept)*x   (:415)
     return x, dH, accept
 
@@ -359,12 +364,12 @@ def sample_f(ds, phi, white_f, white_n, fstart=None, tol=1e-1, nsteps=500):
     return fs + df, hist
 
 
-def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always_accept=False, theta_pass=None):
+def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always_accept=False, theta_pass=None, alias_quirk=None):
     """One `sample_joint` step (src/sampling.jl:187-193, 388-464): f | ϕ,θ -> mix -> HMC ϕ° | f°,θ -> [θ | f°,ϕ°] -> unmix -> logpdf.
     `theta_pass(fo, po)` runs the Gibbs θ passes in the mixed space and leaves the dataset at the new θ (theta.py)."""
     f, hist = sample_f(ds, phi, white_f, white_n)
     fo, po = ds.mix(f, phi)
-    po2, dH, accept = hmc_step(ds, fo, po, white_p, log_u, N=N, eps=eps, always_accept=always_accept)
+    po2, dH, accept = hmc_step(ds, fo, po, white_p, log_u, N=N, eps=eps, always_accept=always_accept, alias_quirk=alias_quirk)
     if theta_pass is not None:
         theta_pass(fo, po2)
     f2, phi2 = ds.unmix(fo, po2)
@@ -373,9 +378,9 @@ def gibbs_step(ds, phi, white_f, white_n, white_p, log_u, N=25, eps=0.01, always
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=None, N=25, eps=0.01, nburnin_always_accept=0,
+def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start="prior", N=25, eps=0.01, nburnin_always_accept=10,
                  dist=None, nchains_total=None, progress=None, rng="host", first_step=0, filename=None, nfilewrite=5, nsavemaps=1,
-                 resume=None, theta_ranges=None, theta_start=None):
+                 resume=None, theta_ranges=None, theta_start="prior", alias_quirk=None):
     """`sample_joint` at fixed θ (src/sampling.jl:180-335): Gibbs loop  f | ϕ  ->  mix  ->  HMC ϕ° | f°  ->  unmix  ->  logpdf.
     The chains owned by this process are the batch slots of `ds` (`ds.d` must have len(chain_ids) slots; the reference runs
     chains under pmap, one worker per GPU, src/sampling.jl:266,292).  Chain c draws from its own generator keyed by
@@ -388,7 +393,13 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
     0 which owns the file; `resume=True` continues from the file's last sample up to `nsamps_per_chain` (:247-256), an existing
     file needs an explicit `resume` (:239-241).
     `theta_ranges` = {"Aphi": grid, "r": grid} adds the Gibbs θ passes (`gibbs_sample_slice_θ!`, :427-437) after the HMC pass; the
-    dataset's ParamDependentOps are then re-evaluated at the sampled θ for the following passes (single chain per dataset).
+    dataset's ParamDependentOps are then re-evaluated at the sampled θ for the following passes (single chain per dataset).  The
+    sampled θ is part of every saved sample (`theta_<key>`, like `filter_for_saving` keeps θ, :226-228) and a resumed run continues
+    from the file's last θ (:247-256).
+    Defaults follow the reference (:190-214): `phi_start="prior"` draws ϕ ~ 𝒩(0, Cϕ) (0 / None = zero, or a Field), `theta_start=
+    "prior"` draws θ uniformly inside its range (or a dict), `nburnin_always_accept=10`.  Step numbering: the reference stores the
+    initial state as step 1 and its first Gibbs pass is step 2 (:268,277); here the first Gibbs pass is saved as step 1, so
+    `always_accept = (step < nburnin_always_accept)` (:400) is evaluated with the reference's step = ours + 1.
     Returns dict(logpdf, dH, accept [nsamps, nchains], phi, f [, theta])."""
     from .chains import gather_chain_values, chain_seed
     from . import rng as R
@@ -399,18 +410,27 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
     assert rng in ("host", "device")
     multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if multi else 0
+    assert not multi or nchains_total is not None, "nchains_total (chains over all ranks) is required when running on more than one rank"
     ntot = nchains_total if multi else B          # file / gather order: global chain id across ranks, position in a single process
     fidx = list(chain_ids) if multi else list(range(B))
     gdev = proj.device if multi and dist.get_backend() == "nccl" else "cpu"
     CF.check_filename(filename, resume)
-    chunk_index, clobber = 1, True
+    chunk_index, clobber, theta_resume = 1, True, None
     if filename is not None and resume and os.path.isfile(filename):
         chunk_index, first_step, last = CF.last_state(filename)
         clobber = False
         phi_start = Field(proj, proj.tensor(np.stack([last[c]["phi"] for c in fidx])[:, None]), FOURIER)
+        theta_resume = {k[6:]: float(v) for k, v in last[fidx[0]].items() if k.startswith("theta_")}
     seeds = [chain_seed(base_seed, c) for c in chain_ids]
     rngs = [np.random.Generator(np.random.PCG64(s if first_step == 0 else [s, first_step])) for s in seeds]
-    phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER) if phi_start is None else phi_start
+    if isinstance(phi_start, str):
+        assert phi_start == "prior", phi_start                      # gibbs_initialize_ϕ! (:363-384): simulate(ds.Cϕ)
+        w0 = proj.randn(seeds, R.stream_id(R.STREAM_INIT, 0), 1) if rng == "device" else np.stack([r.standard_normal((1, proj.Nx, proj.Ny)) for r in rngs])
+        phi = Field(proj, proj.diag_apply(np.sqrt(np.asarray(ds.host["Cphi"], float))[None], proj.rfft(proj.tensor(w0)), FOURIER, FOURIER), FOURIER)
+    elif phi_start is None or (np.isscalar(phi_start) and phi_start == 0):
+        phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER)
+    else:
+        phi = phi_start
     hist = dict(logpdf=[], dH=[], accept=[], ncg=[])
     chunk = [[] for _ in range(B)]
 
@@ -420,7 +440,8 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
         if nsamp == 0:
             return
         gath = lambda a: gather_chain_values(fidx, a, ntot, dist if multi else None, gdev)
-        sc = {k: gath(np.array([[s[k] for s in ch] for ch in chunk], float).reshape(B, nsamp)) for k in ("step", "logpdf", "dH", "accept", "ncg")}
+        skeys = ["step", "logpdf", "dH", "accept", "ncg"] + sorted(k for k in chunk[0][0] if k.startswith("theta_"))
+        sc = {k: gath(np.array([[s[k] for s in ch] for ch in chunk], float).reshape(B, nsamp)) for k in skeys}
         has = [i for i, s in enumerate(chunk[0]) if "phi" in s]
         mp = {}
         for k in ("phi", "f"):
@@ -448,7 +469,15 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
         from . import theta as TH
         assert B == 1, "θ sampling: one chain per dataset (the operators of a dataset carry a single θ)"
         theta = dict(r=None, Aphi=None)
-        theta.update(theta_start or {})
+        if theta_resume:                                            # resumed: the file's last θ (merge!(states, last(chunk)), :252)
+            theta.update(theta_resume)
+        elif isinstance(theta_start, str):
+            assert theta_start == "prior", theta_start              # gibbs_initialize_θ! (:340-354): uniform inside the range
+            for j, (key, xs) in enumerate(theta_ranges.items()):
+                u0 = R.uniform(seeds[0], R.stream_id(R.STREAM_INIT, 1 + j))[0] if rng == "device" else rngs[0].random()
+                theta[key] = float(xs[0] + u0 * (xs[-1] - xs[0]))
+        else:
+            theta.update(theta_start or {})
         TH.set_theta(ds, **theta)
     f = None
     for step in range(first_step, nsamps_per_chain) if (filename is not None and resume) else range(first_step, first_step + nsamps_per_chain):
@@ -467,7 +496,8 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
                     val, _ = TH.gibbs_sample_theta(ds, fo_, po_, theta, key, xs, uu)
                     theta[key] = float(val[0])
                 TH.set_theta(ds, **theta)
-        st = gibbs_step(ds, phi, wf, wn, wp, logu, N=N, eps=eps, always_accept=(step < nburnin_always_accept), theta_pass=tpass)
+        st = gibbs_step(ds, phi, wf, wn, wp, logu, N=N, eps=eps, always_accept=(step + 2 < nburnin_always_accept), theta_pass=tpass,
+                        alias_quirk=alias_quirk)
         if theta_ranges:
             theta_hist.append(dict(theta))
         phi, f = st["phi"], st["f"]
@@ -480,6 +510,8 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start=No
                 ph, fh = phi.to(FOURIER).arr.cpu().numpy(), f.to(HARMONIC).arr.cpu().numpy()
             for b in range(B):
                 smp = dict(step=step + 1, logpdf=st["logpdf"][b], dH=st["dH"][b], accept=float(st["accept"][b]), ncg=float(len(st["cg_hist"])))
+                if theta_ranges:
+                    smp.update({"theta_" + k: float(v) for k, v in theta.items() if v is not None})
                 if maps:
                     smp.update(phi=ph[b, 0], f=fh[b])
                 chunk[b].append(smp)

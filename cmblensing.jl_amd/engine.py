@@ -216,6 +216,42 @@ class ProjLambert:
         check(self.lib.cmbl_logdet(self._h, _ptr(d), d.shape[0], out))
         return out[0]
 
+    def norm(self, a, basis):
+        """norm(f) = sqrt(dot(f, f)) (src/generic.jl:373), per batch slot"""
+        P, B = self._check(a, basis)
+        out = (ctypes.c_double * B)()
+        check(self.lib.cmbl_norm(self._h, basis, _ptr(a), P, B, out))
+        return np.array(out[:])
+
+    def logdet_diag(self, d, basis):
+        """logdet(Diagonal(field)) (src/proj_lambert.jl:331-342): Map basis with the sign term, Fourier bases λ-weighted"""
+        P, B = self._check(d, basis)
+        out = (ctypes.c_double * B)()
+        check(self.lib.cmbl_logdet_diag(self._h, basis, _ptr(d), P, B, out))
+        return np.array(out[:])
+
+    def tr_diag(self, d, basis):
+        """tr(Diagonal(field)) (src/proj_lambert.jl:346-353)"""
+        P, B = self._check(d, basis)
+        out = (ctypes.c_double * B)()
+        check(self.lib.cmbl_tr_diag(self._h, basis, _ptr(d), P, B, out))
+        return np.array(out[:])
+
+    def set_sum_accuracy_mode(self, mode):
+        """`set_sum_accuracy_mode!` (src/util.jl:288-292): None | "working" (the reference's default, plain sum in T), "float64"
+        (the engine's default), "kahan"."""
+        m = {None: 0, "working": 0, "float64": 1, float: 1, np.float64: 1, "kahan": 2}[mode]
+        check(self.lib.cmbl_set_sum_accuracy_mode(self._h, m))
+
+    def timer_report(self):
+        """text table of the per-kernel-class HIP-event timings (cmbl_timer_report)"""
+        n = self.lib.cmbl_timer_report(self._h, None, 0)
+        if n < 0:
+            check(-n)
+        buf = ctypes.create_string_buffer(n + 1)
+        self.lib.cmbl_timer_report(self._h, buf, n + 1)
+        return buf.value.decode()
+
 
 class Field:
     """A field tensor tagged with its basis (tiny stand-in for BaseField{B,...}, src/base_fields.jl:14-21)."""
@@ -229,6 +265,9 @@ class Field:
     def dot(self, other):
         o = other.to(self.basis)
         return self.proj.dot(self.arr, o.arr, self.basis)
+
+    def norm(self):
+        return self.proj.norm(self.arr, self.basis)
 
     def __add__(self, o):
         return self.proj.axpby(1.0, self, 1.0, o)
@@ -358,6 +397,10 @@ class BaseDataSet:
             self.set_data(d)
         self.logdet_sum = float(logdet_sum)
         self.logdet_mix = 0.0          # logdet(D,θ) + logdet(G,θ) of the mixed parametrisation (src/dataset.jl:86); 0 at fiducial θ
+        # ϕ-gradients: False = the mathematically consistent δϕ velocity (default), True = the reference exactly as written, with
+        # the in-place aliasing of src/lenseflow.jl:198-200 (differs by ~3e-4).  Every driver (MAP_joint, MAP_marg,
+        # hmc_step, sample_joint) takes `alias_quirk=None` = this dataset-level setting.
+        self.alias_quirk = False
         check(self.lib.cmbl_dataset_set_logdet(self._h, self.logdet_sum))
 
     def __del__(self):
@@ -376,6 +419,8 @@ class BaseDataSet:
         t = self.proj.tensor(planes)
         t = t.reshape(1, *t.shape) if t.dim() == 2 else t
         self.ops[name] = t
+        if name == "Mpix":
+            self._mask_full = (None, None)          # expanded copy of the pixel mask is stale
         check(self.lib.cmbl_dataset_set_op(self._h, self._ids[name], _ptr(t), t.shape[0]))
 
     def _apply(self, name, f, basis_out=HARMONIC):
@@ -400,11 +445,12 @@ class BaseDataSet:
             self._mask_full = (key, self.ops["Mpix"].reshape(1, 1, self.proj.Nx, self.proj.Ny).expand(*key).contiguous())
         return Field(self.proj, self.proj.map_fma(m.arr, self._mask_full[1]), MAP).to(HARMONIC)
 
-    def gradientphi_logpdf(self, f, phi, d=None, alias_quirk=False):
+    def gradientphi_logpdf(self, f, phi, d=None, alias_quirk=None):
         """∂/∂ϕ logpdf(ds; f, ϕ, d) at fixed f -- what `gradient(ϕ -> logpdf(dsθ; f=f_wf, ϕ, dsθ.d), ϕ)` evaluates in MAP_marg
         (src/maximization.jl:301): the δ-flow pullback of L(ϕ)*f (src/flowops.jl:40-54) applied to ∂/∂f̃ = B'M'Cn⁻¹(d − MBLf),
         minus Cϕ⁻¹ϕ.  f, d may carry B batch slots against one ϕ."""
         d = self.d if d is None else d
+        alias_quirk = self.alias_quirk if alias_quirk is None else alias_quirk
         ft = self.L(phi) * f.to(MAP)
         z = d.to(HARMONIC) - self._mask(self._apply("B", ft))
         w = self._applyT("B", self._maskT(self._apply("Cn_inv", z)), basis_out=FOURIER)
@@ -479,8 +525,9 @@ class BaseDataSet:
         check(self.lib.cmbl_logpdf_mixed(self._h, self.L._h, _ptr(fo.arr), _ptr(phio.arr), lp, B))
         return np.array(lp[:]) - self.logdet_mix
 
-    def gradient_logpdf_mixed(self, fo, phio, alias_quirk=False):
-        """(logpdf, ∇f° [MAP], ∇ϕ° [FOURIER]) — the "∇lnP" step (test/runbenchmarks.jl:120)."""
+    def gradient_logpdf_mixed(self, fo, phio, alias_quirk=None):
+        """(logpdf, ∇f° [MAP], ∇ϕ° [FOURIER]) — the "∇lnP" step (test/runbenchmarks.jl:120).  A NaN logpdf is returned as NaN."""
+        alias_quirk = self.alias_quirk if alias_quirk is None else alias_quirk
         fo, phio = fo.to(MAP), phio.to(FOURIER)
         B = fo.arr.shape[0]
         lp = (ctypes.c_double * B)()
@@ -494,11 +541,11 @@ class BaseDataSet:
     def mix(self, f, phi, G=None):
         """f° = L(ϕ)·D·f, ϕ° = G·ϕ (src/dataset.jl:96-101)"""
         fo = self.L(phi) * self._apply("D", f.to(HARMONIC))
-        if G is None:
-            G = 1.0 / self.ops["G_inv"]
-            G = torch.where(torch.isfinite(G), G, torch.zeros_like(G))
-        phio = Field(self.proj, self.proj.diag_apply(G if torch.is_tensor(G) else np.asarray(G)[None], phi.to(FOURIER).arr, FOURIER, FOURIER), FOURIER)
-        return fo, phio
+        if G is None:                                  # G = pinv(G⁻¹): ϕ° = nan2zero(ϕ / G⁻¹), one library call (DiagOp `\`)
+            phio = self.proj.diag_apply(self.ops["G_inv"], phi.to(FOURIER).arr, FOURIER, FOURIER, kind=DIAG_DIV_NAN2ZERO)
+        else:
+            phio = self.proj.diag_apply(np.asarray(G)[None], phi.to(FOURIER).arr, FOURIER, FOURIER)
+        return fo, Field(self.proj, phio, FOURIER)
 
     def unmix(self, fo, phio, G=None):
         """ϕ = G \\ ϕ°, f = D \\ (L(ϕ) \\ f°) (src/dataset.jl:111-117)"""

@@ -5,7 +5,8 @@ always drawn on the device (ProjLambert.randn)."""
 _M0, _M1, _W0, _W1, _M32 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
 
 # stream ids: (draw kind) + 16 * (running step index) -- independent sequences of one chain's key
-STREAM_F, STREAM_N, STREAM_P, STREAM_U = 0, 1, 2, 3
+STREAM_F, STREAM_N, STREAM_P, STREAM_U = 0, 1, 2, 3         # STREAM_U + 1 + j: uniform of the j-th θ pass
+STREAM_INIT = 12                                         # starting point of a chain: step 0 = ϕ ~ prior, 1 + j = θ_j ~ prior
 
 
 def stream_id(kind, step):

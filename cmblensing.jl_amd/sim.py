@@ -178,7 +178,9 @@ def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T
     ds = BaseDataSet(proj, P, ops, logdet_sum=logdet_sum, nsteps=nsteps)
     Cft = mk(cls["total"])                                                     # Cf̃ (:270)
     ds.host = dict(Cf=Cf, Cn=Cn, Cphi=Cphi, Mf=Mf, B=Bop, D=D, Nphi=Nphi, G=Gp, Mpix=Mpix, precond=precond, Cftilde=Cft,
-                   Cfs=Cfs, Cten=Cten, r0=0.2, Aphi0=1.0, s2len=s2len)           # θ layer (theta.py): r₀ = Cℓ.params.r, Aϕ₀ = 1 (:239,250)
+                   Cfs=Cfs, Cten=Cten, r0=0.2, Aphi0=1.0, s2len=s2len)
+    if G is not None:
+        ds.host["G_user"] = Gp.copy()                                           # theta.set_theta keeps a user-supplied G at fiducial Aϕ           # θ layer (theta.py): r₀ = Cℓ.params.r, Aϕ₀ = 1 (:239,250)
 
     # simulate: x = sqrt(C)·rfft(white)   (src/specialops.jl:6), white ~ NumPy PCG64(seed) uploaded, or with rng="device"
     # drawn on the GPU (cmbl_randn: Philox4x32-10, batch slot b keyed by seed + 1000003*b)
@@ -193,12 +195,7 @@ def load_sim(theta_pix, Nside, pol, cls, T=torch.float32, device=0, muK_arcmin_T
     phi = Field(proj, phi.arr, FOURIER)
     n = sim(Cn.sqrt().p, seeds[2], P)
     ftilde = ds.L(phi) * f                                                       # map
-    x = Field(proj, proj.diag_apply(Bop.p, ftilde.arr, HARMONIC, MAP, HARMONIC), HARMONIC)
-    if Mpix is not None:
-        xm = x.to(MAP)
-        x = Field(proj, xm.arr * proj.tensor(Mpix), MAP).to(HARMONIC)
-    x = Field(proj, proj.diag_apply(Mf.p, x.arr, HARMONIC, HARMONIC), HARMONIC)
-    d = x + n
+    d = ds.mean(f, phi) + n                                                      # M·B·L(ϕ)·f + n  (src/dataset.jl:59-66)
     ds.set_data(d)
     if qe_nphi:                                                                 # ds.Nϕ = quadratic_estimate(ds).Nϕ / Nϕ_fac   (:316)
         from .drivers import quadratic_estimate

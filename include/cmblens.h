@@ -18,7 +18,8 @@
  *   - Ny, Nx must be powers of two in [32, 4096] (the reference accepts any size through FFTW;
  *     other sizes return CMBL_ERR_SHAPE).
  *   - a handle is used by one host thread at a time; different contexts are independent.
- *   - calls are asynchronous on the context's stream unless they return host values.
+ *   - calls are asynchronous on the context's stream unless they return host values (`*_host` outputs), i.e. every
+ *     field-to-field entry point is already the `_async` form; cmbl_ctx_synchronize() waits for the stream.
  */
 #ifndef CMBLENS_H
 #define CMBLENS_H
@@ -72,6 +73,18 @@ int cmbl_prof_count(void);
 const char* cmbl_prof_name(int kernel_class);
 int cmbl_prof_get(cmbl_ctx* ctx, int kernel_class, double* total_ms_host, long* launches_host);
 
+/* report of the accumulated timings as text ("name launches total_ms mean_us" lines), like TimerOutputs' table; returns the
+ * number of bytes the full report needs (excluding the terminator) -- call with buf = NULL to size the buffer. */
+int cmbl_timer_report(cmbl_ctx* ctx, char* buf, size_t buflen);
+
+/* ---- device memory helpers for callers that do not link HIP themselves (a Julia process without AMDGPU.jl, the plain-C
+ *      test): every field pointer of this API is a device pointer; these give a host program the means to own some.
+ *      Copies are ordered on the context's stream and complete on return. */
+int cmbl_device_malloc(size_t bytes, void** out);
+int cmbl_device_free(void* p);
+int cmbl_copy_to_device(cmbl_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int cmbl_copy_to_host(cmbl_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+
 /* ---- basis transforms: m_rfft / m_irfft and the Basis conversion lattice
  *      (src/util_fft.jl:20-31, src/proj_lambert.jl:245-300) */
 int cmbl_rfft(cmbl_ctx* ctx, const void* map, void* fourier, int npol, int nbatch);
@@ -90,6 +103,21 @@ int cmbl_blockdiag_ieb_apply(cmbl_ctx* ctx, const void* te_bb, int transpose,
 /* ---- per-batch reductions: dot, logdet (src/proj_lambert.jl:318-342) */
 int cmbl_dot(cmbl_ctx* ctx, int basis, const void* a, const void* b, int npol, int nbatch, double* out_host);
 int cmbl_logdet(cmbl_ctx* ctx, const void* diag_fourier, int nplanes, double* out_host);
+/* norm(f) = sqrt(dot(f,f)) (src/generic.jl:373), one value per batch slot */
+int cmbl_norm(cmbl_ctx* ctx, int basis, const void* a, int npol, int nbatch, double* out_host);
+/* logdet / tr of Diagonal(field) (src/proj_lambert.jl:331-353), per batch slot.  basis MAP: `diag` is a real map,
+ * logdet = sum log|d| + log(prod sign d) -- NaN for an odd number of negative entries (Julia's log(-1.0) throws), -Inf with a
+ * zero entry; FOURIER / HARMONIC: `diag` is a complex half-plane field, logdet = sum lambda_rfft * log|d| (non-finite terms
+ * dropped), tr = sum lambda_rfft * Re d. */
+int cmbl_logdet_diag(cmbl_ctx* ctx, int basis, const void* diag, int npol, int nbatch, double* out_host);
+int cmbl_tr_diag(cmbl_ctx* ctx, int basis, const void* diag, int npol, int nbatch, double* out_host);
+/* set_sum_accuracy_mode! (src/util.jl:288-316) for every reduction of this context (dot, norm, logdet, tr, the quadratic forms
+ * of logpdf, the conjugate-gradient residuals).  Every term is formed in the working precision like the reference's broadcast;
+ * the mode selects how the terms are added: WORKING = plain sum in the working precision (the reference's default `nothing`),
+ * FLOAT64 = sum(Float64.(A)), KAHAN = compensated (sum_kbn).  The engine's default is FLOAT64: the reductions are HBM-bound
+ * and double accumulation is free, whereas fp32 accumulation of ~1e6 terms loses the O(1) differences HMC accepts on. */
+enum { CMBL_SUM_WORKING = 0, CMBL_SUM_FLOAT64 = 1, CMBL_SUM_KAHAN = 2 };
+int cmbl_set_sum_accuracy_mode(cmbl_ctx* ctx, int mode);
 
 /* ---- LenseFlow: LenseFlow / CachedLenseFlow, precompute!!, the four flow operators and the two
  *      Zygote pullbacks (src/lenseflow.jl:19-214, src/flowops.jl:11-14, 40-68) */

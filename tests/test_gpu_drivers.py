@@ -55,7 +55,7 @@ def test_max_lensing_step(prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("pol", ["P", "I"])
+@pytest.mark.parametrize("pol", ["P", "I", "IP"])
 def test_map_joint_step(prec, pol):
     C, so, sd = _dataset_pair(prec, pol, (64, 64), mask=False, beam=1.0)
     ods, ds, p = so["ds"], sd["ds"], sd["proj"]
@@ -86,12 +86,13 @@ def test_map_joint_step(prec, pol):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-def test_hmc_and_gibbs_step(prec):
-    C, so, sd = _dataset_pair(prec, "P", (64, 64), mask=True, beam=1.0)
+@pytest.mark.parametrize("pol", ["P", "IP"])
+def test_hmc_and_gibbs_step(prec, pol):
+    C, so, sd = _dataset_pair(prec, pol, (64, 64), mask=True, beam=1.0)
     ods, ds, p = so["ds"], sd["ds"], sd["proj"]
     ds.set_data(C.Field(p, p.tensor(so["d"]), C.HARMONIC))
     F = lambda a, b: C.Field(p, p.tensor(a), b)
-    B, P, Nx, Ny = 1, 2, 64, 64
+    B, P, Nx, Ny = 1, ods.P, 64, 64
     wf, wn, wp = (O.white_noise(s, (B, P if s < 9 else 1, Nx, Ny), np.float64) for s in (7, 8, 9))
     logu = np.log(np.random.default_rng(3).random(B))
     # HMC alone from the truth: ΔH, proposal and acceptance agree
@@ -334,3 +335,48 @@ def test_sample_joint_with_theta_pass():
     assert len(th) == 3 and all(xs[0] <= a <= xs[-1] for a in th) and len(set(th)) > 1
     assert ds.theta["Aphi"] == th[-1] and np.all(np.isfinite(out["logpdf"]))
     C.set_theta(ds)
+
+
+def test_sample_joint_theta_is_saved_and_resumed(tmp_path):
+    """θ is part of every saved sample and a resumed θ chain continues the saved one (src/sampling.jl:226-228,247-256):
+    4 + 2 resumed steps == 6 uninterrupted steps, and load_chains gives the θ posterior samples."""
+    import cmblensing_jl_amd as C
+    from bench import synthetic_cls
+    s = C.load_sim(3.0, (64, 64), "P", synthetic_cls(), T=torch.float64, beam_fwhm=1.0, Nphi="flat")
+    ds = s["ds"]
+    xs = np.linspace(0.5, 2.0, 10)
+    run = dict(chain_ids=(0,), base_seed=5, N=3, eps=0.01, rng="device", theta_ranges=dict(Aphi=xs), nfilewrite=2, nsavemaps=2)
+    fa, fb = str(tmp_path / "a.zip"), str(tmp_path / "b.zip")
+    ra = C.sample_joint(ds, 6, filename=fa, **run)
+    C.set_theta(ds)
+    C.sample_joint(ds, 4, filename=fb, **run)
+    C.set_theta(ds)                                                    # the resumed run must take θ from the file, not from the dataset
+    rb = C.sample_joint(ds, 6, filename=fb, resume=True, **run)
+    ca, cb = C.load_chains(fa), C.load_chains(fb)
+    tha = [t["Aphi"] for t in ra["theta"]]
+    np.testing.assert_allclose(ca["theta_Aphi"][0], tha, rtol=1e-12)
+    np.testing.assert_allclose(cb["theta_Aphi"][0], tha, rtol=1e-6)
+    np.testing.assert_allclose(cb["logpdf"], ca["logpdf"], rtol=1e-8)
+    assert len(rb["theta"]) == 2 and xs[0] <= tha[0] <= xs[-1]
+    C.set_theta(ds)
+
+
+def test_nan_logpdf_is_a_value_not_an_error():
+    """logpdf(Mixed) that evaluates to NaN is returned as NaN (src/maximization.jl:194-199 penalises it in the line search,
+    src/sampling.jl:414 rejects the proposal); it must not abort the run."""
+    import cmblensing_jl_amd as C
+    from bench import synthetic_cls
+    s = C.load_sim(3.0, (64, 64), "P", synthetic_cls(), T=torch.float32, beam_fwhm=1.0, Nphi="flat")
+    ds, p = s["ds"], s["proj"]
+    fo, po = ds.mix(s["f"], s["phi"])
+    bad = C.Field(p, po.arr * float("nan"), C.FOURIER)
+    lp = ds.logpdf_mixed(fo, bad)
+    assert np.isnan(lp[0])
+    lp, gf, gp = ds.gradient_logpdf_mixed(fo, bad)
+    assert np.isnan(lp[0])
+    # an absurd step bound drives the line search into NaN territory: the step still succeeds with a finite, improved logpdf
+    st = C.MAP_joint_step(ds, C.Field(p, torch.zeros_like(po.arr), C.FOURIER), alpha_max=1e30, cg_tol=0.0, cg_nsteps=5)
+    assert np.isfinite(st["logpdf"][0]) and np.isfinite(st["alpha"])
+    # HMC: a NaN ΔH is a rejection
+    x, dH, acc = C.hmc_step(ds, fo, bad, np.zeros((1, 1, 64, 64)), np.log([0.5]), N=2, eps=0.01)
+    assert np.isnan(dH[0]) and not acc[0]

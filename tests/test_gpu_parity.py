@@ -124,16 +124,17 @@ def test_reductions_and_diag_ops(prec):
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(128, 128, 1, 1, 1), (64, 128, 2, 1, 1), (128, 64, 3, 1, 1), (64, 64, 2, 3, 3),
                                             (64, 64, 2, 2, 1), (256, 256, 2, 1, 1)])
-def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi):
+@pytest.mark.parametrize("n", [7, 10])
+def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi, n):
     C = _pkg()
     tT, nT = DT[prec]
     oproj, simf, simp = sims(camb, Ny, Nx, P, B)
     f = simf(1).astype(nT).astype(np.float64)
     g = simf(11).astype(nT).astype(np.float64)
     phi = simp(2, Bphi).astype(nT).astype(np.float64)
-    OL = OLenseFlow(oproj, phi, 7)
+    OL = OLenseFlow(oproj, phi, n)
     p = C.ProjLambert(Ny, Nx, 2.0, tT)
-    L = C.LenseFlow(p, 7)(C.Field(p, p.tensor(phi), C.MAP))
+    L = C.LenseFlow(p, n)(C.Field(p, p.tensor(phi), C.MAP))
     F = lambda a, b: C.Field(p, p.tensor(a), b)
     tol = TOL[prec]["flow"]
     out = (L * F(f, C.MAP)).arr.cpu().numpy()
@@ -158,18 +159,19 @@ def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi):
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(128, 128, 1, 1, 1), (64, 128, 2, 1, 1), (128, 64, 3, 1, 1), (64, 64, 2, 2, 2), (64, 64, 2, 2, 1)])
 @pytest.mark.parametrize("mode", ["fwd", "inv"])
-def test_lenseflow_gradient(camb, prec, Ny, Nx, P, B, Bphi, mode):
+@pytest.mark.parametrize("n", [7, 10])
+def test_lenseflow_gradient(camb, prec, Ny, Nx, P, B, Bphi, mode, n):
     C = _pkg()
     tT, nT = DT[prec]
     oproj, simf, simp = sims(camb, Ny, Nx, P, B)
     f = simf(1).astype(nT).astype(np.float64)
     phi = simp(2, Bphi).astype(nT).astype(np.float64)
-    OL = OLenseFlow(oproj, phi, 7)
+    OL = OLenseFlow(oproj, phi, n)
     fe = OL.apply(f) if mode == "fwd" else OL.inv(f)
     fe = fe.astype(nT).astype(np.float64)
     delta = O.rfft2(simf(7)).astype(np.complex64 if prec == "f32" else np.complex128).astype(np.complex128)
     p = C.ProjLambert(Ny, Nx, 2.0, tT)
-    L = C.LenseFlow(p, 7)(C.Field(p, p.tensor(phi), C.MAP))
+    L = C.LenseFlow(p, n)(C.Field(p, p.tensor(phi), C.MAP))
     F = lambda a, b: C.Field(p, p.tensor(a), b)
     for quirk in (False, True):
         f0, df, dp = (OL.grad_apply if mode == "fwd" else OL.grad_inv)(fe, delta, alias_quirk=quirk)
@@ -181,6 +183,36 @@ def test_lenseflow_gradient(camb, prec, Ny, Nx, P, B, Bphi, mode):
     a = L.gradient(C.FLOW_FWD, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=False)[0].arr
     b = L.gradient(C.FLOW_FWD, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=True)[0].arr
     assert rel(a.cpu().numpy(), b.cpu().numpy()) > 1e-6
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("Ny,Nx,P", [(32, 32, 1), (64, 32, 2), (32, 64, 3)])
+def test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P):
+    """Independent known answer (tests/_known.py, no oracle involved): L(ϕ)*f = f(x + ∇ϕ(x)) by direct Fourier summation.
+    Pins the deflection sign / axis conventions, which the reference's self-consistency properties cannot see."""
+    from _known import bandlimited, remap_exact, deflection
+    C = _pkg()
+    tT, nT = DT[prec]
+    theta = 2.0
+    f = bandlimited(1, Nx, Ny, 0.35, 1.5, (1, P))
+    phi0 = bandlimited(2, Nx, Ny, 0.25, 3.0, ())
+    ax, ay = deflection(phi0, np.deg2rad(theta / 60))
+    phi = phi0 * 0.55 / np.sqrt(np.mean(ax ** 2 + ay ** 2))             # 0.55 pixel rms deflection
+    want, _ = remap_exact(f, phi, theta, +1.0)
+    wrong, _ = remap_exact(f, phi, theta, -1.0)
+    p = C.ProjLambert(Ny, Nx, theta, tT)
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    tol = 5e-5 if prec == "f32" else 3e-5                                # fp64 floor 3e-6..8e-6 = aliasing of the lensed field
+    for n in (7, 10):
+        L = C.LenseFlow(p, n)(F(phi[None, None], C.MAP))
+        got = (L * F(f, C.MAP)).arr.cpu().numpy()
+        assert rel(got, want) < tol, (n, rel(got, want))
+        assert rel(got, wrong) > 0.1
+        assert rel(L.ldiv(F(want, C.MAP)).arr.cpu().numpy(), f) < 3 * tol
+        g = np.random.default_rng(3).standard_normal(f.shape)
+        lhs = p.dot(p.tensor(g), p.tensor(want), C.MAP)[0]
+        rhs = (L.adjoint * F(g, C.MAP).to(C.FOURIER)).dot(F(f, C.MAP).to(C.FOURIER))[0]
+        assert abs(lhs - rhs) < 30 * tol * np.linalg.norm(g) * np.linalg.norm(want)
 
 
 def _dataset_pair(prec, pol, Nside, theta=3.0, mask=True, beam=3.0, B=1):

@@ -136,3 +136,38 @@ def test_gradientf_logpdf_and_wiener_filter():
     # Wiener-filtered map correlates with the truth
     r = ds.dot(fwf, f)[0] / np.sqrt(ds.dot(fwf, fwf)[0] * ds.dot(f, f)[0])
     assert r > 0.5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Independent pin of the conventions: LenseFlow(ϕ)*f against the exact remapping f(x + ∇ϕ(x)) evaluated by direct Fourier
+# summation (tests/_known.py).  The reference's own properties (adjoint identity, FD gradients, round trips) are blind to a
+# global sign / convention error such as f(x − ∇ϕ); this one is not (the wrong sign gives an O(1) error).
+def _remap_case(Nx, Ny, P, rms_pix, theta=2.0):
+    from _known import bandlimited, remap_exact, deflection
+    f = bandlimited(1, Nx, Ny, 0.35, 1.5, (1, P))
+    phi0 = bandlimited(2, Nx, Ny, 0.25, 3.0, ())
+    ax, ay = deflection(phi0, np.deg2rad(theta / 60))
+    phi = phi0 * rms_pix / np.sqrt(np.mean(ax ** 2 + ay ** 2))
+    want, rms = remap_exact(f, phi, theta, +1.0)
+    wrong, _ = remap_exact(f, phi, theta, -1.0)
+    assert abs(rms - rms_pix) < 1e-6 * rms_pix
+    return f, phi[None, None], want, wrong
+
+
+@pytest.mark.parametrize("Ny,Nx,P", [(32, 32, 1), (64, 32, 2), (32, 64, 1)])
+def test_lenseflow_is_the_exact_remap(Ny, Nx, P):
+    f, phi, want, wrong = _remap_case(Nx, Ny, P, 0.55)
+    proj = O.Proj(Ny, Nx, 2.0, np.float64)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    for n, tol in ((7, 3e-5), (10, 3e-5)):                 # measured 3e-6 .. 8e-6: the floor is aliasing of the (not band-limited) lensed field
+        L = LenseFlow(proj, phi, n)
+        got = L.apply(f)
+        assert rel(got, want) < tol, (n, rel(got, want))
+        assert rel(got, wrong) > 0.1                       # f(x − ∇ϕ) is NOT what the flow computes
+        # the inverse flow undoes the exact remap
+        assert rel(L.inv(want), f) < 3 * tol
+        # adjoint against the exact remap:  <g, remap(f)> = <L'g, f>
+        g = np.random.default_rng(3).standard_normal(f.shape)
+        lhs = O.dot_map(g, want)[0]
+        rhs = O.dot_fourier(proj, L.adj(O.rfft2(g)), O.rfft2(f))[0]
+        assert abs(lhs - rhs) < 30 * tol * np.sqrt(O.dot_map(g, g)[0] * O.dot_map(want, want)[0])
