@@ -48,7 +48,7 @@ static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x
 // compiled column-tile shapes (lgM, R, NT):  C = R*NT >> lgM columns per workgroup
 #ifndef CMBL_COL_LIST
 #define CMBL_COL_LIST(X) X(4, 1, 256) X(5, 1, 256) X(5, 2, 256) X(6, 1, 256) X(6, 2, 256) X(7, 2, 256) X(7, 4, 256) X(8, 4, 256) X(8, 8, 256) \
-                         X(9, 4, 256) X(9, 8, 256) X(9, 16, 256) X(10, 8, 256) X(10, 16, 256) X(11, 8, 1024) \
+                         X(9, 4, 256) X(9, 8, 256) X(9, 16, 256) X(10, 8, 256) X(10, 16, 256) X(11, 8, 1024) X(11, 4, 1024) X(11, 2, 1024) \
                          X(8, 2, 512) X(8, 4, 512) X(9, 4, 512) X(9, 8, 512) X(10, 4, 512) X(10, 8, 512) X(9, 2, 1024) X(9, 4, 1024) X(10, 4, 1024)
 #endif
 #ifndef CMBL_ROW_LIST
@@ -106,6 +106,7 @@ struct Ctx : CtxBase {
   DevBuf twY, twX, lx_r, ly, lam, cos2F, sin2F, red_part, red_out;
   T dlx_over_Nx = 0;                       // dlx / Nx for the fused i*lx multiply of the d/dx row pass
   DevBuf tmpA, tmpB;                       // conversion scratch (mixed/F complex)
+  DevBuf xtmp;                             // mixed-layout side of a 2-D transform (mixed_scratch)
   static constexpr int RED_BLOCKS = 256;
 
   Ctx(int Ny_, int Nx_, double theta_, int device_, void* stream_) {
@@ -154,9 +155,9 @@ struct Ctx : CtxBase {
         s2F[(size_t)k * Nx + i] = s2[(size_t)r * Nyh + k];
         c2F[(size_t)k * Nx + i] = c2[(size_t)r * Nyh + k];
       }
-    std::vector<cx<T>> ty(M), tx(Nx / 2);
-    for (int k = 0; k < M; ++k) { double a = -2.0 * M_PI * k / Ny; ty[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
-    for (int k = 0; k < Nx / 2; ++k) { double a = -2.0 * M_PI * k / Nx; tx[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
+    std::vector<cx<T>> ty(Ny), tx(Nx);                                         // full-circle twiddle tables exp(-2 pi i k / N)
+    for (int k = 0; k < Ny; ++k) { double a = -2.0 * M_PI * k / Ny; ty[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
+    for (int k = 0; k < Nx; ++k) { double a = -2.0 * M_PI * k / Nx; tx[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
     upload(twY, ty); upload(twX, tx); upload(lx_r, lxr); upload(ly, lyv); upload(lam, lamv); upload(cos2F, c2F); upload(sin2F, s2F);
     red_part.ensure(sizeof(double) * RED_BLOCKS * 64 * 2);
     red_out.ensure(sizeof(double) * 64);
@@ -173,7 +174,7 @@ struct Ctx : CtxBase {
   // CMBL_TUNE_C forces a width, CMBL_TUNE_RX the rows per workgroup of the row kernels (tuning aids).
   struct TileY { int C, NT, R; };
   mutable TileY tile_cache[2] = {{0, 0, 0}, {0, 0, 0}};       // the choice does not depend on `slices`: made once (host launch path)
-  const int tuneC = env_int("CMBL_TUNE_C", 0), tuneNT = env_int("CMBL_TUNE_NT", 0), tuneRX = env_int("CMBL_TUNE_RX", 0);
+  const int tuneC = env_int("CMBL_TUNE_C", 0), tuneNT = env_int("CMBL_TUNE_NT", 0);
   TileY tileY(long slices, bool pair, int preferNT = 0) const {
     if (preferNT == 0 && tile_cache[pair].C > 0) return tile_cache[pair];
     static const int list[][3] = {
@@ -201,25 +202,10 @@ struct Ctx : CtxBase {
     return best;
   }
   // column tile: twiddles + C columns of an N-point (pair) or M-point (packed) transform, padded rows
-  size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
-  int pickRX(int nbuf, long rows) const {
-    int RX = tuneRX;
-    if (RX <= 0) RX = (int)std::max<long>(1, std::min<long>(4096 / ((long)nbuf * Nx), rows / 1024));
-    RX = std::max(RX, (int)((64 * 4 + Nx - 1) / Nx));                   // keep every lane of a wave busy in a radix-4 stage
-    while (RX > 1 && ldsX(RX, nbuf) > 160 * 1024) RX >>= 1;
-    CMBL_REQUIRE(ldsX(RX, nbuf) <= 160 * 1024, ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
-    return RX;
-  }
-  size_t ldsX(int RX, int nbuf) const { return ((size_t)Nx / 2 + (size_t)nbuf * RX * tile_ld(Nx)) * sizeof(cx<T>); }
-  // Row launches: rows are dealt evenly to nblk workgroups (row_range in the kernels), at most `cap` rows each.
-  // (Trimming the grid to a whole number of resident-workgroup rounds -- 1026 rows on 1024 slots -- was measured: no gain, the
-  // workgroups that take the stragglers' rows simply become the new tail.)
-  struct RowPlan { int nblk, cap; };
-  RowPlan plan_rows(int nbuf, long rows) const {
-    const int RX0 = pickRX(nbuf, rows);
-    const long nblk = (rows + RX0 - 1) / RX0;
-    return RowPlan{(int)nblk, (int)((rows + nblk - 1) / nblk)};
-  }
+  size_t ldsY(int C, bool pair = true) const { return ((size_t)2 * M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
+  // Row launches: one workgroup per group of RPW adjacent ky rows of a slice (RPW = row_rpw<T>(lgNx, row sets), kernels_fft.hpp)
+  size_t ldsX(int rpw, int nbuf) const { return ((size_t)Nx + (size_t)nbuf * rpw * row_ld(Nx)) * sizeof(cx<T>); }
+  long row_groups(long slices, int rpw) const { return slices * ((Nyh + rpw - 1) / rpw); }
 
   template <typename Fn> void dispatch_col(const TileY& t, Fn&& fn) const {
     bool done = false;
@@ -228,13 +214,9 @@ struct Ctx : CtxBase {
 #undef CMBL_X
     if (!done) fail(ERR_SHAPE, "unsupported column tile");
   }
-  // row kernels: workgroup of XNT threads
-  int pickXNT(long rows, int RX) const {
-    return 256;                                    // one-wave (64/128-thread) workgroups measured slower: less intra-row parallelism
-  }
-  template <typename Fn> void dispatch_row(int XNT, Fn&& fn) const {
+  template <typename Fn> void dispatch_row(Fn&& fn) const {
     bool done = false;
-#define CMBL_X(lgnx) if (!done && lgNx == lgnx) { fn(std::integral_constant<int, lgnx>{}, std::integral_constant<int, 256>{}); done = true; }
+#define CMBL_X(lgnx) if (!done && lgNx == lgnx) { fn(std::integral_constant<int, lgnx>{}); done = true; }
     CMBL_ROW_LIST(CMBL_X)
 #undef CMBL_X
     if (!done) fail(ERR_SHAPE, "unsupported Nx");
@@ -275,16 +257,21 @@ struct Ctx : CtxBase {
   }
   template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices, hipStream_t st = nullptr) {
     if (!st) st = stream;
-    const long rows = slices * Nyh;
-    dispatch_row(pickXNT(rows, 1), [&](auto lgnx, auto xnt) {
-      constexpr int LGNX = decltype(lgnx)::value, XNT = decltype(xnt)::value;
-      const RowPlan rp = plan_rows(1, rows);
-      CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), XNT, (k_x_fft<T, MODE, XNT, LGNX>), dim3((unsigned)rp.nblk), ldsX(rp.cap, 1), st, in, out,
-                     twX.as<cx<T>>(), lx_r.as<T>(), rows, rp.nblk);
+    CMBL_REQUIRE(in != out, ERR_ARG, "x pass cannot run in place (tiled mixed layout on one side)");
+    dispatch_row([&](auto lgnx) {
+      constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 1);
+      if constexpr (RPW > 0) {
+        CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), XNT, (k_x_fft<T, MODE, LGNX, RPW>), dim3((unsigned)row_groups(slices, RPW)), ldsX(RPW, 1), st,
+                       in, out, twX.as<cx<T>>(), dlx_over_Nx, Nyh);
+      } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
     });
   }
   // map -> F  (m_rfft, src/util_fft.jl:20)
-  void rfft2_F(const T* map, cx<T>* F, long slices) { y_r2c(map, F, slices); x_pass<0>(F, F, slices); }
+  // (the x pass reads the tiled mixed layout and writes F rows, or the reverse: it cannot run in place -- `xtmp` holds the mixed side)
+  cx<T>* mixed_scratch(long slices) { xtmp.ensure(sizeof(cx<T>) * slices * plane()); return xtmp.as<cx<T>>(); }
+  void rfft2_F(const T* map, cx<T>* F, long slices) { cx<T>* m = mixed_scratch(slices); y_r2c(map, m, slices); x_pass<0>(m, F, slices); }
+  // F -> map without a caller-provided scratch (F is left intact)
+  void F_to_map(const cx<T>* F, T* map, long slices) { cx<T>* m = mixed_scratch(slices); x_pass<1>(F, m, slices); y_c2r(m, map, slices); }
   // F -> map  (m_irfft, src/util_fft.jl:21-25); `scratch` (slices*plane) receives the x-inverse unless F may be clobbered
   void irfft2_F(const cx<T>* F, T* map, long slices, cx<T>* scratch) { x_pass<1>(F, scratch, slices); y_c2r(scratch, map, slices); }
 
@@ -384,7 +371,7 @@ struct Ctx : CtxBase {
     cx<T>* F = tmpA.as<cx<T>>();
     ref2F(in_ref, F, B);
     CMBL_LAUNCH(this, K_HARM, (k_qe_leg<T>), dim3((unsigned)((plane() + NTP - 1) / NTP)), 0, stream, F, F, lx_r.as<T>(), ly.as<T>(), lgNx, plane(), B, n, p1, p2, 0);
-    x_pass<1>(F, F, B); y_c2r(F, out_map, B);
+    F_to_map(F, out_map, B);
   }
   // (i lx)^p1 (i ly)^p2 * rfft2(map)  (or its modulus, stored in the real part) -> Fourier reference layout
   void fourier_lmul(const T* in_map, cx<T>* out_ref, int p1, int p2, bool take_abs, int B) {
@@ -420,7 +407,7 @@ struct Ctx : CtxBase {
     const long slices = (long)P * B;
     const bool have_h = (have == B_HARMONIC), want_h = (basis_out == B_HARMONIC);
     if (P >= 2 && have_h != want_h) harm(in_F, in_F, P, B, 0, nullptr, false, !have_h, !want_h);
-    if (basis_out == B_MAP) { x_pass<1>(in_F, in_F, slices); y_c2r(in_F, (T*)out, slices); }
+    if (basis_out == B_MAP) F_to_map(in_F, (T*)out, slices);
     else F2ref(in_F, (cx<T>*)out, slices);
   }
 };
@@ -523,8 +510,7 @@ struct Flow {
     // multipliers: out[comp][b][plane]
     CMBL_LAUNCH(c, K_GRADHESS, (k_gradhess_mult<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
                 c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
-    c->template x_pass<1>(gh.as<cx<T>>(), gh.as<cx<T>>(), 5L * nb);
-    c->y_c2r(gh.as<cx<T>>(), phimaps.as<T>(), 5L * nb);
+    c->F_to_map(gh.as<cx<T>>(), phimaps.as<T>(), 5L * nb);
     // p(t) at the 2n+1 stage times (the reference caches p and M^-1, src/lenseflow.jl:45-46,88-90): 2(2n+1) maps per phi slot,
     // 120 MB at 1024^2 fp32 n = 7.  M^-1(t), needed only by the delta-phi kernel, is still formed on the fly.
     const size_t ntot = (size_t)nb * c->npix(), bytes = sizeof(T) * 2 * (2 * n + 1) * ntot;
@@ -548,8 +534,7 @@ struct Flow {
     gh.ensure(sizeof(cx<T>) * 5 * nb * pl);
     CMBL_LAUNCH(c, K_GRADHESS, (k_gradhess_mult<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
                 c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
-    c->template x_pass<1>(gh.as<cx<T>>(), gh.as<cx<T>>(), 5L * nb);
-    c->y_c2r(gh.as<cx<T>>(), maps, 5L * nb);
+    c->F_to_map(gh.as<cx<T>>(), maps, 5L * nb);
   }
   // get_max_lensing_step (src/lenseflow.jl:242-256); does not touch the flow's own phi cache
   void max_lensing_step(int basis, const void* phi, const void* eta, int nb, double* out_host) {
@@ -630,7 +615,6 @@ struct Flow {
     const int K = groups(P, B);
     const long gs = slices / K;
     const auto tile = c->tileY(gs, true);
-    const long rows = gs * c->Nyh;
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
     fork(K);
     for (int step = 0; step < n; ++step)
@@ -649,12 +633,12 @@ struct Flow {
           });
           AdjXArgs<T> x{};
           x.Wx = a.Wx; x.Wy = a.Wy; x.Y0 = out + so; x.acc = Yacc.as<cx<T>>() + so; x.Hnext = H.as<cx<T>>() + so;
-          x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.rows = rows; x.rk = rk;
-          c->dispatch_row(c->pickXNT(rows, 1), [&](auto lgnx, auto xnt) {
-            constexpr int XNT = decltype(xnt)::value;
-            const auto rp = c->plan_rows(2, rows);
-            x.RX = rp.cap; x.nblk = rp.nblk;
-            CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, XNT, decltype(lgnx)::value>), dim3((unsigned)rp.nblk), c->ldsX(rp.cap, 2), st, x);
+          x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.Nyh = c->Nyh; x.rk = rk;
+          c->dispatch_row([&](auto lgnx) {
+            constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
+            if constexpr (RPW > 0) {
+              CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, LGNX, RPW>), dim3((unsigned)c->row_groups(gs, RPW)), c->ldsX(RPW, 2), st, x);
+            } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
           });
         }
       }
@@ -681,9 +665,6 @@ struct Flow {
     const int K = groups(P, B);
     const long gs = slices / K;
     const auto tile = c->tileY(gs, true);
-    const long rows = gs * c->Nyh;
-    const int RX = c->pickRX(2, rows);
-    const int nb_adj = (int)((rows + RX - 1) / RX);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
     c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);                // later d/dx passes ride along with the previous stage's row launch
     tc_host.resize(2 * (size_t)nst);
@@ -712,12 +693,14 @@ struct Flow {
           // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_nxt holds A_{s+1} after this column launch)
           AdjXArgs<T> x{};
           x.Wx = d.Wx; x.Wy = d.Wy; x.Y0 = df + sp; x.acc = Yacc.as<cx<T>>() + sp; x.Hnext = H.as<cx<T>>() + sp;
-          x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.RX = RX; x.nblk = nb_adj; x.rows = rows; x.rk = rk;
-          GradXArgs<T> gx{a_nxt + sp, Gx.as<cx<T>>() + sp, x.twX, c->dlx_over_Nx, rows, nb_adj};
-          c->dispatch_row(c->pickXNT(rows, RX), [&](auto lgnx, auto xnt) {
-            constexpr int XNT = decltype(xnt)::value;
-            CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, XNT, decltype(lgnx)::value>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))),
-                           c->ldsX(RX, 2), st, x, gx, nb_adj);
+          x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.Nyh = c->Nyh; x.rk = rk;
+          GradXArgs<T> gx{a_nxt + sp, Gx.as<cx<T>>() + sp, x.twX, c->dlx_over_Nx, c->Nyh};
+          c->dispatch_row([&](auto lgnx) {
+            constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
+            if constexpr (RPW > 0) {
+              const int nb_adj = (int)c->row_groups(gs, RPW);
+              CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, LGNX, RPW>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))), c->ldsX(RPW, 2), st, x, gx, nb_adj);
+            } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
           });
         }
         std::swap(a_cur, a_nxt);
@@ -822,17 +805,22 @@ struct Dataset {
   }
   long fsize(int B) const { return (long)P * B * c->plane(); }
 
+  // x (QU Fourier, F layout) <- rfft2(mask .* irfft2(x)): x pass, column kernel (c2r, mask, r2c in LDS), x pass
+  void pixel_mask(cx<T>* x, long sl) {
+    cx<T>* m = c->mixed_scratch(sl);
+    c->template x_pass<1>(x, m, sl); c->y_mask(m, m, ops[OP_MPIX].d[0], sl); c->template x_pass<0>(m, x, sl);
+  }
   // x (harmonic F) -> M x = Mf * (Mpix * x) ; transpose: Mpix' * (Mf' * x)   (src/dataset.jl:279-285)
   void apply_M(cx<T>* x, int B, bool transpose) {
     const long sl = (long)P * B;
     if (!has(OP_MPIX)) { apply(OP_MF, x, x, B, transpose); return; }
     if (!transpose) {
       c->harm(x, x, P, B, 0, nullptr, false, false, true);                 // -> QU Fourier
-      c->template x_pass<1>(x, x, sl); c->y_mask(x, x, ops[OP_MPIX].d[0], sl); c->template x_pass<0>(x, x, sl);
+      pixel_mask(x, sl);
       apply(OP_MF, x, x, B, false, true, false);
     } else {
       apply(OP_MF, x, x, B, true, false, true);
-      c->template x_pass<1>(x, x, sl); c->y_mask(x, x, ops[OP_MPIX].d[0], sl); c->template x_pass<0>(x, x, sl);
+      pixel_mask(x, sl);
       c->harm(x, x, P, B, 0, nullptr, false, true, false);
     }
   }
@@ -842,7 +830,7 @@ struct Dataset {
     const long sl = (long)P * B;
     mp2.ensure(sizeof(T) * sl * c->npix());
     c->harm(f_h, out, P, B, 0, nullptr, false, false, true);
-    c->template x_pass<1>(out, out, sl); c->y_c2r(out, mp2.template as<T>(), sl);
+    c->F_to_map(out, mp2.template as<T>(), sl);
     L.flow_map(mp2.template as<T>(), mp2.template as<T>(), P, B, false);
     c->rfft2_F(mp2.template as<T>(), out, sl);
     apply(OP_B, out, out, B, false, true, false);
@@ -1004,7 +992,7 @@ struct Dataset {
     // pullback through fhat = L \ f° : delta flow t 0->1 from (fhat, w, 0)
     L.flow_delta(fhat.template as<T>(), w, dphi2.template as<cx<T>>(), P, B, false, quirk);
     // d/df° in f°'s basis (QU map)
-    c->template x_pass<1>(w, w, sl); c->y_c2r(w, gfo, sl);
+    c->F_to_map(w, gfo, sl);
     // g_phi = dphi1 + dphi2 - Cphi^-1 phi ; d/dphi° = G' \ g_phi
     cx<T>* g = dphi1.template as<cx<T>>();
     c->lincomb1((T*)g, (const T*)g, (const T*)dphi2.p, 1.0, 1.0, 2 * pl, B);

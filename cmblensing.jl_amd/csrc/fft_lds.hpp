@@ -17,9 +17,11 @@
 // c2r drops Im A[0] and Im A[M] exactly like FFTW / pocketfft / cuFFT do (the src/util_fft.jl:21-25 path relies on it:
 // the reference feeds irfft non-Hermitian input, src/proj_lambert.jl:63-64).
 //
-// tw[] is an LDS table exp(-2*pi*i*k/Ntw), k < Ntw/2 (Ntw = 2^LGNTW); a transform of length n <= Ntw uses stride Ntw/n.
+// tw[] is an LDS table exp(-2*pi*i*k/Ntw), k < Ntw (Ntw = 2^LGNTW, the FULL circle: the external twiddles W_n^(jk) of a radix-16
+// stage run over nearly all of it); a transform of length n <= Ntw uses stride Ntw/n.
 #pragma once
 #include "common.hpp"
+#include "fft_core.hpp"
 
 #ifndef CMBL_STAGE_SYNC
 #define CMBL_STAGE_SYNC() __syncthreads()
@@ -40,25 +42,6 @@ __device__ __forceinline__ void load_twiddles(cx<T>* tw_lds, const cx<T>* __rest
   for (int i = threadIdx.x; i < nhalf; i += NT) tw_lds[i] = tw_g[i];
 }
 
-// exp(-2 pi i k/16), k = 0..7 (compile-time after unrolling)
-template <typename T> __device__ __forceinline__ cx<T> root16(int k) {
-  constexpr double c[8] = {1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0,
-                           -0.38268343236508977, -0.70710678118654752, -0.92387953251128674};
-  constexpr double s[8] = {0.0, -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
-                           -0.92387953251128674, -0.70710678118654752, -0.38268343236508977};
-  return mk<T>((T)c[k], (T)s[k]);
-}
-template <typename T> __device__ __forceinline__ cx<T> mul_root16(cx<T> a, int k) {       // a * exp(-2 pi i k/16)
-  if (k == 0) return a;
-  if (k == 4) return mul_mi(a);
-  return a * root16<T>(k);
-}
-template <typename T> __device__ __forceinline__ cx<T> mul_root16c(cx<T> a, int k) {      // a * exp(+2 pi i k/16)
-  if (k == 0) return a;
-  if (k == 4) return mul_i(a);
-  return cmulconj(a, root16<T>(k));
-}
-
 // ---- stage schedule: levels per stage as even as possible over ceil(lgN/4) stages (9 -> 3,3,3 ; 10 -> 4,3,3 ; 5 -> 3,2)
 // MAXLG caps the radix (2^MAXLG): 4 = radix-16 (fewest barriers), 3 = radix-8 (half the registers, one more round trip).
 constexpr int stage_levels(int remaining, int maxlg = 4) { return (remaining + ((remaining + maxlg - 1) / maxlg) - 1) / ((remaining + maxlg - 1) / maxlg); }
@@ -66,97 +49,112 @@ constexpr int num_stages(int lgN, int maxlg = 4) { int n = 0; while (lgN > 0) { 
 constexpr int stage_lg(int lgN, int idx, int maxlg = 4) { int lg = 0; for (int i = 0; i <= idx; ++i) { lg = stage_levels(lgN, maxlg); lgN -= lg; } return lg; }
 constexpr int levels_after(int lgN, int idx, int maxlg = 4) { int tot = 0; for (int i = 0; i <= idx; ++i) tot += stage_lg(lgN, i, maxlg); return lgN - tot; }
 
-// One fused DIF stage: LG radix-2 levels with spans h = 2^LGH (top) ... hmin = 2^(LGH-LG+1).
-template <typename T, int NT, int LD, int LGN, int LGNTW, int LGH, int LG>
-__device__ __forceinline__ void dif_stage(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
-  constexpr int r = 1 << LG, lghmin = LGH - LG + 1, hmin = 1 << lghmin, lgnb = LGN - LG;
-  for (int q = threadIdx.x; q < (S << lgnb); q += NT) {
-    const int seq = q >> lgnb, rr = q & ((1 << lgnb) - 1);
+// ---- who does what in a stage ------------------------------------------------------------------------------------------------
+// WorkCoop: the NT threads of the workgroup share S sequences (column tiles); stages are separated by workgroup barriers.
+template <int NT> struct WorkCoop {
+  int S;
+  template <int LGNB, typename F> __device__ __forceinline__ void each(F&& f) const {
+    for (int q = threadIdx.x; q < (S << LGNB); q += NT) f(q >> LGNB, q & ((1 << LGNB) - 1));
+  }
+  __device__ __forceinline__ void sync() const { CMBL_STAGE_SYNC(); }
+};
+// WorkRows: RT consecutive threads own row `threadIdx.x / RT` of each of NA arrays (sequence a*RPW + row); rows >= nr are absent.
+// With RT = 64 a row belongs to ONE wavefront: LDS operations of a wave execute in order, so the stages of a row need no barrier.
+template <int RT, int RPW> struct WorkRows {
+  int NA, nr;
+  template <int LGNB, typename F> __device__ __forceinline__ void each(F&& f) const {
+    const int row = threadIdx.x / RT, lane = threadIdx.x % RT;
+    if (row < nr)
+      for (int a = 0; a < NA; ++a)
+        for (int rr = lane; rr < (1 << LGNB); rr += RT) f(a * RPW + row, rr);
+  }
+  __device__ __forceinline__ void sync() const {
+    if constexpr (RT <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+  }
+};
+
+// One fused DIF stage = LG radix-2 levels with spans h = 2^LGH (top) ... hmin = 2^(LGH-LG+1), evaluated as ONE r-point DFT per
+// thread (r = 2^LG, fft_core.hpp) followed by the external twiddles: with a[m] = x[b0 + m hmin], n = r hmin,
+//     x[b0 + brev_LG(k) hmin] <- W_n^(j k) * sum_m a[m] W_r^(m k),     W_n = exp(-2 pi i / n),  j = b0 mod hmin
+// (tools/fft_proto.py: identical to the level-by-level network).  tw[] covers the full circle, so W_n^(jk) is one table read.
+template <typename T, int LD, int LGN, int LGNTW, int LGH, int LG, typename W>
+__device__ __forceinline__ void dif_stage(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw) {
+  using V = typename vreg<T>::type;
+  constexpr int r = 1 << LG, lghmin = LGH - LG + 1, hmin = 1 << lghmin, lgnb = LGN - LG, sh = LGNTW - (LGH + 1);
+  wk.template each<lgnb>([&](int seq, int rr) {
     const int blk = rr >> lghmin, j = rr & (hmin - 1);
     cx<T>* p = s + seq * LD + pad((blk << (LGH + 1)) + j);
-    cx<T> v[r];
+    V v[r];
 #pragma unroll
-    for (int m = 0; m < r; ++m) v[m] = p[pad(m << lghmin)];       // pad(base + m*hmin) == pad(base) + pad(m*hmin) here
+    for (int m = 0; m < r; ++m) v[m] = vload(p + pad(m << lghmin));     // pad(base + m*hmin) == pad(base) + pad(m*hmin) here
+    dft<T, LG, false>(v);
 #pragma unroll
-    for (int t = 0; t < LG; ++t) {
-      // level t: span h_t = h >> t ; pairs (m, m + r/2^(t+1)) inside groups of r/2^t
-      const cx<T> w = tw[j << (LGNTW - (LGH - t) - 1)];            // W_{2 h_t}^j
-      const int half = r >> (t + 1);
-#pragma unroll
-      for (int m = 0; m < r; ++m) {
-        if ((m & half) == 0) {
-          const int mp = m & (half - 1);                            // position inside the half group
-          const cx<T> a = v[m], b = v[m + half];
-          v[m] = a + b;
-          // twiddle W_{2h_t}^{j + mp*hmin} = w * W_{r/2^t}^{mp} = w * root16^(mp * 16 / (r >> t))
-          v[m + half] = mul_root16((a - b) * w, mp << (4 - (LG - t)));
-        }
-      }
+    for (int k = 0; k < r; ++k) {
+      V x = v[dft_loc<LG>(k)];
+      if (hmin > 1 && k > 0) x = vmul(x, vload(tw + ((j * k) << sh)));
+      vstore(p + pad(brevc<LG>(k) << lghmin), x);
     }
-#pragma unroll
-    for (int m = 0; m < r; ++m) p[pad(m << lghmin)] = v[m];
-  }
-  CMBL_STAGE_SYNC();
+  });
+  wk.sync();
 }
 
-// One fused DIT stage: LG levels with spans hmin = 2^LGH (bottom) ... hmin * 2^(LG-1).
+// One fused DIT stage = LG levels with spans hmin = 2^LGH (bottom) ... hmin * 2^(LG-1): the transpose of the above,
+//     x[b0 + m hmin] <- sum_k conj(W_r^(m k)) * conj(W_n^(j k)) * x[b0 + brev_LG(k) hmin]
 struct NoPre { template <typename V> __device__ __forceinline__ V operator()(V v, int) const { return v; } };
 
-template <typename T, int NT, int LD, int LGN, int LGNTW, int LGH, int LG, typename PRE = NoPre>
-__device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
-  constexpr int r = 1 << LG, hmin = 1 << LGH, lgnb = LGN - LG;
-  for (int q = threadIdx.x; q < (S << lgnb); q += NT) {
-    const int seq = q >> lgnb, rr = q & ((1 << lgnb) - 1);
+template <typename T, int LD, int LGN, int LGNTW, int LGH, int LG, typename W, typename PRE = NoPre>
+__device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
+  using V = typename vreg<T>::type;
+  constexpr int r = 1 << LG, hmin = 1 << LGH, lgnb = LGN - LG, sh = LGNTW - (LGH + LG);
+  wk.template each<lgnb>([&](int seq, int rr) {
     const int blk = rr >> LGH, j = rr & (hmin - 1);
     const int b0 = (blk << (LGH + LG)) + j;                          // logical (unpadded) index of element m = 0
     cx<T>* p = s + seq * LD + pad(b0);
-    cx<T> v[r];
+    V v[r];
 #pragma unroll
-    for (int m = 0; m < r; ++m) v[m] = pre(p[pad(m << LGH)], b0 + (m << LGH));   // pre: pointwise op fused into the first stage
-#pragma unroll
-    for (int t = 0; t < LG; ++t) {
-      // level t: span h_t = hmin << t ; pairs (m, m + 2^t) inside groups of 2^(t+1)
-      const cx<T> w = tw[j << (LGNTW - (LGH + t) - 1)];            // W_{2 h_t}^j  (conjugated below)
-      const int half = 1 << t;
-#pragma unroll
-      for (int m = 0; m < r; ++m) {
-        if ((m & half) == 0) {
-          const int mp = m & (half - 1);
-          const cx<T> a = v[m];
-          // conj( W_{2h_t}^{j + mp*hmin} ) = conj(w) * conj(W_{2^(t+1)}^{mp})
-          const cx<T> b = mul_root16c(cmulconj(v[m + half], w), mp << (4 - (t + 1)));
-          v[m] = a + b;
-          v[m + half] = a - b;
-        }
-      }
+    for (int k = 0; k < r; ++k) {                                    // frequency k of the group sits at position brev(k)
+      const int m = brevc<LG>(k);
+      V x = vfrom(pre(*(p + pad(m << LGH)), b0 + (m << LGH)));       // pre: pointwise op fused into the first stage
+      if (hmin > 1 && k > 0) x = vmulc(x, vload(tw + ((j * k) << sh)));
+      v[k] = x;
     }
+    dft<T, LG, true>(v);
 #pragma unroll
-    for (int m = 0; m < r; ++m) p[pad(m << LGH)] = v[m];
-  }
-  CMBL_STAGE_SYNC();
+    for (int m = 0; m < r; ++m) vstore(p + pad(m << LGH), v[dft_loc<LG>(m)]);
+  });
+  wk.sync();
 }
 
 // ---- forward, DIF: natural -> bit-reversed -------------------------------------------------------
-template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, int I = 0>
-__device__ __forceinline__ void fft_dif(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
+template <typename T, int LD, int LGN, int LGNTW, int MAXLG, typename W, int I = 0>
+__device__ __forceinline__ void fft_dif_w(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw) {
   if constexpr (I < num_stages(LGN, MAXLG)) {
     constexpr int LG = stage_lg(LGN, I, MAXLG);
     constexpr int LGH = levels_after(LGN, I, MAXLG) + LG - 1;      // top span index of this stage
-    dif_stage<T, NT, LD, LGN, LGNTW, LGH, LG>(s, S, tw);
-    fft_dif<T, NT, LD, LGN, LGNTW, MAXLG, I + 1>(s, S, tw);
+    dif_stage<T, LD, LGN, LGNTW, LGH, LG>(s, wk, tw);
+    fft_dif_w<T, LD, LGN, LGNTW, MAXLG, W, I + 1>(s, wk, tw);
   }
+}
+template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4>
+__device__ __forceinline__ void fft_dif(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
+  fft_dif_w<T, LD, LGN, LGNTW, MAXLG>(s, WorkCoop<NT>{S}, tw);
 }
 
 // ---- inverse, DIT: bit-reversed -> natural (unnormalised); the forward schedule replayed backwards ----
-template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, int I = num_stages(LGN, MAXLG) - 1, typename PRE = NoPre>
-__device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
+template <typename T, int LD, int LGN, int LGNTW, int MAXLG, typename W, typename PRE = NoPre, int I = num_stages(LGN, MAXLG) - 1>
+__device__ __forceinline__ void fft_dit_w(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
   if constexpr (I >= 0) {
     constexpr int LG = stage_lg(LGN, I, MAXLG);
     constexpr int LGH = levels_after(LGN, I, MAXLG);               // bottom span index of this stage
-    if constexpr (I == num_stages(LGN, MAXLG) - 1) dit_stage<T, NT, LD, LGN, LGNTW, LGH, LG, PRE>(s, S, tw, pre);   // pre applies to the bit-reversed input
-    else dit_stage<T, NT, LD, LGN, LGNTW, LGH, LG>(s, S, tw);
-    fft_dit<T, NT, LD, LGN, LGNTW, MAXLG, I - 1>(s, S, tw);
+    if constexpr (I == num_stages(LGN, MAXLG) - 1) dit_stage<T, LD, LGN, LGNTW, LGH, LG, W, PRE>(s, wk, tw, pre);   // pre applies to the bit-reversed input
+    else dit_stage<T, LD, LGN, LGNTW, LGH, LG>(s, wk, tw);
+    fft_dit_w<T, LD, LGN, LGNTW, MAXLG, W, NoPre, I - 1>(s, wk, tw);
   }
+}
+template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, typename PRE = NoPre>
+__device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
+  fft_dit_w<T, LD, LGN, LGNTW, MAXLG, WorkCoop<NT>, PRE>(s, WorkCoop<NT>{S}, tw, pre);
 }
 
 // ---- packed real <-> half spectrum, in place on the tile ------------------------------------------

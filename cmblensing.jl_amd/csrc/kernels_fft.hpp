@@ -3,7 +3,7 @@
 // Layouts (P*B "slices" always outermost):
 //   map      : real   [slice][x][y]            (== reference (Ny,Nx,P,B) column-major, src/proj_cartesian.jl:13-36)
 //   ref      : cplx   [slice][x][ky]           (== reference half-plane (Ny/2+1,Nx,P,B))
-//   mixed    : cplx   [slice][ky][x]           y-transformed only, x natural      (internal)
+//   mixed    : cplx   [slice][x/4][ky][x%4]    y-transformed only, x natural      (internal, tiled: see mix_idx)
 //   F        : cplx   [slice][ky][xr]          fully transformed, xr = bitrev(kx) (internal Fourier layout)
 // The y pass ("column kernel") owns the transposition: it reads/writes whole contiguous columns on the map
 // side and C-wide segments on the [ky][x] side.  The x pass ("row kernel") then works on contiguous rows.
@@ -31,13 +31,18 @@ namespace cmbl {
 #ifdef CMBL_STAMPS
 __device__ unsigned long long g_stamps[8192 * 16];
 #define CMBL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = clock64(); } while (0)
+// slots 14 / 15: entry / exit on the 100 MHz wall clock, which all XCDs share (launch timeline across the chip)
+#define CMBL_WSTAMP(i) do { if (threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define CMBL_STAMP(i) do {} while (0)
+#define CMBL_WSTAMP(i) do {} while (0)
 #endif
 #ifdef CMBL_STAMPS_X
 #define CMBL_XSTAMP(i) CMBL_STAMP(i)
+#define CMBL_XWSTAMP(i) CMBL_WSTAMP(i)
 #else
 #define CMBL_XSTAMP(i) do {} while (0)
+#define CMBL_XWSTAMP(i) do {} while (0)
 #endif
 
 // register budget of the row kernels (waves per SIMD the compiler must leave room for; fp32 only)
@@ -47,6 +52,15 @@ template <typename T> constexpr int row_min_waves() { return sizeof(T) == 4 ? CM
 // on XCD b % 8 (speed only, never correctness), so give every XCD a contiguous range of tiles: its private L2 then sees
 // both halves of each shared line.
 __device__ __forceinline__ int xcd_tile(int b, int nb) { return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3); }
+
+// The "mixed" arrays (y-transformed, x natural) are what column kernels hand to row kernels and back, so one side always reads
+// them across its natural direction.  As [ky][x] the column tiles (C = 4 columns) pull 32-byte pieces 8 KB apart: measured
+// (tools/micro/ldbench.hip) 11.0 us for the 16.8 MB of a launch's (Gx, A) tiles against 2.9 us for the same bytes as contiguous
+// blocks -- the largest single cost in the round-1 column kernels (first LDS commit at 14k of a 39k-cycle workgroup).  Hence the
+// tiled layout  [x/4][ky][x%4]: a column tile of 4 columns is ONE contiguous block of (Ny/2+1)*4 values, and a row workgroup that
+// takes 4 adjacent ky rows gathers whole 128-byte lines (4 rows x 4 values), which is as fast as contiguous rows (2.9 us / 2.9 us).
+constexpr int MIXW = 4, LGMIXW = 2;
+__device__ __forceinline__ size_t mix_idx(int ky, int x, int Nyh) { return ((size_t)(x >> LGMIXW) * Nyh + ky) * MIXW + (x & (MIXW - 1)); }
 
 // ---------------------------------------------------------------------------------------------
 // ref <-> F  (transpose + bit reversal of x), V = cx<T> or T.   grid (Nx/32, ceil(Nyh/32), slices), block 256
@@ -128,7 +142,7 @@ template <typename T, int NT, int LGM, int LGC> struct TileStage {           // 
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int e = threadIdx.x + i * NT;
-      if (e < TOT) v[i] = g[(size_t)(e >> LGC) * Nx + x0 + (e & (C - 1))];
+      if (e < TOT) v[i] = g[mix_idx(e >> LGC, x0 + (e & (C - 1)), M + 1)];
     }
   }
   template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
@@ -144,7 +158,7 @@ __device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx
   constexpr int M = 1 << LGM, C = 1 << LGC;
   for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
     const int c = e & (C - 1), k = e >> LGC;
-    g[(size_t)k * Nx + x0 + c] = s[c * LD + hslot<LGM>(k)];
+    g[mix_idx(k, x0 + c, M + 1)] = s[c * LD + hslot<LGM>(k)];
   }
 }
 
@@ -162,7 +176,7 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
       const int e = threadIdx.x + i * NT;
       if (e < TOT) {
         const int k = e >> LGC;
-        const size_t gi = (size_t)k * Nx + x0 + (e & (C - 1));
+        const size_t gi = mix_idx(k, x0 + (e & (C - 1)), M + 1);
         X[i] = gX[gi]; Y[i] = gY[gi]; l[i] = ly[k];
       }
     }
@@ -185,35 +199,108 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
     }
   }
 };
-// Row kernels: `rows` rows are dealt to `nblk` workgroups as evenly as possible (the first rows % nblk workgroups take one more).
-// LDS row capacity of a workgroup = ceil(rows / nblk).
-__device__ __forceinline__ void row_range(long rows, int nblk, long blk, long& r0, int& nr) {
-  const long base = rows / nblk, extra = rows - base * nblk;
-  r0 = blk * base + (blk < extra ? blk : extra);
-  nr = (int)base + (blk < extra ? 1 : 0);
+// ---- row workgroups --------------------------------------------------------------------------------------------------------------
+// A row workgroup (XNT = 256 threads) takes RPW adjacent ky rows of one slice, all x: RT = XNT / RPW consecutive threads own a row
+// through every transform stage (WorkRows in fft_lds.hpp; RPW = 4: one wavefront per row, no barriers between stages).  Its
+// mixed-layout side is a gather / scatter of RPW x 4 values per x/4 (one 128-byte line for RPW = 4, fp32), its F-layout side
+// contiguous rows.  Row r of the group sits at LDS offset r * row_ld(Nx); row_ld = 4 (mod 16) slots, so that the 16 lanes
+// that write one gathered line (4 rows x 4 values) hit 16 different bank pairs.
+#ifndef CMBL_ROW_ROT
+#define CMBL_ROW_ROT(ky0) 0        // per-workgroup starting point of the x/4 walk, e.g. (((ky0) * 29) >> 2): measured, no effect
+#endif
+#ifndef CMBL_XNT
+#define CMBL_XNT 256
+#endif
+constexpr int XNT = CMBL_XNT;
+__host__ __device__ constexpr int row_ld(int n) { return pad(n) + ((4 - pad(n) % 16) + 16) % 16; }
+// rows per workgroup: as many of 4, 2, 1 as fit the 160 KB of LDS next to the twiddle table (NA row sets: 1, or 2 for the adjoint pass)
+template <typename T> __host__ __device__ constexpr int row_rpw(int lgnx, int na) {
+  for (int rpw = 4; rpw >= 1; rpw >>= 1)
+    if (((size_t)(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024) return rpw;
+  return 0;
 }
-// rows of Nx contiguous values -> row tiles (row kernels): the loads of one row are issued together
-template <typename T, int NT, int LGNX, int NA>
-__device__ __forceinline__ void rows_load(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], int nr) {
-  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
-  if constexpr (Nx >= NT) {
-    constexpr int PF = Nx / NT;
-    for (int r = 0; r < nr; ++r) {
-      cx<T> v[NA][PF];
+struct RowGroup { int sl, ky0, nr; };
+template <int RPW> __device__ __forceinline__ RowGroup row_group(long blk, int Nyh) {
+  const int G = (Nyh + RPW - 1) / RPW;
+  RowGroup g;
+  g.sl = (int)(blk / G); g.ky0 = (int)(blk % G) * RPW; g.nr = Nyh - g.ky0 < RPW ? Nyh - g.ky0 : RPW;
+  return g;
+}
+// 16-byte global accesses: 2 single-precision or 1 double-precision complex values
+template <typename T> struct alignas(16) CxVec { cx<T> v[16 / sizeof(cx<T>)]; };
+
+// mixed layout (slice bases g[a]) -> the NA row sets in LDS; all loads of the thread are issued before the first LDS store
+// (CMBL_ROW_ROT lets every workgroup walk x/4 from its own starting point, so that the workgroups of a launch do not touch the same
+// 16 KB window at the same moment; measured on MI355X: no difference, the default is no rotation)
+template <typename T, int LGNX, int RPW, int NA>
+__device__ __forceinline__ void rows_load_mixed(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], int Nyh, int ky0, int nr) {
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE;       // 16-byte units per row of a gathered line
+  constexpr int TOT = RPW * Nx / VE, K = (TOT + XNT - 1) / XNT;
+  const int rot = CMBL_ROW_ROT(ky0);
+  CxVec<T> v[NA][K];
 #pragma unroll
-      for (int a = 0; a < NA; ++a)
+  for (int i = 0; i < K; ++i) {
+    const int u = threadIdx.x + i * XNT, xt = (u / (UPG * RPW) + rot) & (Nx / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+    if ((TOT % XNT == 0 || u < TOT) && r < nr) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) v[a][i] = g[a][(size_t)r * Nx + threadIdx.x + i * NT];
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int i = 0; i < PF; ++i) s[a][r * LD + pad(threadIdx.x + i * NT)] = v[a][i];
+      for (int a = 0; a < NA; ++a) v[a][i] = *reinterpret_cast<const CxVec<T>*>(g[a] + ((size_t)xt * Nyh + ky0 + r) * MIXW + c);
     }
-  } else {
-    for (int e = threadIdx.x; e < nr * Nx; e += NT) {
-      const int si = (e >> LGNX) * LD + pad(e & (Nx - 1));
+  }
 #pragma unroll
-      for (int a = 0; a < NA; ++a) s[a][si] = g[a][e];
+  for (int i = 0; i < K; ++i) {
+    const int u = threadIdx.x + i * XNT, xt = (u / (UPG * RPW) + rot) & (Nx / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+    if ((TOT % XNT == 0 || u < TOT) && r < nr) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[a][r * LD + pad(xt * MIXW + c) + e] = v[a][i].v[e];        // c even: pad(x + 1) == pad(x) + 1
+    }
+  }
+}
+// LDS rows -> mixed layout, values scaled by `scale`
+template <typename T, int LGNX, int RPW>
+__device__ __forceinline__ void rows_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int Nyh, int ky0, int nr, T scale) {
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, TOT = RPW * Nx / VE;
+  const int rot = CMBL_ROW_ROT(ky0);
+  for (int u = threadIdx.x; u < TOT; u += XNT) {
+    const int xt = (u / (UPG * RPW) + rot) & (Nx / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+    if (r < nr) {
+      CxVec<T> v;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v.v[e] = scale * s[r * LD + pad(xt * MIXW + c) + e];
+      *reinterpret_cast<CxVec<T>*>(g + ((size_t)xt * Nyh + ky0 + r) * MIXW + c) = v;
+    }
+  }
+}
+// F layout: contiguous rows (g = first row of the group)
+template <typename T, int LGNX, int RPW>
+__device__ __forceinline__ void rows_load_F(cx<T>* __restrict__ s, const cx<T>* __restrict__ g, int nr) {
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), TOT = RPW * Nx / VE, K = (TOT + XNT - 1) / XNT;
+  CxVec<T> v[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int u = threadIdx.x + i * XNT, r = (u * VE) >> LGNX;
+    if ((TOT % XNT == 0 || u < TOT) && r < nr) v[i] = *reinterpret_cast<const CxVec<T>*>(g + (size_t)u * VE);
+  }
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int u = threadIdx.x + i * XNT, r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
+    if ((TOT % XNT == 0 || u < TOT) && r < nr) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) s[r * LD + pad(x) + e] = v[i].v[e];
+    }
+  }
+}
+template <typename T, int LGNX, int RPW>
+__device__ __forceinline__ void rows_store_F(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int nr, T scale) {
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), TOT = RPW * Nx / VE;
+  for (int u = threadIdx.x; u < TOT; u += XNT) {
+    const int r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
+    if (r < nr) {
+      CxVec<T> v;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v.v[e] = scale * s[r * LD + pad(x) + e];
+      *reinterpret_cast<CxVec<T>*>(g + (size_t)u * VE) = v;
     }
   }
 }
@@ -235,17 +322,17 @@ __device__ __forceinline__ void pair_split(const cx<T>* __restrict__ s, F&& f) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// y pass, forward: map -> mixed.   grid (Nx/C, slices).  LDS: twY[M] + C*tile_ld(M) cplx
+// y pass, forward: map -> mixed.   grid (Nx/C, slices).  LDS: twY[2M] (full circle) + C*tile_ld(M) cplx
 template <typename T, int R, int NT, int LGM>
 __global__ __launch_bounds__(NT) void k_y_r2c(const T* __restrict__ in, cx<T>* __restrict__ out, const cx<T>* __restrict__ twY, int Nx) {
   using G = ColTile<R, NT, LGM>;
   constexpr int M = G::M, LD = G::LDM, C = G::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + M;
+  cx<T>* s = tw + 2 * M;
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
-  TwStage<T, NT, M> twr;
+  TwStage<T, NT, 2 * M> twr;
   twr.issue(twY);
   const cx<T>* src = reinterpret_cast<const cx<T>*>(in) + (sl * Nx + x0) * (size_t)M;
   cx<T> v[R];
@@ -270,10 +357,10 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
   constexpr int M = G::M, LD = G::LDM, C = G::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + M;
+  cx<T>* s = tw + 2 * M;
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
-  TwStage<T, NT, M> twr;
+  TwStage<T, NT, 2 * M> twr;
   TileStage<T, NT, LGM, G::LGC> tl;
   twr.issue(twY);
   tl.issue(in + sl * (size_t)G::Nyh * Nx, Nx, x0);
@@ -299,10 +386,10 @@ __global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<
   constexpr int M = G::M, LD = G::LDM, C = G::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + M;
+  cx<T>* s = tw + 2 * M;
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
-  TwStage<T, NT, M> twr;
+  TwStage<T, NT, 2 * M> twr;
   TileStage<T, NT, LGM, G::LGC> tl;
   twr.issue(twY);
   tl.issue(in + sl * (size_t)G::Nyh * Nx, Nx, x0);
@@ -328,47 +415,53 @@ __global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<
 }
 
 // ---------------------------------------------------------------------------------------------
-// x pass on contiguous rows.  `rows` = slices*Nyh rows of Nx.  grid nblk.  LDS: twX[Nx/2] + ceil(rows/nblk)*tile_ld(Nx) cplx
+// x pass.  grid = slices * ceil(Nyh / RPW) row groups.  LDS: twX[Nx] + RPW * row_ld(Nx) cplx
 //   MODE 0: forward  (mixed -> F)
 //   MODE 1: inverse  (F -> mixed), scaled by 1/Nx
 //   MODE 2: x-derivative  (mixed -> mixed):  ifft_x( i*lx * fft_x(row) ) / Nx        (src/proj_lambert.jl:146-159, coord 1)
-template <typename T, int MODE, int NT, int LGNX>
-__global__ __launch_bounds__(NT, row_min_waves<T>()) void k_x_fft(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
-                                              const cx<T>* __restrict__ twX, const T* __restrict__ lx_r, long rows, int nblk) {
+template <typename T, int MODE, int LGNX, int RPW>
+__global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_x_fft(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
+                                                                  const cx<T>* __restrict__ twX, T dlx_over_Nx, int Nyh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), RT = XNT / RPW;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + (Nx >> 1);
-  long r0; int nr;
-  row_range(rows, nblk, blockIdx.x, r0, nr);
+  cx<T>* s = tw + Nx;
+  const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh);
+  const size_t mo = (size_t)rg.sl * Nyh * Nx, fo = mo + (size_t)rg.ky0 * Nx;
+  CMBL_XWSTAMP(14);
   CMBL_XSTAMP(0);
-  TwStage<T, NT, (Nx >> 1)> twr;
+  TwStage<T, XNT, Nx> twr;
   twr.issue(twX);
-  const T inv = T(1) / T(Nx);
-  const T dl = MODE == 2 ? lx_r[1] * T(-2) * inv * inv : T(0);      // lx_r[1] = lx(kx = Nx/2) = -(Nx/2) dlx
-  {
+  if (MODE == 1) rows_load_F<T, LGNX, RPW>(s, in + fo, rg.nr);
+  else {
     cx<T>* const sa[1] = {s};
-    const cx<T>* const ga[1] = {in + r0 * Nx};
-    rows_load<T, NT, LGNX, 1>(sa, ga, nr);
+    const cx<T>* const ga[1] = {in + mo};
+    rows_load_mixed<T, LGNX, RPW, 1>(sa, ga, Nyh, rg.ky0, rg.nr);
   }
   twr.commit(tw);
+  CMBL_XSTAMP(6);
   __syncthreads();
   CMBL_XSTAMP(1);
-  if (MODE == 0 || MODE == 2) fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
+  const WorkRows<RT, RPW> wk{1, rg.nr};
+  if (MODE == 0 || MODE == 2) fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
   CMBL_XSTAMP(2);
   if (MODE == 2) {
-    // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i)
-    fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw, [dl](cx<T> v, int i) {
+    // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
+    const T dl = dlx_over_Nx;
+    fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw, [dl](cx<T> v, int i) {
       const int kx = brevc<LGNX>(i);
-      return mk<T>(-(dl * T(kx < (Nx >> 1) ? kx : kx - Nx)) * v.y, (dl * T(kx < (Nx >> 1) ? kx : kx - Nx)) * v.x);
+      const T l = dl * T(kx < (Nx >> 1) ? kx : kx - Nx);
+      return mk<T>(-l * v.y, l * v.x);
     });
   }
-  if (MODE == 1) fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
+  if (MODE == 1) fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
+  CMBL_XSTAMP(5);
+  __syncthreads();
   CMBL_XSTAMP(3);
-  cx<T>* dst = out + r0 * Nx;
-  if (MODE == 1) { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = inv * s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }
-  else           { for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))]; }
+  if (MODE == 0) rows_store_F<T, LGNX, RPW>(s, out + fo, rg.nr, T(1));
+  else rows_store_mixed<T, LGNX, RPW>(s, out + mo, Nyh, rg.ky0, rg.nr, MODE == 1 ? T(1) / T(Nx) : T(1));
   CMBL_XSTAMP(4);
+  CMBL_XWSTAMP(15);
 }
 
 }  // namespace cmbl

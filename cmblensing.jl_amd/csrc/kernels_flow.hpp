@@ -116,14 +116,14 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + M;
+  cx<T>* s = tw + 2 * M;
   const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
   const size_t moff = sl * (size_t)Nyh * Nx;
   // everything this workgroup needs from HBM is requested before anything is waited for
-  TwStage<T, NT, M> twr;
+  TwStage<T, NT, 2 * M> twr;
   PairStage<T, NT, LGN, LGC> ps;
   twr.issue(a.twY);
   ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, x0);
@@ -182,13 +182,13 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + M;
+  cx<T>* s = tw + 2 * M;
   const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
   const size_t moff = sl * (size_t)Nyh * Nx;
-  TwStage<T, NT, M> twr;
+  TwStage<T, NT, 2 * M> twr;
   TileStage<T, NT, LGM, LGC> tl;
   twr.issue(a.twY);
   tl.issue(a.H + moff, Nx, x0);
@@ -220,114 +220,118 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
   cx<T>* Wx = a.Wx + moff; cx<T>* Wy = a.Wy + moff;
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
-    const size_t gi = (size_t)k * Nx + x0 + c;
+    const size_t gi = mix_idx(k, x0 + c, Nyh);
     Wx[gi] = A; Wy[gi] = mul_il(B, lyr[i]);
   });
 }
 
 // Adjoint flow, row kernel:  k = i*lx*fft_x(Wx) + fft_x(Wy')  -> RK update of the Fourier state (F layout)
-//   -> Hnext = ifft_x(next stage input) (mixed).     rows = slices*Nyh, grid ceil(rows/RX).  LDS: twX + 2*RX*tile_ld(Nx)
+//   -> Hnext = ifft_x(next stage input) (mixed).     grid = slices * ceil(Nyh / RPW) row groups.  LDS: twX + 2*RPW*row_ld(Nx)
 template <typename T> struct AdjXArgs {
   const cx<T>* Wx; const cx<T>* Wy; cx<T>* Y0; cx<T>* acc; cx<T>* Hnext;
   const cx<T>* twX; const T* lx_r;
-  int RX, nblk; long rows;          // RX = LDS row capacity of a workgroup (stride between the row sets); rows dealt to nblk workgroups
+  int Nyh;
   RKCoef<T> rk;
 };
 
-template <typename T, int NT, int LGNX>
+template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* smem, long blk) {
-  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx), PF = Nx >= NT ? Nx / NT : 1;
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), RT = XNT / RPW, PF = Nx >= RT ? Nx / RT : 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + (Nx >> 1);
-  long r0; int nr;
-  row_range(a.rows, a.nblk, blk, r0, nr);
-  cx<T>* s2 = s + (size_t)nr * LD;                            // the two row sets are adjacent: one transform call covers both
-  TwStage<T, NT, (Nx >> 1)> twr;
+  cx<T>* s = tw + Nx;
+  cx<T>* s2 = s + RPW * LD;                                   // second row set: sequence RPW + row, owned by the same threads
+  const RowGroup rg = row_group<RPW>(blk, a.Nyh);
+  const size_t mo = (size_t)rg.sl * a.Nyh * Nx;
+  TwStage<T, XNT, Nx> twr;
   twr.issue(a.twX);
-  T lxr[PF];                                                  // lx of this thread's columns (Nx >= NT: the same for every row)
-  if constexpr (Nx >= NT) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i) lxr[i] = a.lx_r[threadIdx.x + i * NT];
-  }
   {
     cx<T>* const sa[2] = {s, s2};
-    const cx<T>* const ga[2] = {a.Wx + r0 * Nx, a.Wy + r0 * Nx};
-    rows_load<T, NT, LGNX, 2>(sa, ga, nr);
+    const cx<T>* const ga[2] = {a.Wx + mo, a.Wy + mo};
+    rows_load_mixed<T, LGNX, RPW, 2>(sa, ga, a.Nyh, rg.ky0, rg.nr);
   }
   twr.commit(tw);
   __syncthreads();
-  fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, 2 * nr, tw);
+  fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, WorkRows<RT, RPW>{2, rg.nr}, tw);
+  // RK update of this thread's part of its row (F layout: contiguous in x)
+  const int row = threadIdx.x / RT, lane = threadIdx.x % RT;
   const T inv = T(1) / T(Nx);
-  if constexpr (Nx >= NT) {
-    for (int r = 0; r < nr; ++r) {                            // per row: RK state loads first, then the stores (they may alias for the compiler)
-      const long g0 = (r0 + r) * Nx;
-      cx<T> y0[PF], acc[PF];
+  if (row < rg.nr) {
+    const size_t g0 = mo + (size_t)(rg.ky0 + row) * Nx;
+    cx<T>* sr = s + row * LD; const cx<T>* sr2 = s2 + row * LD;
+    if constexpr (Nx >= RT) {
+      constexpr int CH = PF > 8 ? 8 : PF;                     // state loads in flight per thread: CH values of Y0 and of acc
+      for (int i0 = 0; i0 < PF; i0 += CH) {
+        cx<T> y0[CH], acc[CH]; T lxr[CH];
 #pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const long gi = g0 + threadIdx.x + i * NT;
-        y0[i] = a.Y0[gi];
-        acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
-      }
+        for (int i = 0; i < CH; ++i) {
+          const int x = lane + (i0 + i) * RT;
+          y0[i] = a.Y0[g0 + x];
+          acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[g0 + x];
+          lxr[i] = a.lx_r[x];
+        }
 #pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int e = threadIdx.x + i * NT, si = r * LD + pad(e);
-        const cx<T> kv = mul_il(s[si], lxr[i]) + s2[si];
-        const cx<T> fn = rk_update(a.rk, kv, y0[i], acc[i]);
-        if (a.rk.stage == 4) a.Y0[g0 + e] = y0[i]; else a.acc[g0 + e] = acc[i];
-        s[si] = inv * fn;
+        for (int i = 0; i < CH; ++i) {
+          const int x = lane + (i0 + i) * RT, si = pad(x);
+          const cx<T> kv = mul_il(sr[si], lxr[i]) + sr2[si];
+          const cx<T> fn = rk_update(a.rk, kv, y0[i], acc[i]);
+          if (a.rk.stage == 4) a.Y0[g0 + x] = y0[i]; else a.acc[g0 + x] = acc[i];
+          sr[si] = inv * fn;
+        }
       }
-    }
-  } else {
-    for (int e = threadIdx.x; e < nr * Nx; e += NT) {
-      const int i = e & (Nx - 1), si = (e >> LGNX) * LD + pad(i);
-      const cx<T> kv = mul_il(s[si], a.lx_r[i]) + s2[si];
-      const long gi = r0 * Nx + e;
-      cx<T> y0 = a.Y0[gi];
-      cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[gi];
-      cx<T> fn = rk_update(a.rk, kv, y0, acc);
-      if (a.rk.stage == 4) a.Y0[gi] = y0; else a.acc[gi] = acc;
-      s[si] = inv * fn;
+    } else {
+      for (int x = lane; x < Nx; x += RT) {
+        const int si = pad(x);
+        const cx<T> kv = mul_il(sr[si], a.lx_r[x]) + sr2[si];
+        cx<T> y0 = a.Y0[g0 + x];
+        cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[g0 + x];
+        const cx<T> fn = rk_update(a.rk, kv, y0, acc);
+        if (a.rk.stage == 4) a.Y0[g0 + x] = y0; else a.acc[g0 + x] = acc;
+        sr[si] = inv * fn;
+      }
     }
   }
   if (a.rk.last) return;
+  const WorkRows<RT, RPW> wk{1, rg.nr};
+  wk.sync();
+  fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
   __syncthreads();
-  fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
-  for (int e = threadIdx.x; e < nr * Nx; e += NT) a.Hnext[r0 * Nx + e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
+  rows_store_mixed<T, LGNX, RPW>(s, a.Hnext + mo, a.Nyh, rg.ky0, rg.nr, T(1));
 }
 
-template <typename T, int NT, int LGNX>
-__global__ __launch_bounds__(NT, row_min_waves<T>()) void k_adj_x(AdjXArgs<T> a) {
+template <typename T, int LGNX, int RPW>
+__global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_adj_x(AdjXArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  adj_x_body<T, NT, LGNX>(a, smem, blockIdx.x);
+  adj_x_body<T, LGNX, RPW>(a, smem, blockIdx.x);
 }
 
 // x-derivative row pass as a device function (same as k_x_fft<MODE 2>)
-template <typename T> struct GradXArgs { const cx<T>* in; cx<T>* out; const cx<T>* twX; T dlx_over_Nx; long rows; int nblk; };
-template <typename T, int NT, int LGNX>
+template <typename T> struct GradXArgs { const cx<T>* in; cx<T>* out; const cx<T>* twX; T dlx_over_Nx; int Nyh; };
+template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char* smem, long blk) {
-  constexpr int Nx = 1 << LGNX, LD = tile_ld(Nx);
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), RT = XNT / RPW;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + (Nx >> 1);
-  long r0; int nr;
-  row_range(g.rows, g.nblk, blk, r0, nr);
-  TwStage<T, NT, (Nx >> 1)> twr;
+  cx<T>* s = tw + Nx;
+  const RowGroup rg = row_group<RPW>(blk, g.Nyh);
+  const size_t mo = (size_t)rg.sl * g.Nyh * Nx;
+  TwStage<T, XNT, Nx> twr;
   twr.issue(g.twX);
   {
     cx<T>* const sa[1] = {s};
-    const cx<T>* const ga[1] = {g.in + r0 * Nx};
-    rows_load<T, NT, LGNX, 1>(sa, ga, nr);
+    const cx<T>* const ga[1] = {g.in + mo};
+    rows_load_mixed<T, LGNX, RPW, 1>(sa, ga, g.Nyh, rg.ky0, rg.nr);
   }
   twr.commit(tw);
   __syncthreads();
-  fft_dif<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw);
+  const WorkRows<RT, RPW> wk{1, rg.nr};
+  fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
   // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
   const T dl = g.dlx_over_Nx;
-  fft_dit<T, NT, LD, LGNX, LGNX, CMBL_XLG>(s, nr, tw, [dl](cx<T> v, int i) {
+  fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw, [dl](cx<T> v, int i) {
     const int kx = brevc<LGNX>(i);
     return mul_il(v, dl * T(kx < (Nx >> 1) ? kx : kx - Nx));
   });
-  cx<T>* dst = g.out + r0 * Nx;
-  for (int e = threadIdx.x; e < nr * Nx; e += NT) dst[e] = s[(e >> LGNX) * LD + pad(e & (Nx - 1))];
+  __syncthreads();
+  rows_store_mixed<T, LGNX, RPW>(s, g.out + mo, g.Nyh, rg.ky0, rg.nr, T(1));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -346,25 +350,30 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   const FlowYArgs<T>& a = d.f;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + M;
+  cx<T>* s = tw + 2 * M;
   const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
   const size_t moff = sl * (size_t)Nyh * Nx;
   const size_t pbase = ((size_t)bphi * Nx + x0) * M, mbase = (sl * Nx + x0) * (size_t)M;
+  CMBL_WSTAMP(14);
   CMBL_STAMP(0);
-  // requested up front: twiddles, the (Gx, A) pair tile, p(t), the delta-f tile -- one wait instead of one per loop iteration
-  TwStage<T, NT, M> twr;
+  // Loads are requested in the order they are needed and as late as their consumer allows without exposing latency: every
+  // workgroup of the launch starts at the same moment, so everything requested at t = 0 shares the memory system with the
+  // same request of 511 other workgroups -- the pair tile, which alone gates the first transform, then arrives with the LAST
+  // bytes of the burst (in-kernel stamps: first commit at 13.9k cycles of a 39k-cycle workgroup).  So: pair tile first; p(t) and
+  // the delta-f tile fly during the first transform; the RK state during the second.
+  TwStage<T, NT, 2 * M> twr;
   PairStage<T, NT, LGN, LGC> ps;
   TileStage<T, NT, LGM, LGC> th;
   twr.issue(a.twY);
   ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, x0);
+  twr.commit(tw);
+  ps.template commit<LD>(s);
   cx<T> px[R], py[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + threadIdx.x + i * NT, a.rk.t, px[i], py[i]);
   th.issue(d.H + moff, Nx, x0);
-  twr.commit(tw);
-  ps.template commit<LD>(s);
   __syncthreads();
   CMBL_STAMP(1);
   // (d/dx f, d/dy f) from one N-point inverse transform
@@ -380,20 +389,20 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   CMBL_STAMP(3);
   // L(delta f) = irfft2(delta f)
   th.template commit<LD>(s);
+  cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
+  cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
+  cx<T> fn[R], ldf[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {                               // RK state: requested now, used after the second transform
+    const int e = threadIdx.x + i * NT;
+    fn[i] = y0p[e];
+    ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
+  }
   __syncthreads();
   CMBL_STAMP(4);
   c2r_pre<T, NT, LD, LGM>(s, C, tw);
   fft_dit<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
   CMBL_STAMP(5);
-  cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
-  cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
-  cx<T> fn[R], ldf[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) {                               // RK state: all loads before any of the stores below
-    const int e = threadIdx.x + i * NT;
-    fn[i] = y0p[e];
-    ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
-  }
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
@@ -420,12 +429,12 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   {
     cx<T>* Wx = d.Wx + moff; cx<T>* Wy = d.Wy + moff;
     pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
-      const size_t gi = (size_t)k * Nx + x0 + c;
+      const size_t gi = mix_idx(k, x0 + c, Nyh);
       Wx[gi] = A; Wy[gi] = mul_il(B, ps.l[i]);                // ly[k] is still in registers from the pair load (same entry mapping)
     });
   }
   CMBL_STAMP(9);
-  if (a.rk.last) return;
+  if (a.rk.last) { CMBL_WSTAMP(15); return; }
   __syncthreads();
   // next-stage f : rfft_y
 #pragma unroll
@@ -437,6 +446,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   CMBL_STAMP(11);
   tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0);
   CMBL_STAMP(12);
+  CMBL_WSTAMP(15);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -529,12 +539,12 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_cols(Delt
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   delta_y_body<T, R, NT, LGM>(d, smem, blockIdx.y);
 }
-template <typename T, int NT, int LGNX>
-__global__ __launch_bounds__(NT, row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
+template <typename T, int LGNX, int RPW>
+__global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
-  if (b < nblk_adj) adj_x_body<T, NT, LGNX>(a, smem, b);
-  else grad_x_body<T, NT, LGNX>(g, smem, (long)b - nblk_adj);
+  if (b < nblk_adj) adj_x_body<T, LGNX, RPW>(a, smem, b);
+  else grad_x_body<T, LGNX, RPW>(g, smem, (long)b - nblk_adj);
 }
 
 // gradient / hessian multipliers for precompute (src/specialops.jl:184-188): F layout in, five F-layout outputs

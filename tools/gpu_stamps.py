@@ -1,24 +1,36 @@
-"""Phase timestamps inside k_delta_y (debug build: tools/devbuild.sh stamps -DCMBL_STAMPS):
-   CMBL_LIB=cmblensing.jl_amd/_dev/lib_stamps.so python tools/gpu_stamps.py"""
+"""Phase timestamps inside k_delta_cols (debug build: tools/devbuild.sh stamps -DCMBL_STAMPS):
+   CMBL_SLICE_STREAMS=1 CMBL_LIB=cmblensing.jl_amd/_dev/lib_stamps.so python tools/gpu_stamps.py
+(slice streams off: concurrent half-grid launches would write the same stamp slots)"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("CMBL_SLICE_STREAMS", "1")
 import numpy as np, torch
 import cmblensing_jl_amd as C
 from bench import synthetic_cls
-s = C.load_sim(2.0, 1024, "P", synthetic_cls(), T=torch.float32, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0))
+s = C.load_sim(2.0, 1024, "P", synthetic_cls(), T=torch.float32, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), Nphi="flat")
 ds, f, phi = s["ds"], s["f"], s["phi"]
 fm = f.to(C.MAP); L = ds.L(phi); gl = fm.to(C.FOURIER); ft = L * fm
 for _ in range(3):
     L.gradient(C.FLOW_FWD, ft, gl)
 torch.cuda.synchronize()
 lib = C.load_library()
-nb = 512
+nb = int(os.environ.get('NB', 512))
 buf = (ctypes.c_ulonglong * (nb * 16))()
 lib.cmbl_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.cmbl_debug_stamps(buf, nb * 16) == 0
 st = np.array(buf[:], dtype=np.uint64).reshape(nb, 16).astype(np.int64)
-swp = os.environ.get("SWAP", "0") == "1"
-for sel, lab in ((slice(0, None, 2), "even tiles (order A)"), (slice(1, None, 2), "odd tiles")) if swp else ((slice(None), "all"),):
-    t = st[sel]
-    rel = t[:, :13] - t[:, :1]
-    print(lab, "stamp times since kernel start (mean cycles):", " ".join(f"{i}:{rel[:, i].mean():.0f}" for i in range(13)))
+rel = st[:, :13] - st[:, :1]
+names = ["start", "loads committed (pair tile)", "N-pt inverse (dx,dy)", "read pair", "commit H tile", "M-pt inverse (L df)", "pointwise + RK + stores", "write pair",
+         "N-pt forward", "pair split + Wx,Wy stores", "write fn", "M-pt forward + r2c_post", "Anext store"]
+prev = 0
+for i in range(13):
+    m = rel[:, i]
+    if (m < 0).any():
+        continue
+    print(f"{i:2d} {names[i]:34s} t = {m.mean():8.0f}  (+{m.mean() - prev:7.0f})   min {m.min():7d} max {m.max():7d}")
+    prev = m.mean()
+w = st[:, 14:16]
+t0 = w[:, 0].min()
+print("wall clock (10 ns ticks): block starts after first start: p50 %.2f us p99 %.2f us max %.2f us; block durations mean %.2f us max %.2f us; launch span %.2f us"
+      % (np.percentile(w[:, 0] - t0, 50) / 100, np.percentile(w[:, 0] - t0, 99) / 100, (w[:, 0] - t0).max() / 100,
+         (w[:, 1] - w[:, 0]).mean() / 100, (w[:, 1] - w[:, 0]).max() / 100, (w[:, 1].max() - t0) / 100))

@@ -2,6 +2,7 @@
    CMBL_LIB=cmblensing.jl_amd/_dev/lib_stx.so python tools/gpu_stamps_x.py"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("CMBL_SLICE_STREAMS", "1")
 import numpy as np, torch
 import cmblensing_jl_amd as C
 from bench import synthetic_cls
@@ -12,19 +13,21 @@ for _ in range(3):
     out = L * fm
 torch.cuda.synchronize()
 lib = C.load_library()
-nb = 1026
+nb = int(os.environ.get("NB", 2 * ((513 + 3) // 4)))            # row groups of the last launch (RPW = 4)
 buf = (ctypes.c_ulonglong * (nb * 16))()
 lib.cmbl_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.cmbl_debug_stamps(buf, nb * 16) == 0
 st = np.array(buf[:], dtype=np.uint64).reshape(nb, 16).astype(np.int64)
-d = np.diff(st[:, :5], axis=1)
-for i, n in enumerate(["load row + twiddles + sync", "forward FFT", "inverse FFT (with i*lx)", "store"]):
-    print(f"{n:30s} mean {d[:, i].mean():8.0f}  min {d[:, i].min():6d}  max {d[:, i].max():6d} cycles")
-print("total", (st[:, 4] - st[:, 0]).mean())
-# per-XCD launch span: blocks with the same (id % 8) share a clock; keep the blocks of the last launch only
-for x in range(2):
-    sel = st[x::8]
-    med = np.median(sel[:, 0])
-    sel = sel[np.abs(sel[:, 0] - med) < 200000]
-    print("XCD", x, len(sel), "blocks; first start -> last end:", sel[:, 4].max() - sel[:, 0].min(), "cycles; start spread", sel[:, 0].max() - sel[:, 0].min(),
-          "; starts sorted (first 6, last 6):", np.sort(sel[:, 0] - sel[:, 0].min())[[0, 1, 2, 3, 4, 5, -6, -5, -4, -3, -2, -1]])
+seq = [0, 6, 1, 2, 5, 3, 4]
+names = ["loads issued+committed (wave 0)", "barrier after load", "forward FFT", "inverse FFT (wave 0)", "barrier after inverse", "store"]
+for (a, b), n in zip(zip(seq[:-1], seq[1:]), names):
+    d = st[:, b] - st[:, a]
+    print(f"{n:34s} mean {d.mean():8.0f}  p10 {np.percentile(d, 10):7.0f} p50 {np.percentile(d, 50):7.0f} p90 {np.percentile(d, 90):7.0f} max {d.max():7d} cycles")
+tot = st[:, 4] - st[:, 0]
+print("total mean %.0f p50 %.0f p90 %.0f max %d" % (tot.mean(), np.percentile(tot, 50), np.percentile(tot, 90), tot.max()))
+w = st[:, 14:16]
+t0 = w[:, 0].min()
+print("wall clock: block starts after first start: p50 %.2f us p99 %.2f us max %.2f us; block durations mean %.2f us p90 %.2f max %.2f us; launch span %.2f us"
+      % (np.percentile(w[:, 0] - t0, 50) / 100, np.percentile(w[:, 0] - t0, 99) / 100, (w[:, 0] - t0).max() / 100,
+         (w[:, 1] - w[:, 0]).mean() / 100, np.percentile(w[:, 1] - w[:, 0], 90) / 100, (w[:, 1] - w[:, 0]).max() / 100, (w[:, 1].max() - t0) / 100))
+print("shader clock estimate: %.2f GHz" % (tot.mean() / ((w[:, 1] - w[:, 0]).mean() * 10)))

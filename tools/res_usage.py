@@ -7,7 +7,7 @@ import sys
 txt = open(sys.argv[1]).read()
 flt = sys.argv[2:]
 names, rows = [], []
-for b in re.split(r"remark: Function Name: ", txt)[1:]:
+for b in re.split(r"remark:[^\n]*?Function Name: ", txt)[1:]:
     name = b.split()[0]
     g = lambda k: int(m.group(1)) if (m := re.search(re.escape(k) + r": (\d+)", b)) else -1
     names.append(name)
