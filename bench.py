@@ -5,8 +5,16 @@ One "step" = one evaluation of ∇_(f°,ϕ°) logpdf(Mixed(ds)) (the reference's
 test/runbenchmarks.jl:120): precompute(ϕ) + 1 inverse flow + 1 forward flow + 2 δ-flows +
 the Fourier-diagonal / mask / reduction work, LenseFlow n = 7 RK4 steps, fp32, inputs resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nside 1024] [--pol P] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nside 1024] [--pol P] [--nbatch B] [--config {2,3,5}] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--config C` runs BASELINE.json's configuration C (2: 512² QU fp32; 3: 1024² T+QU fp32; 5: 2048² QU fp64 n=10) with the same step and
+adds that configuration's own operations (L*f, L'g, Wiener CG / one MAP_joint step / quadratic_estimate) under `extras`.
+
+roofline: `frac` divides SURVEY.md §8(d)'s ALGORITHMIC bytes of the dominant kernel (its share of the reference's pass structure) by
+the kernel's mean launch time and the 8 TB/s peak; `frac_traffic` divides the MEASURED HBM bytes of the same launch (rocprofv3 PMC
+passes, profiles/r02_traffic_*.json) instead -- the utilisation figure -- and `frac_traffic_vs_6300` uses the 6.3 TB/s a streaming copy
+achieves on this part.  `per_kernel` carries the same three numbers for every flow kernel, `whole_step` for the whole step.
 
 N > 1: one process per GPU, every rank runs its own independent posterior chain state (weak scaling, no
 data-path collective); RCCL (`nccl` backend) only gathers the per-chain scalars, as SURVEY.md §8(e) prescribes.
@@ -60,26 +68,27 @@ KERNEL_SHARE = {
 }
 
 
-def measured_traffic(kernel_class, N, P, B):
-    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-    separate runs, gfx950 correction applied: profiles/r01_traffic_*.json); None when no profile matches this workload."""
-    path = os.path.join(ROOT, "profiles", f"r01_traffic_{N}{'IQU'[3 - P:] if P > 1 else 'I'}.json")
+def measured_traffic(N, P, B, dtype):
+    """HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs, gfx950 correction
+    applied: profiles/r02_traffic_*.json, tools/make_traffic_json.py): ({kernel class: bytes per launch}, bytes per step) or
+    ({}, None) when no profile matches this workload.  It cannot be measured from inside this process."""
+    path = os.path.join(ROOT, "profiles", f"r02_traffic_{N}{'IQU'[3 - P:] if P > 1 else 'I'}_{dtype}.json")
     try:
         z = json.load(open(path))
         w = z["workload"]
-        if (w["nside"], w["npol"], w["nbatch"]) != (N, P, B):
-            return None
-        return z["by_class"][kernel_class]["traffic_bytes_per_launch"]
+        if (w["nside"], w["npol"], w["nbatch"], w["dtype"]) != (N, P, B, dtype):
+            return {}, None
+        return {k: v["traffic_bytes_per_launch"] for k, v in z["by_class"].items()}, z.get("total_bytes_per_step")
     except (OSError, KeyError, ValueError):
-        return None
+        return {}, None
 
 
-def cpu_baseline(N, pol, nsteps):
+def cpu_baseline(N, pol, nsteps, npT=np.float32):
     """The NumPy oracle (kind 'port': the Julia reference cannot run here) timed on the host cores: one ∇lnP
     evaluation of the same workload (bounded sample)."""
     import oracle as O
     t0 = time.time()
-    so = O.load_sim(2.0, N, pol, np.float32, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=nsteps)
+    so = O.load_sim(2.0, N, pol, npT, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=nsteps)
     ds = so["ds"]
     fo, po = ds.mix(so["f"], so["phi"])
     t_setup = time.time() - t0
@@ -88,23 +97,56 @@ def cpu_baseline(N, pol, nsteps):
     lp, gf, gp = ds.grad_logpdf_mixed(fo, po)
     dt = time.time() - t0
     return dict(value=1.0 / dt, unit="steps/s", cores=int(os.environ.get("CMBL_ORACLE_FFT_WORKERS", os.cpu_count() or 1)),
-                kind="port", sample=f"1 ∇logpdf(Mixed) evaluation, {N}² {pol} fp32, NumPy/SciPy-pocketfft oracle "
+                kind="port", sample=f"1 ∇logpdf(Mixed) evaluation, {N}² {pol} {np.dtype(npT).name}, n={nsteps}, NumPy/SciPy-pocketfft oracle "
                 f"({dt:.2f} s; setup {t_setup:.1f} s not counted)")
+
+
+CONFIGS = {2: dict(nside=512, pol="P", dtype="f32", nrk=7), 3: dict(nside=1024, pol="IP", dtype="f32", nrk=7),
+           5: dict(nside=2048, pol="P", dtype="f64", nrk=10)}
+
+
+def config_extras(C, torch, cfg, sim, timeit):
+    """the operations BASELINE.json names for configuration `cfg`, timed outside the headline region"""
+    ds, f, phi = sim["ds"], sim["f"], sim["phi"]
+    fm = f.to(C.MAP)
+    L = ds.L(phi)
+    gl = fm.to(C.FOURIER)
+    ex = {"L*f_ms": timeit(lambda: L * fm), "L'g_ms": timeit(lambda: L.adjoint * gl)}
+    if cfg == 2:
+        t0 = time.perf_counter(); fw, h = ds.argmaxf_logpdf(phi); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        ex.update(wiener_cg_iterations=len(h), wiener_cg_ms=dt * 1e3, wiener_cg_ms_per_iteration=dt * 1e3 / len(h))
+    if cfg == 3:
+        p0 = C.Field(sim["proj"], torch.zeros_like(phi.arr), C.FOURIER)
+        C.MAP_joint_step(ds, p0, cg_nsteps=100)
+        t0 = time.perf_counter(); st = C.MAP_joint_step(ds, p0, cg_nsteps=100); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        ex.update(map_joint_step_ms=dt * 1e3, map_joint_cg_iterations=len(st["cg_hist"]), map_joint_linesearch_evals=st["linesearch_evals"],
+                  map_joint_note="one MAP_joint step from ϕ = 0: Wiener CG capped at 100 iterations + ∇logpdf(Mixed) + Brent line search")
+    if cfg == 5:
+        C.quadratic_estimate(ds, "EB")
+        t0 = time.perf_counter(); C.quadratic_estimate(ds, "EB"); torch.cuda.synchronize()
+        ex["quadratic_estimate_EB_ms"] = (time.perf_counter() - t0) * 1e3
+    return ex
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nside", type=int, default=1024)
     ap.add_argument("--pol", default="P", choices=["I", "P", "IP"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--nrk", type=int, default=7, help="LenseFlow RK4 steps")
     ap.add_argument("--nbatch", type=int, default=1, help="chains per GPU (batch dim 4)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5], help="BASELINE.json configuration (0 = the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets the N>1 logic be exercised on a box with fewer GPUs than ranks")
     args = ap.parse_args()
+    if args.config:
+        for k, v in CONFIGS[args.config].items():
+            setattr(args, k, v)
 
     import torch
     import cmblensing_jl_amd as C
@@ -127,11 +169,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
 
-    N, pol, B, nrk = args.nside, args.pol, args.nbatch, 7
+    N, pol, B, nrk = args.nside, args.pol, args.nbatch, args.nrk
     P = {"I": 1, "P": 2, "IP": 3}[pol]
+    tT, npT, sz = (torch.float32, np.float32, 4) if args.dtype == "f32" else (torch.float64, np.float64, 8)
     # every rank = an independent chain: different simulation seeds per rank (seed = base + chain id)
     seeds = (1 + 1000 * rank, 2 + 1000 * rank, 3 + 1000 * rank)
-    sim = C.load_sim(2.0, N, pol, synthetic_cls(), T=torch.float32, device=local, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0),
+    sim = C.load_sim(2.0, N, pol, synthetic_cls(), T=tT, device=local, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0),
                      nsteps=nrk, Nbatch=B, seeds=seeds)
     ds, proj = sim["ds"], sim["proj"]
     fo, po = ds.mix(sim["f"], sim["phi"])
@@ -169,45 +212,75 @@ def main():
     value = world * B * args.steps / dt
 
     out = {
-        "metric": "LenseFlow+∇logP steps/sec (∇logpdf(Mixed) evaluations/s, LenseFlow n=7, whole job)",
+        "metric": f"LenseFlow+∇logP steps/sec (∇logpdf(Mixed) evaluations/s, LenseFlow n={nrk}, whole job)",
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{N}² flat-sky {pol} (npol={P}), θpix=2′, ∇logpdf(Mixed(ds)) step = precompute + L\\f° + L·f + 2 δ-flows "
-                               f"+ diag/mask/reductions; 1° apodised border mask, LowPass(3000), 3 μK′ noise",
+                               f"+ diag/mask/reductions; 1° apodised border mask, LowPass(3000), 3 μK′ noise"
+                               + (f" [BASELINE.json configs[{args.config - 1}]]" if args.config else ""),
                    "nside": N, "npol": P, "chains_per_gpu": B, "rk4_steps": nrk, "parallelism": f"{world} independent chains (no data-path collective)"},
         "logpdf": [float(x) for x in lps],
     }
 
     if rank == 0 and not args.no_roofline:
-        # roofline of the dominant kernel: per-launch HIP events on the library's stream over a re-run of the same K steps.
-        # The timed region above runs each pol slice as its own launch chain on its own stream (concurrent half-size launches have
-        # no individual bandwidth), so this leg switches that off: one launch over all slices, the same kernels.
+        # per-launch HIP events on the library's stream over a re-run of (at most 20 of) the same steps.  The timed region above
+        # runs each pol slice as its own launch chain on its own stream (concurrent half-size launches have no individual
+        # bandwidth), so this leg switches that off: one launch over all slices, the same kernels.
         os.environ["CMBL_SLICE_STREAMS"] = "1"
+        nprof = min(args.steps, 20)
         proj.prof_reset(); proj.prof_enable(True)
-        for _ in range(args.steps):
+        for _ in range(nprof):
             step()
         proj.prof_enable(False)
+        os.environ.pop("CMBL_SLICE_STREAMS")
         tab = proj.prof_table()
         tot = sum(v[0] for v in tab.values())
-        dom = max((k for k in tab if k in KERNEL_SHARE), key=lambda k: tab[k][0])
-        ms, nl = tab[dom]
-        ab = algorithmic_bytes(N, P, B, B, nrk, 4)
-        bytes_per_launch = KERNEL_SHARE[dom](P, B, B) * ab["map_pass"]
-        achieved = bytes_per_launch / (ms / nl * 1e-3) / 1e9
-        traffic = measured_traffic(dom, N, P, B)
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                           "traffic": traffic, "avg_launch_us": ms / nl * 1e3, "launches_per_step": nl / args.steps,
+        ab = algorithmic_bytes(N, P, B, B, nrk, sz)
+        traf, traf_step = measured_traffic(N, P, B, args.dtype)
+        per = {}
+        for k, (ms, nl) in sorted(tab.items(), key=lambda kv: -kv[1][0]):
+            t_us = ms / nl * 1e3
+            e = {"ms_per_step": ms / nprof, "avg_launch_us": t_us, "launches_per_step": nl / nprof}
+            if k in KERNEL_SHARE:
+                e["algorithmic_bytes_per_launch"] = KERNEL_SHARE[k](P, B, B) * ab["map_pass"]
+                e["frac"] = e["algorithmic_bytes_per_launch"] / (t_us * 1e-6) / 8e12
+            if k in traf:
+                e["traffic_bytes_per_launch"] = traf[k]
+                e["frac_traffic"] = traf[k] / (t_us * 1e-6) / 8e12
+                e["frac_traffic_vs_6300"] = traf[k] / (t_us * 1e-6) / 6.3e12
+            per[k] = e
+        dom = max((k for k in per if k in KERNEL_SHARE), key=lambda k: per[k]["ms_per_step"])
+        d = per[dom]
+        whole = {"survey_algorithmic_GB": ab["grad_lnP"] / 1e9,
+                 "survey_equivalent_GB_per_s": ab["grad_lnP"] / 1e9 / (ms_per_step * 1e-3),
+                 "survey_equivalent_frac": ab["grad_lnP"] / 1e9 / (ms_per_step * 1e-3) / 8000.0,
+                 "note": "survey_equivalent_* divides SURVEY §8(d)'s pass structure of the REFERENCE (31.5 GB at 1024² QU) by our step time: "
+                         "a speed-up figure, not a bandwidth; traffic_* are the measured HBM bytes of our launches"}
+        if traf_step:
+            whole.update(traffic_GB_per_step=traf_step / 1e9, traffic_GB_per_s=traf_step / 1e9 / (ms_per_step * 1e-3),
+                         frac_traffic=traf_step / (ms_per_step * 1e-3) / 8e12, frac_traffic_vs_6300=traf_step / (ms_per_step * 1e-3) / 6.3e12)
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["algorithmic_bytes_per_launch"] / (d["avg_launch_us"] * 1e-6) / 1e9,
+                           "peak": 8000.0, "unit": "GB/s", "frac": d["frac"], "traffic": d.get("traffic_bytes_per_launch"),
+                           "frac_traffic": d.get("frac_traffic"), "frac_traffic_vs_6300": d.get("frac_traffic_vs_6300"),
+                           "avg_launch_us": d["avg_launch_us"], "launches_per_step": d["launches_per_step"],
+                           "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "kernel_time_share": d["ms_per_step"] * nprof / tot,
                            "note": "per-kernel figures from a re-run with CMBL_SLICE_STREAMS=1 (one launch over all pol slices); "
-                                   "value / ms_per_step / whole_step are the timed region with one launch chain per pol slice",
-                           "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "kernel_time_share": ms / tot,
-                           "whole_step": {"algorithmic_GB": ab["grad_lnP"] / 1e9,
-                                          "achieved_GB_per_s": ab["grad_lnP"] / 1e9 / (ms_per_step * 1e-3),
-                                          "frac": ab["grad_lnP"] / 1e9 / (ms_per_step * 1e-3) / 8000.0},
-                           "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])}}
+                                   "value / ms_per_step / whole_step are the timed region with one launch chain per pol slice; "
+                                   "`frac` = SURVEY-algorithmic bytes, `frac_traffic` = measured HBM bytes (profiles/r02_traffic_*.json)",
+                           "per_kernel": per, "whole_step": whole}
+    if rank == 0 and args.config:
+        def timeit(fn, n=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        out["extras"] = config_extras(C, torch, args.config, sim, timeit)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, pol, nrk)
+        out["cpu_baseline"] = cpu_baseline(N, pol, nrk, npT)
     if rank == 0:
         print(json.dumps(out, ensure_ascii=False))
     if dist is not None:

@@ -98,6 +98,7 @@ struct CtxBase {
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
   long plane() const { return (long)Nyh * Nx; }
+  long mplane() const { return (long)((Nyh + 3) & ~3) * Nx; }   // one slice of a mixed-layout array (kernels_fft.hpp: mixed_rows)
   long npix() const { return (long)Ny * Nx; }
 };
 
@@ -268,12 +269,10 @@ struct Ctx : CtxBase {
   }
   // map -> F  (m_rfft, src/util_fft.jl:20)
   // (the x pass reads the tiled mixed layout and writes F rows, or the reverse: it cannot run in place -- `xtmp` holds the mixed side)
-  cx<T>* mixed_scratch(long slices) { xtmp.ensure(sizeof(cx<T>) * slices * plane()); return xtmp.as<cx<T>>(); }
+  cx<T>* mixed_scratch(long slices) { xtmp.ensure(sizeof(cx<T>) * slices * mplane()); return xtmp.as<cx<T>>(); }
   void rfft2_F(const T* map, cx<T>* F, long slices) { cx<T>* m = mixed_scratch(slices); y_r2c(map, m, slices); x_pass<0>(m, F, slices); }
   // F -> map without a caller-provided scratch (F is left intact)
   void F_to_map(const cx<T>* F, T* map, long slices) { cx<T>* m = mixed_scratch(slices); x_pass<1>(F, m, slices); y_c2r(m, map, slices); }
-  // F -> map  (m_irfft, src/util_fft.jl:21-25); `scratch` (slices*plane) receives the x-inverse unless F may be clobbered
-  void irfft2_F(const cx<T>* F, T* map, long slices, cx<T>* scratch) { x_pass<1>(F, scratch, slices); y_c2r(scratch, map, slices); }
 
   // harmonic-operator application (see k_harm_apply)
   void harm(const cx<T>* in, cx<T>* out, int P, int B, int kind, const T* const* d, bool transpose, bool in_qu, bool out_qu,
@@ -570,7 +569,7 @@ struct Flow {
   // L*f (inverse=false) or L\f (inverse=true) on maps; out may alias in
   void flow_map(const T* in, T* out, int P, int B, bool inverse) {
     check_ready(B);
-    const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    const long slices = (long)P * B, pl = c->mplane(), np = c->npix();          // A, Gx: mixed layout
     A.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
     acc.ensure(sizeof(T) * slices * np);
     T* y = out;
@@ -607,8 +606,8 @@ struct Flow {
   // L'*g (inverse=false, t 1->0) or L'\g (inverse=true, t 0->1); F layout, QU-Fourier basis; out may alias in
   void flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse) {
     check_ready(B);
-    const long slices = (long)P * B, pl = c->plane();
-    H.ensure(sizeof(cx<T>) * slices * pl); Wx.ensure(sizeof(cx<T>) * slices * pl); Wy.ensure(sizeof(cx<T>) * slices * pl);
+    const long slices = (long)P * B, pl = c->plane(), mpl = c->mplane();
+    H.ensure(sizeof(cx<T>) * slices * mpl); Wx.ensure(sizeof(cx<T>) * slices * mpl); Wy.ensure(sizeof(cx<T>) * slices * mpl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     c->template x_pass<1>(out, H.as<cx<T>>(), slices);
@@ -622,9 +621,9 @@ struct Flow {
         const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
         for (int g = 0; g < K; ++g) {
           hipStream_t st = gstream(g);
-          const long so = g * gs * pl;
+          const long so = g * gs * pl, som = g * gs * mpl;
           AdjYArgs<T> a{};
-          a.H = H.as<cx<T>>() + so; a.Wx = Wx.as<cx<T>>() + so; a.Wy = Wy.as<cx<T>>() + so; a.ph = ph(rk.t, phi_off(g, K, B));
+          a.H = H.as<cx<T>>() + som; a.Wx = Wx.as<cx<T>>() + som; a.Wy = Wy.as<cx<T>>() + som; a.ph = ph(rk.t, phi_off(g, K, B));
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
           a.Nx = c->Nx; a.P = P; a.t = rk.t;
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
@@ -632,7 +631,7 @@ struct Flow {
             CMBL_LAUNCH_NT(c, K_ADJ_Y, NT, (k_adj_y<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)gs), c->ldsY(tile.C), st, a);
           });
           AdjXArgs<T> x{};
-          x.Wx = a.Wx; x.Wy = a.Wy; x.Y0 = out + so; x.acc = Yacc.as<cx<T>>() + so; x.Hnext = H.as<cx<T>>() + so;
+          x.Wx = a.Wx; x.Wy = a.Wy; x.Y0 = out + so; x.acc = Yacc.as<cx<T>>() + so; x.Hnext = H.as<cx<T>>() + som;
           x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.Nyh = c->Nyh; x.rk = rk;
           c->dispatch_row([&](auto lgnx) {
             constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
@@ -651,11 +650,11 @@ struct Flow {
   // per-stage buffer and delta-phi -- a pure quadrature over the stages -- is formed once at the end (k_dphi_reduce, 5 rffts, combine).
   void flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
     check_ready(B);
-    const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    const long slices = (long)P * B, pl = c->plane(), mpl = c->mplane(), np = c->npix();
     const int nst = 4 * n;
-    A.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
+    A.ensure(sizeof(cx<T>) * slices * mpl); A2.ensure(sizeof(cx<T>) * slices * mpl); Gx.ensure(sizeof(cx<T>) * slices * mpl);
     acc.ensure(sizeof(T) * slices * np);
-    H.ensure(sizeof(cx<T>) * slices * pl); Wx.ensure(sizeof(cx<T>) * slices * pl); Wy.ensure(sizeof(cx<T>) * slices * pl);
+    H.ensure(sizeof(cx<T>) * slices * mpl); Wx.ensure(sizeof(cx<T>) * slices * mpl); Wy.ensure(sizeof(cx<T>) * slices * mpl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
     Wst.ensure(sizeof(T) * (size_t)nst * 2 * slices * np);              // 4n x 2 maps per slice: 448 MB at 1024^2 QU fp32, n = 7
     U5.ensure(sizeof(T) * 5 * B * np); F5.ensure(sizeof(cx<T>) * 5 * B * pl); tcbuf.ensure(sizeof(T) * 2 * nst);
@@ -678,13 +677,13 @@ struct Flow {
         tc_host[2 * it + 1] = (T)((stage == 1 || stage == 4 ? 1.0 : 2.0) * h / 6);   // RK4 weights (src/numerical_algorithms.jl:20)
         for (int g = 0; g < K; ++g) {
           hipStream_t st = gstream(g);
-          const long so = g * gs, sp = so * pl, sm = so * np;
+          const long so = g * gs, sp = so * pl, spm = so * mpl, sm = so * np;
           DeltaYArgs<T> d{};
           FlowYArgs<T>& a = d.f;
-          a.A = a_cur + sp; a.Gx = Gx.as<cx<T>>() + sp; a.Anext = a_nxt + sp; a.y0 = f + sm; a.acc = acc.as<T>() + sm; a.ph = ph(rk.t, phi_off(g, K, B));
+          a.A = a_cur + spm; a.Gx = Gx.as<cx<T>>() + spm; a.Anext = a_nxt + spm; a.y0 = f + sm; a.acc = acc.as<T>() + sm; a.ph = ph(rk.t, phi_off(g, K, B));
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
           a.Nx = c->Nx; a.P = P; a.rk = rk;
-          d.H = H.as<cx<T>>() + sp; d.Wx = Wx.as<cx<T>>() + sp; d.Wy = Wy.as<cx<T>>() + sp;
+          d.H = H.as<cx<T>>() + spm; d.Wx = Wx.as<cx<T>>() + spm; d.Wy = Wy.as<cx<T>>() + spm;
           d.w1p = Wst.as<T>() + ((size_t)(2 * it) * slices + so) * np; d.w2p = d.w1p + (size_t)slices * np;
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
             constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
@@ -692,9 +691,9 @@ struct Flow {
           });
           // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_nxt holds A_{s+1} after this column launch)
           AdjXArgs<T> x{};
-          x.Wx = d.Wx; x.Wy = d.Wy; x.Y0 = df + sp; x.acc = Yacc.as<cx<T>>() + sp; x.Hnext = H.as<cx<T>>() + sp;
+          x.Wx = d.Wx; x.Wy = d.Wy; x.Y0 = df + sp; x.acc = Yacc.as<cx<T>>() + sp; x.Hnext = H.as<cx<T>>() + spm;
           x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.Nyh = c->Nyh; x.rk = rk;
-          GradXArgs<T> gx{a_nxt + sp, Gx.as<cx<T>>() + sp, x.twX, c->dlx_over_Nx, c->Nyh};
+          GradXArgs<T> gx{a_nxt + spm, Gx.as<cx<T>>() + spm, x.twX, c->dlx_over_Nx, c->Nyh};
           c->dispatch_row([&](auto lgnx) {
             constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
             if constexpr (RPW > 0) {

@@ -59,8 +59,11 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) { return (nb & 7) ? b : (
 // blocks -- the largest single cost in the round-1 column kernels (first LDS commit at 14k of a 39k-cycle workgroup).  Hence the
 // tiled layout  [x/4][ky][x%4]: a column tile of 4 columns is ONE contiguous block of (Ny/2+1)*4 values, and a row workgroup that
 // takes 4 adjacent ky rows gathers whole 128-byte lines (4 rows x 4 values), which is as fast as contiguous rows (2.9 us / 2.9 us).
+// The row count of a block is padded to a multiple of 4 (Ny/2+1 is odd): blocks and the gathered 4 x 4 lines then start on 128-byte
+// boundaries (unpadded, every line of a row workgroup straddled two: +35 % measured traffic in the row kernels).
 constexpr int MIXW = 4, LGMIXW = 2;
-__device__ __forceinline__ size_t mix_idx(int ky, int x, int Nyh) { return ((size_t)(x >> LGMIXW) * Nyh + ky) * MIXW + (x & (MIXW - 1)); }
+__host__ __device__ constexpr int mixed_rows(int Nyh) { return (Nyh + 3) & ~3; }
+__device__ __forceinline__ size_t mix_idx(int ky, int x, int NyhP) { return ((size_t)(x >> LGMIXW) * NyhP + ky) * MIXW + (x & (MIXW - 1)); }
 
 // ---------------------------------------------------------------------------------------------
 // ref <-> F  (transpose + bit reversal of x), V = cx<T> or T.   grid (Nx/32, ceil(Nyh/32), slices), block 256
@@ -142,7 +145,7 @@ template <typename T, int NT, int LGM, int LGC> struct TileStage {           // 
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int e = threadIdx.x + i * NT;
-      if (e < TOT) v[i] = g[mix_idx(e >> LGC, x0 + (e & (C - 1)), M + 1)];
+      if (e < TOT) v[i] = g[mix_idx(e >> LGC, x0 + (e & (C - 1)), mixed_rows(M + 1))];
     }
   }
   template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
@@ -158,7 +161,7 @@ __device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx
   constexpr int M = 1 << LGM, C = 1 << LGC;
   for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
     const int c = e & (C - 1), k = e >> LGC;
-    g[mix_idx(k, x0 + c, M + 1)] = s[c * LD + hslot<LGM>(k)];
+    g[mix_idx(k, x0 + c, mixed_rows(M + 1))] = s[c * LD + hslot<LGM>(k)];
   }
 }
 
@@ -176,7 +179,7 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
       const int e = threadIdx.x + i * NT;
       if (e < TOT) {
         const int k = e >> LGC;
-        const size_t gi = mix_idx(k, x0 + (e & (C - 1)), M + 1);
+        const size_t gi = mix_idx(k, x0 + (e & (C - 1)), mixed_rows(M + 1));
         X[i] = gX[gi]; Y[i] = gY[gi]; l[i] = ly[k];
       }
     }
@@ -233,7 +236,7 @@ template <typename T> struct alignas(16) CxVec { cx<T> v[16 / sizeof(cx<T>)]; };
 // (CMBL_ROW_ROT lets every workgroup walk x/4 from its own starting point, so that the workgroups of a launch do not touch the same
 // 16 KB window at the same moment; measured on MI355X: no difference, the default is no rotation)
 template <typename T, int LGNX, int RPW, int NA>
-__device__ __forceinline__ void rows_load_mixed(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], int Nyh, int ky0, int nr) {
+__device__ __forceinline__ void rows_load_mixed(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], int NyhP, int ky0, int nr) {
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE;       // 16-byte units per row of a gathered line
   constexpr int TOT = RPW * Nx / VE, K = (TOT + XNT - 1) / XNT;
   const int rot = CMBL_ROW_ROT(ky0);
@@ -243,7 +246,7 @@ __device__ __forceinline__ void rows_load_mixed(cx<T>* const (&s)[NA], const cx<
     const int u = threadIdx.x + i * XNT, xt = (u / (UPG * RPW) + rot) & (Nx / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
     if ((TOT % XNT == 0 || u < TOT) && r < nr) {
 #pragma unroll
-      for (int a = 0; a < NA; ++a) v[a][i] = *reinterpret_cast<const CxVec<T>*>(g[a] + ((size_t)xt * Nyh + ky0 + r) * MIXW + c);
+      for (int a = 0; a < NA; ++a) v[a][i] = *reinterpret_cast<const CxVec<T>*>(g[a] + ((size_t)xt * NyhP + ky0 + r) * MIXW + c);
     }
   }
 #pragma unroll
@@ -259,7 +262,7 @@ __device__ __forceinline__ void rows_load_mixed(cx<T>* const (&s)[NA], const cx<
 }
 // LDS rows -> mixed layout, values scaled by `scale`
 template <typename T, int LGNX, int RPW>
-__device__ __forceinline__ void rows_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int Nyh, int ky0, int nr, T scale) {
+__device__ __forceinline__ void rows_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int NyhP, int ky0, int nr, T scale) {
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, TOT = RPW * Nx / VE;
   const int rot = CMBL_ROW_ROT(ky0);
   for (int u = threadIdx.x; u < TOT; u += XNT) {
@@ -268,7 +271,7 @@ __device__ __forceinline__ void rows_store_mixed(const cx<T>* __restrict__ s, cx
       CxVec<T> v;
 #pragma unroll
       for (int e = 0; e < VE; ++e) v.v[e] = scale * s[r * LD + pad(xt * MIXW + c) + e];
-      *reinterpret_cast<CxVec<T>*>(g + ((size_t)xt * Nyh + ky0 + r) * MIXW + c) = v;
+      *reinterpret_cast<CxVec<T>*>(g + ((size_t)xt * NyhP + ky0 + r) * MIXW + c) = v;
     }
   }
 }
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(NT) void k_y_r2c(const T* __restrict__ in, cx<T>* _
   __syncthreads();
   fft_dif<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
   r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)G::Nyh * Nx, Nx, x0);
+  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)mixed_rows(G::Nyh) * Nx, Nx, x0);
 }
 
 // y pass, inverse: mixed -> map, scaled by `scale` (1/Ny; the x pass already carries 1/Nx)
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
   TwStage<T, NT, 2 * M> twr;
   TileStage<T, NT, LGM, G::LGC> tl;
   twr.issue(twY);
-  tl.issue(in + sl * (size_t)G::Nyh * Nx, Nx, x0);
+  tl.issue(in + sl * (size_t)mixed_rows(G::Nyh) * Nx, Nx, x0);
   twr.commit(tw);
   tl.template commit<LD>(s);
   __syncthreads();
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<
   TwStage<T, NT, 2 * M> twr;
   TileStage<T, NT, LGM, G::LGC> tl;
   twr.issue(twY);
-  tl.issue(in + sl * (size_t)G::Nyh * Nx, Nx, x0);
+  tl.issue(in + sl * (size_t)mixed_rows(G::Nyh) * Nx, Nx, x0);
   const cx<T>* mk2 = reinterpret_cast<const cx<T>*>(mask) + (size_t)x0 * M;       // the mask is one (Nx, Ny) map for all slices
   cx<T> mv[R];
 #pragma unroll
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<
   __syncthreads();
   fft_dif<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
   r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)G::Nyh * Nx, Nx, x0);
+  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)mixed_rows(G::Nyh) * Nx, Nx, x0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,7 +430,8 @@ __global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_x_fft(const cx<T>* 
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + Nx;
   const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh);
-  const size_t mo = (size_t)rg.sl * Nyh * Nx, fo = mo + (size_t)rg.ky0 * Nx;
+  const int NyhP = mixed_rows(Nyh);
+  const size_t mo = (size_t)rg.sl * NyhP * Nx, fo = ((size_t)rg.sl * Nyh + rg.ky0) * Nx;
   CMBL_XWSTAMP(14);
   CMBL_XSTAMP(0);
   TwStage<T, XNT, Nx> twr;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_x_fft(const cx<T>* 
   else {
     cx<T>* const sa[1] = {s};
     const cx<T>* const ga[1] = {in + mo};
-    rows_load_mixed<T, LGNX, RPW, 1>(sa, ga, Nyh, rg.ky0, rg.nr);
+    rows_load_mixed<T, LGNX, RPW, 1>(sa, ga, NyhP, rg.ky0, rg.nr);
   }
   twr.commit(tw);
   CMBL_XSTAMP(6);
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_x_fft(const cx<T>* 
   __syncthreads();
   CMBL_XSTAMP(3);
   if (MODE == 0) rows_store_F<T, LGNX, RPW>(s, out + fo, rg.nr, T(1));
-  else rows_store_mixed<T, LGNX, RPW>(s, out + mo, Nyh, rg.ky0, rg.nr, MODE == 1 ? T(1) / T(Nx) : T(1));
+  else rows_store_mixed<T, LGNX, RPW>(s, out + mo, NyhP, rg.ky0, rg.nr, MODE == 1 ? T(1) / T(Nx) : T(1));
   CMBL_XSTAMP(4);
   CMBL_XWSTAMP(15);
 }

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
-  const size_t moff = sl * (size_t)Nyh * Nx;
+  constexpr int NyhP = mixed_rows(Nyh);
+  const size_t moff = sl * (size_t)NyhP * Nx;
   // everything this workgroup needs from HBM is requested before anything is waited for
   TwStage<T, NT, 2 * M> twr;
   PairStage<T, NT, LGN, LGC> ps;
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
-  const size_t moff = sl * (size_t)Nyh * Nx;
+  constexpr int NyhP = mixed_rows(Nyh);
+  const size_t moff = sl * (size_t)NyhP * Nx;
   TwStage<T, NT, 2 * M> twr;
   TileStage<T, NT, LGM, LGC> tl;
   twr.issue(a.twY);
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
   cx<T>* Wx = a.Wx + moff; cx<T>* Wy = a.Wy + moff;
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
-    const size_t gi = mix_idx(k, x0 + c, Nyh);
+    const size_t gi = mix_idx(k, x0 + c, NyhP);
     Wx[gi] = A; Wy[gi] = mul_il(B, lyr[i]);
   });
 }
@@ -241,13 +243,14 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   cx<T>* s = tw + Nx;
   cx<T>* s2 = s + RPW * LD;                                   // second row set: sequence RPW + row, owned by the same threads
   const RowGroup rg = row_group<RPW>(blk, a.Nyh);
-  const size_t mo = (size_t)rg.sl * a.Nyh * Nx;
+  const int NyhP = mixed_rows(a.Nyh);
+  const size_t mo = (size_t)rg.sl * NyhP * Nx;
   TwStage<T, XNT, Nx> twr;
   twr.issue(a.twX);
   {
     cx<T>* const sa[2] = {s, s2};
     const cx<T>* const ga[2] = {a.Wx + mo, a.Wy + mo};
-    rows_load_mixed<T, LGNX, RPW, 2>(sa, ga, a.Nyh, rg.ky0, rg.nr);
+    rows_load_mixed<T, LGNX, RPW, 2>(sa, ga, NyhP, rg.ky0, rg.nr);
   }
   twr.commit(tw);
   __syncthreads();
@@ -256,7 +259,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   const int row = threadIdx.x / RT, lane = threadIdx.x % RT;
   const T inv = T(1) / T(Nx);
   if (row < rg.nr) {
-    const size_t g0 = mo + (size_t)(rg.ky0 + row) * Nx;
+    const size_t g0 = ((size_t)rg.sl * a.Nyh + rg.ky0 + row) * Nx;
     cx<T>* sr = s + row * LD; const cx<T>* sr2 = s2 + row * LD;
     if constexpr (Nx >= RT) {
       constexpr int CH = PF > 8 ? 8 : PF;                     // state loads in flight per thread: CH values of Y0 and of acc
@@ -295,7 +298,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   wk.sync();
   fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
   __syncthreads();
-  rows_store_mixed<T, LGNX, RPW>(s, a.Hnext + mo, a.Nyh, rg.ky0, rg.nr, T(1));
+  rows_store_mixed<T, LGNX, RPW>(s, a.Hnext + mo, NyhP, rg.ky0, rg.nr, T(1));
 }
 
 template <typename T, int LGNX, int RPW>
@@ -312,13 +315,14 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + Nx;
   const RowGroup rg = row_group<RPW>(blk, g.Nyh);
-  const size_t mo = (size_t)rg.sl * g.Nyh * Nx;
+  const int NyhP = mixed_rows(g.Nyh);
+  const size_t mo = (size_t)rg.sl * NyhP * Nx;
   TwStage<T, XNT, Nx> twr;
   twr.issue(g.twX);
   {
     cx<T>* const sa[1] = {s};
     const cx<T>* const ga[1] = {g.in + mo};
-    rows_load_mixed<T, LGNX, RPW, 1>(sa, ga, g.Nyh, rg.ky0, rg.nr);
+    rows_load_mixed<T, LGNX, RPW, 1>(sa, ga, NyhP, rg.ky0, rg.nr);
   }
   twr.commit(tw);
   __syncthreads();
@@ -331,7 +335,7 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
     return mul_il(v, dl * T(kx < (Nx >> 1) ? kx : kx - Nx));
   });
   __syncthreads();
-  rows_store_mixed<T, LGNX, RPW>(s, g.out + mo, g.Nyh, rg.ky0, rg.nr, T(1));
+  rows_store_mixed<T, LGNX, RPW>(s, g.out + mo, NyhP, rg.ky0, rg.nr, T(1));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -354,7 +358,8 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
-  const size_t moff = sl * (size_t)Nyh * Nx;
+  constexpr int NyhP = mixed_rows(Nyh);
+  const size_t moff = sl * (size_t)NyhP * Nx;
   const size_t pbase = ((size_t)bphi * Nx + x0) * M, mbase = (sl * Nx + x0) * (size_t)M;
   CMBL_WSTAMP(14);
   CMBL_STAMP(0);
@@ -429,7 +434,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   {
     cx<T>* Wx = d.Wx + moff; cx<T>* Wy = d.Wy + moff;
     pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
-      const size_t gi = mix_idx(k, x0 + c, Nyh);
+      const size_t gi = mix_idx(k, x0 + c, NyhP);
       Wx[gi] = A; Wy[gi] = mul_il(B, ps.l[i]);                // ly[k] is still in registers from the pair load (same entry mapping)
     });
   }
