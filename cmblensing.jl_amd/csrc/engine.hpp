@@ -262,7 +262,7 @@ struct Ctx : CtxBase {
     dispatch_row([&](auto lgnx) {
       constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 1);
       if constexpr (RPW > 0) {
-        CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), XNT, (k_x_fft<T, MODE, LGNX, RPW>), dim3((unsigned)row_groups(slices, RPW)), ldsX(RPW, 1), st,
+        CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), row_nt(RPW), (k_x_fft<T, MODE, LGNX, RPW>), dim3((unsigned)row_groups(slices, RPW)), ldsX(RPW, 1), st,
                        in, out, twX.as<cx<T>>(), dlx_over_Nx, Nyh);
       } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
     });
@@ -636,7 +636,7 @@ struct Flow {
           c->dispatch_row([&](auto lgnx) {
             constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
             if constexpr (RPW > 0) {
-              CMBL_LAUNCH_NT(c, K_ADJ_X, XNT, (k_adj_x<T, LGNX, RPW>), dim3((unsigned)c->row_groups(gs, RPW)), c->ldsX(RPW, 2), st, x);
+              CMBL_LAUNCH_NT(c, K_ADJ_X, row_nt(RPW), (k_adj_x<T, LGNX, RPW>), dim3((unsigned)c->row_groups(gs, RPW)), c->ldsX(RPW, 2), st, x);
             } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
           });
         }
@@ -698,7 +698,7 @@ struct Flow {
             constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
             if constexpr (RPW > 0) {
               const int nb_adj = (int)c->row_groups(gs, RPW);
-              CMBL_LAUNCH_NT(c, K_DELTA_ROWS, XNT, (k_delta_rows<T, LGNX, RPW>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))), c->ldsX(RPW, 2), st, x, gx, nb_adj);
+              CMBL_LAUNCH_NT(c, K_DELTA_ROWS, row_nt(RPW), (k_delta_rows<T, LGNX, RPW>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))), c->ldsX(RPW, 2), st, x, gx, nb_adj);
             } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
           });
         }

@@ -59,17 +59,37 @@ template <int NT> struct WorkCoop {
   __device__ __forceinline__ void sync() const { CMBL_STAGE_SYNC(); }
 };
 // WorkRows: RT consecutive threads own row `threadIdx.x / RT` of each of NA arrays (sequence a*RPW + row); rows >= nr are absent.
-// With RT = 64 a row belongs to ONE wavefront: LDS operations of a wave execute in order, so the stages of a row need no barrier.
+// The row kernels run the TOP radix-2 level of a row transform while loading / storing (kernels_fft.hpp), so the stages here act on
+// the two halves of a row independently.  With RT = 128 wave w of a row takes the items of half w in every stage (items
+// [w*I/2, (w+1)*I/2) of the I items of a stage are exactly those that touch half w), with RT = 64 one wave has the whole row: either
+// way a wave only ever reads LDS slots it wrote itself, LDS operations of a wave execute in order, and no barrier is needed
+// between stages.  Other RT fall back to workgroup barriers.
 template <int RT, int RPW> struct WorkRows {
   int NA, nr;
+  static constexpr bool wave_private = RT <= 128;
   template <int LGNB, typename F> __device__ __forceinline__ void each(F&& f) const {
-    const int row = threadIdx.x / RT, lane = threadIdx.x % RT;
-    if (row < nr)
+    const int row = threadIdx.x / RT, t = threadIdx.x % RT;
+    if (row >= nr) return;
+    if constexpr (RT == 128) {
+      constexpr int I = 1 << LGNB, HI = I >> 1;                       // items of the stage, items per half
+      const int w = t >> 6, lane = t & 63;
+      for (int a = 0; a < NA; ++a) {
+        if constexpr (HI >= 64) {
+#pragma unroll
+          for (int i = 0; i < HI / 64; ++i) f(a * RPW + row, w * HI + lane + 64 * i);
+        } else if constexpr (HI >= 1) {
+          if (lane < HI) f(a * RPW + row, w * HI + lane);
+        } else {
+          if (t == 0) f(a * RPW + row, 0);
+        }
+      }
+    } else {
       for (int a = 0; a < NA; ++a)
-        for (int rr = lane; rr < (1 << LGNB); rr += RT) f(a * RPW + row, rr);
+        for (int rr = t; rr < (1 << LGNB); rr += RT) f(a * RPW + row, rr);
+    }
   }
   __device__ __forceinline__ void sync() const {
-    if constexpr (RT <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    if constexpr (wave_private) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     else __syncthreads();
   }
 };
@@ -127,34 +147,35 @@ __device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, const W& wk, co
 }
 
 // ---- forward, DIF: natural -> bit-reversed -------------------------------------------------------
-template <typename T, int LD, int LGN, int LGNTW, int MAXLG, typename W, int I = 0>
+// SKIP = 1: the top level (span N/2) is done by the caller; the stages cover the remaining LGN - 1 levels, i.e. both halves
+template <typename T, int LD, int LGN, int LGNTW, int MAXLG, int SKIP, typename W, int I = 0>
 __device__ __forceinline__ void fft_dif_w(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw) {
-  if constexpr (I < num_stages(LGN, MAXLG)) {
-    constexpr int LG = stage_lg(LGN, I, MAXLG);
-    constexpr int LGH = levels_after(LGN, I, MAXLG) + LG - 1;      // top span index of this stage
+  if constexpr (I < num_stages(LGN - SKIP, MAXLG)) {
+    constexpr int LG = stage_lg(LGN - SKIP, I, MAXLG);
+    constexpr int LGH = levels_after(LGN - SKIP, I, MAXLG) + LG - 1;      // top span index of this stage
     dif_stage<T, LD, LGN, LGNTW, LGH, LG>(s, wk, tw);
-    fft_dif_w<T, LD, LGN, LGNTW, MAXLG, W, I + 1>(s, wk, tw);
+    fft_dif_w<T, LD, LGN, LGNTW, MAXLG, SKIP, W, I + 1>(s, wk, tw);
   }
 }
 template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4>
 __device__ __forceinline__ void fft_dif(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw) {
-  fft_dif_w<T, LD, LGN, LGNTW, MAXLG>(s, WorkCoop<NT>{S}, tw);
+  fft_dif_w<T, LD, LGN, LGNTW, MAXLG, 0>(s, WorkCoop<NT>{S}, tw);
 }
 
 // ---- inverse, DIT: bit-reversed -> natural (unnormalised); the forward schedule replayed backwards ----
-template <typename T, int LD, int LGN, int LGNTW, int MAXLG, typename W, typename PRE = NoPre, int I = num_stages(LGN, MAXLG) - 1>
+template <typename T, int LD, int LGN, int LGNTW, int MAXLG, int SKIP, typename W, typename PRE = NoPre, int I = num_stages(LGN - SKIP, MAXLG) - 1>
 __device__ __forceinline__ void fft_dit_w(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
   if constexpr (I >= 0) {
-    constexpr int LG = stage_lg(LGN, I, MAXLG);
-    constexpr int LGH = levels_after(LGN, I, MAXLG);               // bottom span index of this stage
-    if constexpr (I == num_stages(LGN, MAXLG) - 1) dit_stage<T, LD, LGN, LGNTW, LGH, LG, W, PRE>(s, wk, tw, pre);   // pre applies to the bit-reversed input
+    constexpr int LG = stage_lg(LGN - SKIP, I, MAXLG);
+    constexpr int LGH = levels_after(LGN - SKIP, I, MAXLG);        // bottom span index of this stage
+    if constexpr (I == num_stages(LGN - SKIP, MAXLG) - 1) dit_stage<T, LD, LGN, LGNTW, LGH, LG, W, PRE>(s, wk, tw, pre);   // pre applies to the bit-reversed input
     else dit_stage<T, LD, LGN, LGNTW, LGH, LG>(s, wk, tw);
-    fft_dit_w<T, LD, LGN, LGNTW, MAXLG, W, NoPre, I - 1>(s, wk, tw);
+    fft_dit_w<T, LD, LGN, LGNTW, MAXLG, SKIP, W, NoPre, I - 1>(s, wk, tw);
   }
 }
 template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, typename PRE = NoPre>
 __device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
-  fft_dit_w<T, LD, LGN, LGNTW, MAXLG, WorkCoop<NT>, PRE>(s, WorkCoop<NT>{S}, tw, pre);
+  fft_dit_w<T, LD, LGN, LGNTW, MAXLG, 0, WorkCoop<NT>, PRE>(s, WorkCoop<NT>{S}, tw, pre);
 }
 
 // ---- packed real <-> half spectrum, in place on the tile ------------------------------------------

@@ -203,18 +203,21 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
   }
 };
 // ---- row workgroups --------------------------------------------------------------------------------------------------------------
-// A row workgroup (XNT = 256 threads) takes RPW adjacent ky rows of one slice, all x: RT = XNT / RPW consecutive threads own a row
-// through every transform stage (WorkRows in fft_lds.hpp; RPW = 4: one wavefront per row, no barriers between stages).  Its
-// mixed-layout side is a gather / scatter of RPW x 4 values per x/4 (one 128-byte line for RPW = 4, fp32), its F-layout side
-// contiguous rows.  Row r of the group sits at LDS offset r * row_ld(Nx); row_ld = 4 (mod 16) slots, so that the 16 lanes
-// that write one gathered line (4 rows x 4 values) hit 16 different bank pairs.
+// A row workgroup takes RPW adjacent ky rows of one slice, all x; RT = 128 consecutive threads (two wavefronts) own a row.  The
+// TOP radix-2 level of a row transform (span Nx/2) is done while the row moves between memory and LDS -- the thread that loads
+// x[a] also loads x[a + Nx/2] and stores their sum and twiddled difference (forward), or combines the two halves on the way out
+// (inverse) -- and each wavefront then runs the remaining levels on ITS half of the row without any barrier (WorkRows in
+// fft_lds.hpp): 1024 points = 2 x 512 = 2 waves x 3 radix-8 stages of exactly one butterfly per lane.  (One wave per row with
+// radix-16 stages measured 5.0k cycles per 1024-point transform -- a single wave's sequential instruction stream; lower radices
+// with workgroup barriers were no faster.)
+// The mixed-layout side is a gather / scatter of RPW x 4 values per x/4 (one 128-byte line for RPW = 4, fp32), the F-layout side
+// contiguous rows.  Row r of the group sits at LDS offset r * row_ld(Nx); row_ld = 4 (mod 16) slots, so that the 16 lanes that
+// write one gathered line (4 rows x 4 values) hit 16 different bank pairs.
 #ifndef CMBL_ROW_ROT
 #define CMBL_ROW_ROT(ky0) 0        // per-workgroup starting point of the x/4 walk, e.g. (((ky0) * 29) >> 2): measured, no effect
 #endif
-#ifndef CMBL_XNT
-#define CMBL_XNT 256
-#endif
-constexpr int XNT = CMBL_XNT;
+constexpr int ROW_RT = 128;                                              // threads per row
+__host__ __device__ constexpr int row_nt(int rpw) { return ROW_RT * rpw; }   // workgroup size
 __host__ __device__ constexpr int row_ld(int n) { return pad(n) + ((4 - pad(n) % 16) + 16) % 16; }
 // rows per workgroup: as many of 4, 2, 1 as fit the 160 KB of LDS next to the twiddle table (NA row sets: 1, or 2 for the adjoint pass)
 template <typename T> __host__ __device__ constexpr int row_rpw(int lgnx, int na) {
@@ -232,63 +235,82 @@ template <int RPW> __device__ __forceinline__ RowGroup row_group(long blk, int N
 // 16-byte global accesses: 2 single-precision or 1 double-precision complex values
 template <typename T> struct alignas(16) CxVec { cx<T> v[16 / sizeof(cx<T>)]; };
 
-// mixed layout (slice bases g[a]) -> the NA row sets in LDS; all loads of the thread are issued before the first LDS store
+// mixed layout (slice bases g[a]) -> the NA row sets in LDS, through the top DIF level:
+//   s[a] <- x[a] + x[a + N/2],   s[a + N/2] <- (x[a] - x[a + N/2]) * W_N^a        (twg: the global twiddle table exp(-2 pi i k / N))
+// All loads of the thread are issued before the first LDS store.
 // (CMBL_ROW_ROT lets every workgroup walk x/4 from its own starting point, so that the workgroups of a launch do not touch the same
 // 16 KB window at the same moment; measured on MI355X: no difference, the default is no rotation)
 template <typename T, int LGNX, int RPW, int NA>
-__device__ __forceinline__ void rows_load_mixed(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], int NyhP, int ky0, int nr) {
-  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE;       // 16-byte units per row of a gathered line
-  constexpr int TOT = RPW * Nx / VE, K = (TOT + XNT - 1) / XNT;
+__device__ __forceinline__ void rows_load_mixed_dif(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr) {
+  using V = typename vreg<T>::type;
+  constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW);
+  constexpr int TOT = RPW * NH / VE, K = (TOT + NT - 1) / NT;
   const int rot = CMBL_ROW_ROT(ky0);
-  CxVec<T> v[NA][K];
+  CxVec<T> va[NA][K], vb[NA][K], w[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int u = threadIdx.x + i * XNT, xt = (u / (UPG * RPW) + rot) & (Nx / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
-    if ((TOT % XNT == 0 || u < TOT) && r < nr) {
+    const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+    if ((TOT % NT == 0 || u < TOT) && r < nr) {
+      w[i] = *reinterpret_cast<const CxVec<T>*>(twg + xt * MIXW + c);
 #pragma unroll
-      for (int a = 0; a < NA; ++a) v[a][i] = *reinterpret_cast<const CxVec<T>*>(g[a] + ((size_t)xt * NyhP + ky0 + r) * MIXW + c);
+      for (int a = 0; a < NA; ++a) {
+        va[a][i] = *reinterpret_cast<const CxVec<T>*>(g[a] + ((size_t)xt * NyhP + ky0 + r) * MIXW + c);
+        vb[a][i] = *reinterpret_cast<const CxVec<T>*>(g[a] + ((size_t)(xt + NH / MIXW) * NyhP + ky0 + r) * MIXW + c);
+      }
     }
   }
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int u = threadIdx.x + i * XNT, xt = (u / (UPG * RPW) + rot) & (Nx / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
-    if ((TOT % XNT == 0 || u < TOT) && r < nr) {
+    const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+    if ((TOT % NT == 0 || u < TOT) && r < nr) {
 #pragma unroll
       for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int e = 0; e < VE; ++e) s[a][r * LD + pad(xt * MIXW + c) + e] = v[a][i].v[e];        // c even: pad(x + 1) == pad(x) + 1
+        for (int e = 0; e < VE; ++e) {
+          const V xa = vfrom(va[a][i].v[e]), xb = vfrom(vb[a][i].v[e]);
+          cx<T>* p = s[a] + r * LD + pad(xt * MIXW + c) + e;              // c even: pad(x + 1) == pad(x) + 1; pad(x + N/2) == pad(x) + pad(N/2)
+          vstore(p, vadd(xa, xb));
+          vstore(p + pad(NH), vmul(vsub(xa, xb), vfrom(w[i].v[e])));
+        }
     }
   }
 }
-// LDS rows -> mixed layout, values scaled by `scale`
+// LDS rows -> mixed layout through the last DIT level:  x[a] = u[a] + conj(W_N^a) v[a],  x[a + N/2] = u[a] - conj(W_N^a) v[a]  with
+// u, v the two halves of the row in LDS; values scaled by `scale`.  tw: the LDS twiddle table.
 template <typename T, int LGNX, int RPW>
-__device__ __forceinline__ void rows_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int NyhP, int ky0, int nr, T scale) {
-  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, TOT = RPW * Nx / VE;
+__device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, const cx<T>* __restrict__ tw, int NyhP, int ky0, int nr, T scale) {
+  using V = typename vreg<T>::type;
+  constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW), TOT = RPW * NH / VE;
   const int rot = CMBL_ROW_ROT(ky0);
-  for (int u = threadIdx.x; u < TOT; u += XNT) {
-    const int xt = (u / (UPG * RPW) + rot) & (Nx / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+  for (int u = threadIdx.x; u < TOT; u += NT) {
+    const int xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
     if (r < nr) {
-      CxVec<T> v;
+      CxVec<T> oa, ob;
 #pragma unroll
-      for (int e = 0; e < VE; ++e) v.v[e] = scale * s[r * LD + pad(xt * MIXW + c) + e];
-      *reinterpret_cast<CxVec<T>*>(g + ((size_t)xt * NyhP + ky0 + r) * MIXW + c) = v;
+      for (int e = 0; e < VE; ++e) {
+        const cx<T>* p = s + r * LD + pad(xt * MIXW + c) + e;
+        const V uu = vload(p), t = vmulc(vload(p + pad(NH)), vload(tw + xt * MIXW + c + e));
+        oa.v[e] = vcx(vscale(vadd(uu, t), scale)); ob.v[e] = vcx(vscale(vsub(uu, t), scale));
+      }
+      *reinterpret_cast<CxVec<T>*>(g + ((size_t)xt * NyhP + ky0 + r) * MIXW + c) = oa;
+      *reinterpret_cast<CxVec<T>*>(g + ((size_t)(xt + NH / MIXW) * NyhP + ky0 + r) * MIXW + c) = ob;
     }
   }
 }
-// F layout: contiguous rows (g = first row of the group)
+// F layout: contiguous rows (g = first row of the group).  The F side of a transform is its bit-reversed end: no level is fused here.
 template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void rows_load_F(cx<T>* __restrict__ s, const cx<T>* __restrict__ g, int nr) {
-  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), TOT = RPW * Nx / VE, K = (TOT + XNT - 1) / XNT;
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), NT = row_nt(RPW), TOT = RPW * Nx / VE, K = (TOT + NT - 1) / NT;
   CxVec<T> v[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int u = threadIdx.x + i * XNT, r = (u * VE) >> LGNX;
-    if ((TOT % XNT == 0 || u < TOT) && r < nr) v[i] = *reinterpret_cast<const CxVec<T>*>(g + (size_t)u * VE);
+    const int u = threadIdx.x + i * NT, r = (u * VE) >> LGNX;
+    if ((TOT % NT == 0 || u < TOT) && r < nr) v[i] = *reinterpret_cast<const CxVec<T>*>(g + (size_t)u * VE);
   }
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int u = threadIdx.x + i * XNT, r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
-    if ((TOT % XNT == 0 || u < TOT) && r < nr) {
+    const int u = threadIdx.x + i * NT, r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
+    if ((TOT % NT == 0 || u < TOT) && r < nr) {
 #pragma unroll
       for (int e = 0; e < VE; ++e) s[r * LD + pad(x) + e] = v[i].v[e];
     }
@@ -296,8 +318,8 @@ __device__ __forceinline__ void rows_load_F(cx<T>* __restrict__ s, const cx<T>* 
 }
 template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void rows_store_F(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int nr, T scale) {
-  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), TOT = RPW * Nx / VE;
-  for (int u = threadIdx.x; u < TOT; u += XNT) {
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), NT = row_nt(RPW), TOT = RPW * Nx / VE;
+  for (int u = threadIdx.x; u < TOT; u += NT) {
     const int r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
     if (r < nr) {
       CxVec<T> v;
@@ -418,15 +440,15 @@ __global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<
 }
 
 // ---------------------------------------------------------------------------------------------
-// x pass.  grid = slices * ceil(Nyh / RPW) row groups.  LDS: twX[Nx] + RPW * row_ld(Nx) cplx
+// x pass.  grid = slices * ceil(Nyh / RPW) row groups, 128 * RPW threads.  LDS: twX[Nx] + RPW * row_ld(Nx) cplx
 //   MODE 0: forward  (mixed -> F)
 //   MODE 1: inverse  (F -> mixed), scaled by 1/Nx
 //   MODE 2: x-derivative  (mixed -> mixed):  ifft_x( i*lx * fft_x(row) ) / Nx        (src/proj_lambert.jl:146-159, coord 1)
 template <typename T, int MODE, int LGNX, int RPW>
-__global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_x_fft(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
-                                                                  const cx<T>* __restrict__ twX, T dlx_over_Nx, int Nyh) {
+__global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
+                                                                          const cx<T>* __restrict__ twX, T dlx_over_Nx, int Nyh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), RT = XNT / RPW;
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + Nx;
   const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh);
@@ -434,36 +456,36 @@ __global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_x_fft(const cx<T>* 
   const size_t mo = (size_t)rg.sl * NyhP * Nx, fo = ((size_t)rg.sl * Nyh + rg.ky0) * Nx;
   CMBL_XWSTAMP(14);
   CMBL_XSTAMP(0);
-  TwStage<T, XNT, Nx> twr;
+  TwStage<T, NT, Nx> twr;
   twr.issue(twX);
   if (MODE == 1) rows_load_F<T, LGNX, RPW>(s, in + fo, rg.nr);
   else {
     cx<T>* const sa[1] = {s};
     const cx<T>* const ga[1] = {in + mo};
-    rows_load_mixed<T, LGNX, RPW, 1>(sa, ga, NyhP, rg.ky0, rg.nr);
+    rows_load_mixed_dif<T, LGNX, RPW, 1>(sa, ga, twX, NyhP, rg.ky0, rg.nr);
   }
   twr.commit(tw);
   CMBL_XSTAMP(6);
   __syncthreads();
   CMBL_XSTAMP(1);
-  const WorkRows<RT, RPW> wk{1, rg.nr};
-  if (MODE == 0 || MODE == 2) fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
+  const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
+  if (MODE == 0 || MODE == 2) fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw);
   CMBL_XSTAMP(2);
   if (MODE == 2) {
     // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
     const T dl = dlx_over_Nx;
-    fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw, [dl](cx<T> v, int i) {
+    fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw, [dl](cx<T> v, int i) {
       const int kx = brevc<LGNX>(i);
       const T l = dl * T(kx < (Nx >> 1) ? kx : kx - Nx);
       return mk<T>(-l * v.y, l * v.x);
     });
   }
-  if (MODE == 1) fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
+  if (MODE == 1) fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw);
   CMBL_XSTAMP(5);
   __syncthreads();
   CMBL_XSTAMP(3);
   if (MODE == 0) rows_store_F<T, LGNX, RPW>(s, out + fo, rg.nr, T(1));
-  else rows_store_mixed<T, LGNX, RPW>(s, out + mo, NyhP, rg.ky0, rg.nr, MODE == 1 ? T(1) / T(Nx) : T(1));
+  else rows_store_mixed_dit<T, LGNX, RPW>(s, out + mo, tw, NyhP, rg.ky0, rg.nr, MODE == 1 ? T(1) / T(Nx) : T(1));
   CMBL_XSTAMP(4);
   CMBL_XWSTAMP(15);
 }

@@ -238,43 +238,43 @@ template <typename T> struct AdjXArgs {
 
 template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* smem, long blk) {
-  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), RT = XNT / RPW, PF = Nx >= RT ? Nx / RT : 1;
+  constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), NT = row_nt(RPW), PF = NH >= 64 ? NH / 64 : 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + Nx;
   cx<T>* s2 = s + RPW * LD;                                   // second row set: sequence RPW + row, owned by the same threads
   const RowGroup rg = row_group<RPW>(blk, a.Nyh);
   const int NyhP = mixed_rows(a.Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx;
-  TwStage<T, XNT, Nx> twr;
+  TwStage<T, NT, Nx> twr;
   twr.issue(a.twX);
   {
     cx<T>* const sa[2] = {s, s2};
     const cx<T>* const ga[2] = {a.Wx + mo, a.Wy + mo};
-    rows_load_mixed<T, LGNX, RPW, 2>(sa, ga, NyhP, rg.ky0, rg.nr);
+    rows_load_mixed_dif<T, LGNX, RPW, 2>(sa, ga, a.twX, NyhP, rg.ky0, rg.nr);
   }
   twr.commit(tw);
   __syncthreads();
-  fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, WorkRows<RT, RPW>{2, rg.nr}, tw);
-  // RK update of this thread's part of its row (F layout: contiguous in x)
-  const int row = threadIdx.x / RT, lane = threadIdx.x % RT;
+  fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
+  // RK update: wave w of a row updates the slots of half w (the ones it transformed; F layout: contiguous in x)
+  const int row = threadIdx.x / ROW_RT, w = (threadIdx.x % ROW_RT) >> 6, lane = threadIdx.x & 63;
   const T inv = T(1) / T(Nx);
   if (row < rg.nr) {
-    const size_t g0 = ((size_t)rg.sl * a.Nyh + rg.ky0 + row) * Nx;
-    cx<T>* sr = s + row * LD; const cx<T>* sr2 = s2 + row * LD;
-    if constexpr (Nx >= RT) {
+    const size_t g0 = ((size_t)rg.sl * a.Nyh + rg.ky0 + row) * Nx + w * NH;
+    cx<T>* sr = s + row * LD + pad(w * NH); const cx<T>* sr2 = s2 + row * LD + pad(w * NH);
+    if constexpr (NH >= 64) {
       constexpr int CH = PF > 8 ? 8 : PF;                     // state loads in flight per thread: CH values of Y0 and of acc
       for (int i0 = 0; i0 < PF; i0 += CH) {
         cx<T> y0[CH], acc[CH]; T lxr[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-          const int x = lane + (i0 + i) * RT;
+          const int x = lane + (i0 + i) * 64;
           y0[i] = a.Y0[g0 + x];
           acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[g0 + x];
-          lxr[i] = a.lx_r[x];
+          lxr[i] = a.lx_r[w * NH + x];
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-          const int x = lane + (i0 + i) * RT, si = pad(x);
+          const int x = lane + (i0 + i) * 64, si = pad(x);
           const cx<T> kv = mul_il(sr[si], lxr[i]) + sr2[si];
           const cx<T> fn = rk_update(a.rk, kv, y0[i], acc[i]);
           if (a.rk.stage == 4) a.Y0[g0 + x] = y0[i]; else a.acc[g0 + x] = acc[i];
@@ -282,9 +282,9 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
         }
       }
     } else {
-      for (int x = lane; x < Nx; x += RT) {
+      for (int x = lane; x < NH; x += 64) {
         const int si = pad(x);
-        const cx<T> kv = mul_il(sr[si], a.lx_r[x]) + sr2[si];
+        const cx<T> kv = mul_il(sr[si], a.lx_r[w * NH + x]) + sr2[si];
         cx<T> y0 = a.Y0[g0 + x];
         cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[g0 + x];
         const cx<T> fn = rk_update(a.rk, kv, y0, acc);
@@ -294,15 +294,15 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
     }
   }
   if (a.rk.last) return;
-  const WorkRows<RT, RPW> wk{1, rg.nr};
+  const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
   wk.sync();
-  fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
+  fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw);
   __syncthreads();
-  rows_store_mixed<T, LGNX, RPW>(s, a.Hnext + mo, NyhP, rg.ky0, rg.nr, T(1));
+  rows_store_mixed_dit<T, LGNX, RPW>(s, a.Hnext + mo, tw, NyhP, rg.ky0, rg.nr, T(1));
 }
 
 template <typename T, int LGNX, int RPW>
-__global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_adj_x(AdjXArgs<T> a) {
+__global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_adj_x(AdjXArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   adj_x_body<T, LGNX, RPW>(a, smem, blockIdx.x);
 }
@@ -311,31 +311,31 @@ __global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_adj_x(AdjXArgs<T> a
 template <typename T> struct GradXArgs { const cx<T>* in; cx<T>* out; const cx<T>* twX; T dlx_over_Nx; int Nyh; };
 template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char* smem, long blk) {
-  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), RT = XNT / RPW;
+  constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + Nx;
   const RowGroup rg = row_group<RPW>(blk, g.Nyh);
   const int NyhP = mixed_rows(g.Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx;
-  TwStage<T, XNT, Nx> twr;
+  TwStage<T, NT, Nx> twr;
   twr.issue(g.twX);
   {
     cx<T>* const sa[1] = {s};
     const cx<T>* const ga[1] = {g.in + mo};
-    rows_load_mixed<T, LGNX, RPW, 1>(sa, ga, NyhP, rg.ky0, rg.nr);
+    rows_load_mixed_dif<T, LGNX, RPW, 1>(sa, ga, g.twX, NyhP, rg.ky0, rg.nr);
   }
   twr.commit(tw);
   __syncthreads();
-  const WorkRows<RT, RPW> wk{1, rg.nr};
-  fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw);
+  const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
+  fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw);
   // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
   const T dl = g.dlx_over_Nx;
-  fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG>(s, wk, tw, [dl](cx<T> v, int i) {
+  fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw, [dl](cx<T> v, int i) {
     const int kx = brevc<LGNX>(i);
     return mul_il(v, dl * T(kx < (Nx >> 1) ? kx : kx - Nx));
   });
   __syncthreads();
-  rows_store_mixed<T, LGNX, RPW>(s, g.out + mo, NyhP, rg.ky0, rg.nr, T(1));
+  rows_store_mixed_dit<T, LGNX, RPW>(s, g.out + mo, tw, NyhP, rg.ky0, rg.nr, T(1));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_cols(Delt
   delta_y_body<T, R, NT, LGM>(d, smem, blockIdx.y);
 }
 template <typename T, int LGNX, int RPW>
-__global__ __launch_bounds__(XNT, row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
+__global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   if (b < nblk_adj) adj_x_body<T, LGNX, RPW>(a, smem, b);
