@@ -220,8 +220,16 @@ constexpr int ROW_RT = 128;                                              // thre
 __host__ __device__ constexpr int row_nt(int rpw) { return ROW_RT * rpw; }   // workgroup size
 __host__ __device__ constexpr int row_ld(int n) { return pad(n) + ((4 - pad(n) % 16) + 16) % 16; }
 // rows per workgroup: as many of 4, 2, 1 as fit the 160 KB of LDS next to the twiddle table (NA row sets: 1, or 2 for the adjoint pass)
+#ifndef CMBL_RPW_SMALL
+#define CMBL_RPW_SMALL 4
+#endif
+#ifndef CMBL_XLG_SMALL
+#define CMBL_XLG_SMALL 3      // Nx < 1024: radix-8 stages keep 64+ butterflies per stage for the two waves of a row (512²: step 2.58 -> 2.32 ms)
+#endif
+// fused radix-2 levels per stage of a row transform
+__host__ __device__ constexpr int row_xlg(int lgnx) { return lgnx >= 10 ? CMBL_XLG : CMBL_XLG_SMALL; }
 template <typename T> __host__ __device__ constexpr int row_rpw(int lgnx, int na) {
-  for (int rpw = 4; rpw >= 1; rpw >>= 1)
+  for (int rpw = (lgnx >= 10 ? 4 : CMBL_RPW_SMALL); rpw >= 1; rpw >>= 1)
     if (((size_t)(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024) return rpw;
   return 0;
 }
@@ -469,18 +477,18 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   __syncthreads();
   CMBL_XSTAMP(1);
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
-  if (MODE == 0 || MODE == 2) fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw);
+  if (MODE == 0 || MODE == 2) fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
   CMBL_XSTAMP(2);
   if (MODE == 2) {
     // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
     const T dl = dlx_over_Nx;
-    fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw, [dl](cx<T> v, int i) {
+    fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](cx<T> v, int i) {
       const int kx = brevc<LGNX>(i);
       const T l = dl * T(kx < (Nx >> 1) ? kx : kx - Nx);
       return mk<T>(-l * v.y, l * v.x);
     });
   }
-  if (MODE == 1) fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw);
+  if (MODE == 1) fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
   CMBL_XSTAMP(5);
   __syncthreads();
   CMBL_XSTAMP(3);

@@ -254,7 +254,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   }
   twr.commit(tw);
   __syncthreads();
-  fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
+  fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
   // RK update: wave w of a row updates the slots of half w (the ones it transformed; F layout: contiguous in x)
   const int row = threadIdx.x / ROW_RT, w = (threadIdx.x % ROW_RT) >> 6, lane = threadIdx.x & 63;
   const T inv = T(1) / T(Nx);
@@ -296,7 +296,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   if (a.rk.last) return;
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
   wk.sync();
-  fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw);
+  fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
   __syncthreads();
   rows_store_mixed_dit<T, LGNX, RPW>(s, a.Hnext + mo, tw, NyhP, rg.ky0, rg.nr, T(1));
 }
@@ -327,10 +327,10 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
   twr.commit(tw);
   __syncthreads();
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
-  fft_dif_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw);
+  fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
   // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
   const T dl = g.dlx_over_Nx;
-  fft_dit_w<T, LD, LGNX, LGNX, CMBL_XLG, 1>(s, wk, tw, [dl](cx<T> v, int i) {
+  fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](cx<T> v, int i) {
     const int kx = brevc<LGNX>(i);
     return mul_il(v, dl * T(kx < (Nx >> 1) ? kx : kx - Nx));
   });
@@ -465,6 +465,12 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
 // partial products w of each stage (two maps per slice, which it wrote before as well), ONE pointwise pass reduces them over
 // stages and pols into five maps, and five real transforms per delta flow replace five per STAGE (4n times fewer).
 // Identical to the reference's stage-by-stage update up to the order of floating-point summation.
+// 16-byte non-temporal load (streaming data read exactly once: keeps the caches for the arrays the flow re-reads)
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_load16(const float* p, float (&o)[4]) { const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void nt_load16(const double* p, double (&o)[2]) { const nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p)); o[0] = v.x; o[1] = v.y; }
+
 template <typename T>
 __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __restrict__ W /*[nst][2][slices][npix]*/,
                                                     const T* __restrict__ tc /*[nst][2] = (t_s, c_s)*/, T* __restrict__ out /*[5][B][npix]*/,
@@ -480,24 +486,36 @@ __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __r
     const Vec hxx = *reinterpret_cast<const Vec*>(ph.hxx + pb + i), hyx = *reinterpret_cast<const Vec*>(ph.hyx + pb + i);
     const Vec hyy = *reinterpret_cast<const Vec*>(ph.hyy + pb + i);
     double U1[V] = {}, U2[V] = {}, A[V] = {}, Bb[V] = {}, Cc[V] = {};
-    for (int s = 0; s < nst; ++s) {
-      const T t = tc[2 * s], c = tc[2 * s + 1];
-      Vec w1 = {}, w2 = {};
-      for (int p = 0; p < P; ++p) {
-        const Vec a1 = *reinterpret_cast<const Vec*>(W + ((size_t)(2 * s) * slices + (size_t)b * P + p) * npix + i);
-        const Vec a2 = *reinterpret_cast<const Vec*>(W + ((size_t)(2 * s + 1) * slices + (size_t)b * P + p) * npix + i);
+    // the per-stage products are read exactly once: non-temporal loads, four stages' worth requested before the first is used
+    constexpr int SU = 4;
+    for (int s0 = 0; s0 < nst; s0 += SU) {
+      Vec w1[SU], w2[SU];
 #pragma unroll
-        for (int k = 0; k < V; ++k) { w1.v[k] += a1.v[k]; w2.v[k] += a2.v[k]; }
+      for (int j = 0; j < SU; ++j) {
+        w1[j] = Vec{}; w2[j] = Vec{};
+        if (s0 + j < nst)
+          for (int p = 0; p < P; ++p) {
+            Vec a1, a2;
+            nt_load16(W + ((size_t)(2 * (s0 + j)) * slices + (size_t)b * P + p) * npix + i, a1.v);
+            nt_load16(W + ((size_t)(2 * (s0 + j) + 1) * slices + (size_t)b * P + p) * npix + i, a2.v);
+#pragma unroll
+            for (int k = 0; k < V; ++k) { w1[j].v[k] += a1.v[k]; w2[j].v[k] += a2.v[k]; }
+          }
       }
 #pragma unroll
-      for (int k = 0; k < V; ++k) {
-        T px, py, m11, m12, m22;
-        flow_pm(t, gx.v[k], gy.v[k], hxx.v[k], hyx.v[k], hyy.v[k], px, py, m11, m12, m22);
-        // u = M^-1 w   (src/field_vectors.jl:48-49; with the reference's aliasing, v[2] sees the updated v[1])
-        const T v1 = m11 * w1.v[k] + m12 * w2.v[k];
-        const T u2 = m12 * (alias_quirk ? v1 : w1.v[k]) + m22 * w2.v[k];
-        U1[k] += (double)(c * v1); U2[k] += (double)(c * u2);
-        A[k] += (double)(c * t * px * v1); Bb[k] += (double)(c * t * (py * v1 + px * u2)); Cc[k] += (double)(c * t * py * u2);
+      for (int j = 0; j < SU; ++j) {
+        if (s0 + j >= nst) break;
+        const T t = tc[2 * (s0 + j)], c = tc[2 * (s0 + j) + 1];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          T px, py, m11, m12, m22;
+          flow_pm(t, gx.v[k], gy.v[k], hxx.v[k], hyx.v[k], hyy.v[k], px, py, m11, m12, m22);
+          // u = M^-1 w   (src/field_vectors.jl:48-49; with the reference's aliasing, v[2] sees the updated v[1])
+          const T v1 = m11 * w1[j].v[k] + m12 * w2[j].v[k];
+          const T u2 = m12 * (alias_quirk ? v1 : w1[j].v[k]) + m22 * w2[j].v[k];
+          U1[k] += (double)(c * v1); U2[k] += (double)(c * u2);
+          A[k] += (double)(c * t * px * v1); Bb[k] += (double)(c * t * (py * v1 + px * u2)); Cc[k] += (double)(c * t * py * u2);
+        }
       }
     }
     const size_t o = (size_t)b * npix + i, cs = (size_t)B * npix;
