@@ -14,4 +14,6 @@ from .drivers import (quadratic_estimate, MAP_joint, MAP_joint_step, hmc_step, s
                       mass_matrix_phi, brent_minimize, sample_joint, MAP_marg, simulate_data)
 from . import rng                                                         # noqa: F401
 from .chainfile import load_chains, Chain, Chains                         # noqa: F401
-from .theta import set_theta, logpdf_mixed_theta, grid_and_sample, gibbs_sample_theta   # noqa: F401
+from .theta import (set_theta, logpdf_mixed_theta, grid_and_sample, gibbs_sample_theta, findbin, bandpower_rescale,   # noqa: F401
+                    BinRescaledCov, use_bandpowers)
+from .muse import CMBLensingMuseProblem                                   # noqa: F401

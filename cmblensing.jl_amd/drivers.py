@@ -233,12 +233,12 @@ def MAP_joint_step(ds, phi, fstart=None, alpha_prev=1.0, alpha_tol=1e-4, alpha_m
         ds.set_op("G_inv", Ginv_saved)
 
 
-def MAP_joint(ds, nsteps=20, phi_start=None, **kw):
-    """`MAP_joint(ds; nsteps)` (src/maximization.jl:116-233): returns (f, ϕ, history)."""
+def MAP_joint(ds, nsteps=20, phi_start=None, fstart=None, **kw):
+    """`MAP_joint(ds; nsteps, fstart)` (src/maximization.jl:116-233) at the dataset's current θ: returns (f, ϕ, history)."""
     proj = ds.proj
     B = ds.d.arr.shape[0]
     phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER) if phi_start is None else phi_start
-    f, alpha, hist = None, 1.0, []
+    f, alpha, hist = fstart, 1.0, []
     for _ in range(nsteps):
         st = MAP_joint_step(ds, phi, fstart=f, alpha_prev=alpha, **kw)
         f, phi, alpha = st["f"], st["phi"], st["alpha"]

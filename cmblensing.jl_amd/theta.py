@@ -15,15 +15,59 @@ import numpy as np
 from .sim import HarmOp, _pinv
 
 
-def _ops(ds, r, Aphi):
+# ---- bandpower amplitudes (src/proj_lambert.jl:374-411) ----------------------------------------------------------------------
+def findbin(ledges, l):
+    """bin index (0-based) of every ℓ in the half-open bins [ℓedges[i], ℓedges[i+1]); out of range -> len(ledges) - 1, the slot of
+    the constant amplitude 1 that `bandpower_rescale` appends (src/proj_lambert.jl:402-404)"""
+    ledges, l = np.asarray(ledges, float), np.asarray(l, float)
+    idx = np.searchsorted(ledges, l, side="right") - 1               # findfirst(>(ℓ), ℓedges) - 1
+    return np.where((l < ledges[0]) | (l >= ledges[-1]), len(ledges) - 1, idx)
+
+
+def bandpower_rescale(plane, bin_idx, amplitudes):
+    """`[amplitudes; 1][ℓbin_indices] .* arr` (src/proj_lambert.jl:405-408)"""
+    a = np.append(np.asarray(amplitudes, float), 1.0)
+    return a[bin_idx] * plane
+
+
+class BinRescaledCov:
+    """`Cℓ_to_Cov(pol, proj, (Cℓ, ℓedges, θname), ...)`: a covariance whose TT / EE / TE planes are rescaled by one amplitude per
+    ℓ-bin (ParamDependentOp over the amplitude vectors; BB is never rescaled, like the reference).  `bands` maps a spectrum
+    ("TT", "EE", "TE") to (ℓedges, θname); `op(**θ)` gives the HarmOp at the named amplitudes (default: all ones)."""
+
+    def __init__(self, pol, proj, cls, bands):
+        self.C0 = HarmOp.from_cls(pol, proj, cls)
+        self.pol = pol
+        plane_of = {"I": {"TT": [0]}, "P": {"EE": [0]}, "IP": {"TT": [0], "TE": [1, 2], "EE": [3]}}[pol]
+        self.bands = {}
+        for spec, (ledges, name) in bands.items():
+            if spec not in plane_of:
+                raise ValueError(f"no rescalable {spec} spectrum for pol={pol} (BB is fixed, src/proj_lambert.jl:385-393)")
+            self.bands[name] = (plane_of[spec], findbin(ledges, proj.lmag), len(ledges) - 1)
+        self.names = list(self.bands)
+
+    def __call__(self, **theta):
+        p = self.C0.p.copy()
+        for name, (planes, idx, nb) in self.bands.items():
+            amps = theta.get(name)
+            amps = np.ones(nb) if amps is None else np.asarray(amps, float)
+            assert amps.shape == (nb,), f"{name}: expected {nb} amplitudes"
+            for k in planes:
+                p[k] = bandpower_rescale(self.C0.p[k], idx, amps)
+        return HarmOp(p)
+
+
+def _ops(ds, r, Aphi, bands=None):
     h = ds.host
     proj = ds.proj
     out, logdet_mix = {}, 0.0
-    Cf = h["Cfs"] + h["Cten"].scale((h["r0"] if r is None else r) / h["r0"])
+    Cfs = h["Cfs_bands"](**(bands or {})) if "Cfs_bands" in h else h["Cfs"]       # bandpower amplitudes rescale the scalar part
+    Cf = Cfs + h["Cten"].scale((h["r0"] if r is None else r) / h["r0"])
     Cphi0 = np.asarray(h.get("Cphi0", h["Cphi"]), float)
     Cphi = Cphi0 * (h["Aphi0"] if Aphi is None else Aphi) / h["Aphi0"]
     Dof = lambda C: ((C + (h["Cn"].scale(2) + h["s2len"])) @ C.pinv()).sqrt()
-    D = Dof(Cf)
+    # D closes over the covariance load_sim built and names r only (src/dataset.jl:322-328): bandpower amplitudes do not enter it
+    D = Dof(h["Cfs"] + h["Cten"].scale((h["r0"] if r is None else r) / h["r0"]))
     if r is not None:
         D0 = Dof(h["Cfs"] + h["Cten"])
         logdet_mix += (D0.pinv() @ D).logdet(proj)
@@ -39,25 +83,35 @@ def _ops(ds, r, Aphi):
     return out, logdet_sum, logdet_mix, dict(Cf=Cf, Cphi=Cphi, D=D, G=G, precond=precond)
 
 
-def set_theta(ds, r=None, Aphi=None):
-    """Evaluate the dataset's ParamDependentOps at θ = (r, Aϕ) (`ds(θ)`, src/dataset.jl:23-31) and make them current on the device;
-    a parameter left None is 'not named in θ': its operators stay fiducial and its logdet term is 0.  `set_theta(ds)` restores the
-    fiducial dataset."""
+def use_bandpowers(ds, bands, cls_scalar):
+    """Make the scalar part of `ds.Cf` a bandpower-rescaled covariance: `bands` = {"EE": (ℓedges, "AEE"), ...}
+    (`ds.Cf = Cℓ_to_Cov(pol, proj, (Cℓ, ℓedges, :AEE), ...)` in the reference).  The amplitude vectors then are parameters of
+    `set_theta` / `logpdf_mixed_theta` / the Gibbs θ pass, next to r and Aϕ."""
+    pol = {1: "I", 2: "P", 3: "IP"}[ds.P]
+    ds.host["Cfs_bands"] = BinRescaledCov(pol, ds.proj, cls_scalar, bands)
+
+
+def set_theta(ds, r=None, Aphi=None, **bands):
+    """Evaluate the dataset's ParamDependentOps at θ = (r, Aϕ[, bandpower amplitude vectors]) (`ds(θ)`, src/dataset.jl:23-31) and
+    make them current on the device; a parameter left None is 'not named in θ': its operators stay fiducial and its logdet term is
+    0.  `set_theta(ds)` restores the fiducial dataset."""
     h = ds.host
     h.setdefault("Cphi0", np.asarray(h["Cphi"], float).copy())
-    ops, logdet_sum, logdet_mix, host = _ops(ds, r, Aphi)
+    if bands and "Cfs_bands" not in h:
+        raise ValueError("bandpower amplitudes given but the dataset has no bandpower covariance (theta.use_bandpowers)")
+    ops, logdet_sum, logdet_mix, host = _ops(ds, r, Aphi, bands)
     for k, v in ops.items():
         ds.set_op(k, v)
     ds.set_logdet(logdet_sum)
     ds.logdet_mix = float(logdet_mix)
     h.update(host)
     ds.L.invalidate()
-    ds.theta = dict(r=r, Aphi=Aphi)
+    ds.theta = dict(r=r, Aphi=Aphi, **bands)
 
 
-def logpdf_mixed_theta(ds, fo, po, r=None, Aphi=None):
+def logpdf_mixed_theta(ds, fo, po, r=None, Aphi=None, **bands):
     """logpdf(Mixed(ds); f°, ϕ°, θ) (src/dataset.jl:84-87), per batch slot; leaves the dataset at θ"""
-    set_theta(ds, r, Aphi)
+    set_theta(ds, r, Aphi, **bands)
     return ds.logpdf_mixed(fo, po)
 
 

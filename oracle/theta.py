@@ -18,31 +18,71 @@ import numpy as np
 
 from .flatsky import pinv, logdet_fourier
 
-__all__ = ["ThetaDataSet", "loess", "grid_and_sample"]
+__all__ = ["ThetaDataSet", "loess", "grid_and_sample", "findbin", "bandpower_rescale"]
+
+
+def findbin(ledges, l):
+    """`findbin` (src/proj_lambert.jl:402-404), 0-based: out of range -> len(ledges) - 1; else (first edge > ℓ) - 1"""
+    ledges = list(ledges)
+    out = np.empty(np.shape(l), int)
+    for i, x in np.ndenumerate(np.asarray(l, float)):
+        if x < ledges[0] or x >= ledges[-1]:
+            out[i] = len(ledges) - 1
+        else:
+            out[i] = next(k for k, e in enumerate(ledges) if e > x) - 1
+    return out
+
+
+def bandpower_rescale(arr, bin_idx, amplitudes):
+    """src/proj_lambert.jl:405-408"""
+    return np.concatenate([np.asarray(amplitudes, float), [1.0]])[bin_idx] * arr
 
 
 class ThetaDataSet:
     """BaseDataSet with the ParamDependentOps of `load_sim`; `base` is the fiducial oracle DataSet (G₀-normalised G = I)."""
 
-    def __init__(self, base, Cfs, Cten, r0=0.2, Aphi0=1.0):
-        self.base, self.Cfs, self.Cten, self.r0, self.Aphi0 = base, Cfs, Cten, r0, Aphi0
+    def __init__(self, base, Cfs, Cten, r0=0.2, Aphi0=1.0, bands=None):
+        """bands: {θname: (plane indices of Cfs to rescale, ℓedges)} -- bandpower amplitudes of the scalar part (src/proj_lambert.jl:374-400)"""
+        self.base, self.Cfs0, self.Cfs, self.Cten, self.r0, self.Aphi0 = base, Cfs, Cfs, Cten, r0, Aphi0
+        self.bands = {k: (pl, findbin(le, base.proj.lmag), len(le) - 1) for k, (pl, le) in (bands or {}).items()}
         self.Cphi0 = base.Cphi / Aphi0
         self.s2len = base.proj.T(np.deg2rad(5 / 60) ** 2)
 
     def D(self, r):
-        Cf = self.Cfs + self.Cten.scale(r / self.r0)
-        return ((Cf + (self.base.Cnhat.scale(2) + self.s2len)) @ Cf.pinv()).sqrt(), Cf
+        """(D(r), Cf(r, amplitudes)): D is built from the covariance `load_sim` created (src/dataset.jl:322-328: it closes over that
+        Cf and names r only), so bandpower amplitudes of a Cf assigned later do not enter it"""
+        Cf0 = self.Cfs0 + self.Cten.scale(r / self.r0)
+        return ((Cf0 + (self.base.Cnhat.scale(2) + self.s2len)) @ Cf0.pinv()).sqrt(), self.Cfs + self.Cten.scale(r / self.r0)
 
     def G(self, Aphi):
         g0 = np.sqrt(1 + 2 * self.base.Nphi * pinv(self.Cphi0 * self.Aphi0))
         return pinv(g0) * np.sqrt(1 + 2 * self.base.Nphi * pinv(self.Cphi0 * Aphi))
 
-    def at(self, r=None, Aphi=None):
+    def _rescaled_Cfs(self, amps):
+        C = copy.deepcopy(self.Cfs0)
+        for name, (planes, idx, nb) in self.bands.items():
+            a = amps.get(name)
+            a = np.ones(nb) if a is None else a
+            for k in planes:                                   # plane k of the operator's array form (HarmOp.arrays order)
+                if C.P == 3:
+                    te = list(C.te)
+                    te[k] = bandpower_rescale(self.Cfs0.te[k], idx, a)
+                    C.te = tuple(te)
+                else:
+                    C.d[k] = bandpower_rescale(self.Cfs0.d[k], idx, a)
+        return C
+
+    def at(self, r=None, Aphi=None, **amps):
         """(dataset at θ, logdet(D,θ), logdet(G,θ)); a parameter left None is 'not in θ' (operators stay fiducial, logdet term 0)"""
         ds = copy.copy(self.base)
         ds._L = None
         proj = ds.proj
         ldD = ldG = 0.0
+        if amps:
+            self.Cfs = self._rescaled_Cfs(amps)
+            ds.Cf = self.Cfs + self.Cten                        # D does not depend on the amplitudes (src/dataset.jl:322-328: r only)
+        else:
+            self.Cfs = self.Cfs0
         if r is not None:
             ds.D, ds.Cf = self.D(r)
             D0, _ = self.D(self.r0)
@@ -53,8 +93,8 @@ class ThetaDataSet:
             ldG = logdet_fourier(proj, ds.G[None, None])              # G() = I at the fiducial point
         return ds, ldD, ldG
 
-    def logpdf_mixed(self, fo, po, r=None, Aphi=None):
-        ds, ldD, ldG = self.at(r, Aphi)
+    def logpdf_mixed(self, fo, po, r=None, Aphi=None, **amps):
+        ds, ldD, ldG = self.at(r, Aphi, **amps)
         return ds.logpdf_mixed(fo, po) - ldD - ldG
 
 

@@ -57,3 +57,34 @@ def test_write_append_load(tmp_path):
     CF.write_chunk(fn, 3, [_samples(c, [9]) for c in range(3)])       # last sample without maps -> cannot resume from it
     with pytest.raises(ValueError):
         CF.last_state(fn)
+
+
+def test_container_is_readable_without_the_package(tmp_path):
+    """Independent reader: the chain container is a plain zip of .npy members laid out like the reference's JLD2 groups
+    (`rundat`, `chunks_<k>` -> per chain -> per sample -> key; src/sampling.jl:311-320), so it can be read with nothing but
+    zipfile + numpy -- here without touching cmblensing.jl_amd.chainfile -- and agrees with load_chains."""
+    import io, json, zipfile
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_cf", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cmblensing.jl_amd", "chainfile.py"))
+    CF = importlib.util.module_from_spec(spec); spec.loader.exec_module(CF)
+    fn = str(tmp_path / "c.zip")
+    rng = np.random.default_rng(0)
+    chains = [[dict(step=i + 1, logpdf=float(rng.normal()), theta_Aphi=1.0 + 0.1 * i, **({"phi": rng.normal(size=(4, 3)) + 1j} if i % 2 == 0 else {}))
+               for i in range(3)] for _ in range(2)]
+    CF.write_chunk(fn, 1, chains, rundat=dict(nchains=2, eps=0.01), clobber=True)
+    CF.write_chunk(fn, 2, [[dict(step=4, logpdf=0.5, theta_Aphi=1.3, phi=np.ones((4, 3), complex))]] * 2)
+    # --- the independent reader
+    got = {}
+    with zipfile.ZipFile(fn) as z:
+        assert json.loads(z.read("rundat.json"))["nchains"] == 2
+        for name in z.namelist():
+            if name.startswith("chunks_"):
+                chunk, chain, idx, key = name.split("/")
+                got.setdefault(int(chain[5:]), {}).setdefault((int(chunk[7:]), int(idx)), {})[key[:-4]] = np.load(io.BytesIO(z.read(name)))
+    ch = CF.load_chains(fn)
+    for c in (0, 1):
+        samples = [got[c][k] for k in sorted(got[c])]
+        assert [int(s["step"]) for s in samples] == [1, 2, 3, 4] == ch[c]["step"].tolist()
+        np.testing.assert_allclose([float(s["theta_Aphi"]) for s in samples], ch[c]["theta_Aphi"])
+        np.testing.assert_allclose(samples[0]["phi"], chains[c][0]["phi"])
+        assert "phi" not in samples[1]

@@ -101,7 +101,10 @@ def test_config1_256_T_lenseflow_forward(camb):
 
 
 def test_config2_512_QU_fwd_adjoint_wiener():
-    """BASELINE config 2: 512² QU fp32 -- L*f, L'g and one argmaxf_logpdf (tol 1e-1, <= 500 its) at the true ϕ vs the oracle"""
+    """BASELINE config 2: 512² QU fp32 -- L*f and L'g against the oracle run here; the argmaxf_logpdf solve (tol 1e-1, <= 500 its, true
+    ϕ) against the float64 oracle's solve of the same problem, which takes the oracle minutes and is committed as data
+    (tests/golden/config2_cg.json, tools/make_config2_golden.py): iteration count within 5 %, same residual history, same solution norm."""
+    import json, os
     C, so, sd = _dataset_pair("f32", "P", (512, 512), theta=2.0, mask=True, beam=0.0)
     ods, ds, p = so["ds"], sd["ds"], sd["proj"]
     F = lambda a, b: C.Field(p, p.tensor(a), b)
@@ -113,11 +116,15 @@ def test_config2_512_QU_fwd_adjoint_wiener():
     assert rel((L * F(fm, C.MAP)).arr.cpu().numpy(), OL.apply(fm)) < 5e-5, "L*f"
     gl = O.rfft2(fm[:, ::-1].copy())
     assert rel((L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy(), OL.adj(gl)) < 5e-5, "L'g"
-    fw_o, h_o = ods.argmaxf_logpdf(phi, tol=1e-1, nsteps=500)
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_cg.json")))
     fw_g, h_g = ds.argmaxf_logpdf(F(phi, C.FOURIER), tol=1e-1, nsteps=500)
-    assert abs(len(h_g) - len(h_o)) <= max(2, len(h_o) // 20), (len(h_g), len(h_o))          # CG count within 5 %
-    np.testing.assert_allclose(h_g[0][1], h_o[0][1], rtol=1e-3)
-    assert rel(fw_g.arr.cpu().numpy(), fw_o) < 1e-2
+    assert abs(len(h_g) - gold["ncg"]) <= max(2, gold["ncg"] // 20), (len(h_g), gold["ncg"])          # CG count within 5 %
+    res_g = np.array([h[1][0] for h in h_g])
+    n = min(len(res_g), gold["ncg"])
+    np.testing.assert_allclose(res_g[0], gold["res"][0], rtol=1e-3)
+    np.testing.assert_allclose(res_g[:10], gold["res"][:10], rtol=1e-3)                                 # fp32 round-off is amplified from there on
+    assert res_g[n - 1] < 1e-3 * res_g[0] and gold["res"][n - 1] < 1e-3 * gold["res"][0]
+    np.testing.assert_allclose(float(fw_g.arr.abs().pow(2).sum().sqrt()), gold["f_l2"], rtol=1e-2)
 
 
 def _fd_check_f_gradient(C, ds, fo, po, lp0, gfo, seed=3, e=0.05):

@@ -382,3 +382,45 @@ def test_nan_logpdf_is_a_value_not_an_error():
     # HMC: a NaN ΔH is a rejection
     x, dH, acc = C.hmc_step(ds, fo, bad, np.zeros((1, 1, 64, 64)), np.log([0.5]), N=2, eps=0.01)
     assert np.isnan(dH[0]) and not acc[0]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_bandpower_theta_and_muse_adapter(prec):
+    """(f) rank 4 remainder: bandpower-rescaled covariances as θ (src/proj_lambert.jl:374-411) against the oracle, and the MUSE problem
+    interface (ext/CMBLensingMuseInferenceExt.jl:44-72) on the device dataset."""
+    from oracle.theta import ThetaDataSet
+    C, so, sd = _dataset_pair(prec, "P", (64, 64), mask=True, beam=1.0)
+    ods, ds, p = so["ds"], sd["ds"], sd["proj"]
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    ds.set_data(F(so["d"], C.HARMONIC))
+    le = [100, 600, 1500, 3000]
+    cls = {k: C.Cls(v.ell, v.cl) for k, v in so["cls"]["unlensed_scalar"].items()}
+    C.use_bandpowers(ds, {"EE": (le, "AEE")}, cls)
+    th = ThetaDataSet(ods, so["Cfs"], so["Cten"], bands={"AEE": ([0], le)})
+    fo_o, po_o = ods.mix(so["f"], so["phi"])
+    fo, po = F(fo_o, C.MAP), F(po_o, C.FOURIER)
+    rt = 3e-5 if prec == "f32" else 1e-10
+    for kw in (dict(), dict(AEE=np.ones(3)), dict(AEE=np.array([1.3, 1.0, 0.8])), dict(AEE=np.array([0.9, 1.1, 1.0]), r=0.3, Aphi=1.1)):
+        np.testing.assert_allclose(C.logpdf_mixed_theta(ds, fo, po, **kw), th.logpdf_mixed(fo_o, po_o, **kw), rtol=rt, err_msg=str(kw))
+    C.set_theta(ds)
+    # ---- MUSE adapter
+    prob = C.CMBLensingMuseProblem(ds, MAP_joint_kwargs=dict(nsteps=2, cg_nsteps=20))
+    z = dict(f=F(so["f"], C.HARMONIC), phi=F(so["phi"], C.FOURIER))
+    d = F(so["d"], C.HARMONIC)
+    ll = prob.logLike(d, z, dict(Aphi=1.0))
+    np.testing.assert_allclose(ll, ods.logpdf(so["f"], so["phi"]), rtol=2e-5 if prec == "f32" else 1e-10)
+    if prec == "f64":
+        g = prob.grad_theta_logLike(d, z, dict(Aphi=1.0, r=0.2))
+        o = lambda **kw: th.at(**kw)[0].logpdf(so["f"], so["phi"])[0]
+        for k, x0 in (("Aphi", 1.0), ("r", 0.2)):
+            h = 1e-3 * x0
+            fd = (o(**{k: x0 + h}) - o(**{k: x0 - h})) / (2 * h)
+            np.testing.assert_allclose(g[k], fd, rtol=1e-5)
+    x, zs = prob.sample_x_z(7, dict(Aphi=1.2))
+    assert tuple(x.arr.shape) == (1, 2, 64, 33) and np.isfinite(x.arr.abs().sum().item())
+    x2, _ = prob.sample_x_z(7, dict(Aphi=1.2))
+    assert torch.equal(x.arr, x2.arr)                                   # same seed, same simulation
+    zh, hist = prob.zhat_at_theta(x, None, dict(Aphi=1.2))
+    assert len(hist) == 2 and hist[1]["logpdf"][0] > hist[0]["logpdf"][0]
+    assert abs(ds.d.arr - d.arr).max().item() == 0                      # the dataset's own data is restored
+    C.set_theta(ds)

@@ -9,25 +9,29 @@ import cmblensing_jl_amd as C
 from bench import synthetic_cls
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+POL = os.environ.get("CMBL_DIST_POL", "P")                     # "IP": T+QU chains (BASELINE config 4)
+NCH = int(os.environ.get("CMBL_DIST_NCH", "4"))
+SKIP_MARG = os.environ.get("CMBL_DIST_SKIP_MARG", "0") == "1"
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
 kw = dict(T=torch.float64, beam_fwhm=1.0, pixel_mask=dict(pad_deg=0.3, apod_deg=0.4))
-s = C.load_sim(3.0, (64, 64), "P", synthetic_cls(), **kw)
+s = C.load_sim(3.0, (64, 64), POL, synthetic_cls(), **kw)
 ds = s["ds"]
-# MAP_marg: 6 sims over the ranks vs all on one rank
-mm = dict(nsteps=2, nsteps_with_meanfield_update=2, alpha=0.2, Nsims=6, sims_per_batch=1, base_seed=3, cg_tol=0.0, cg_nsteps=10)
-phi_d, _ = C.MAP_marg(ds, dist=dist if world > 1 else None, **mm)
-phi_1, _ = C.MAP_marg(ds, dist=None, **mm)
-err = float((phi_d.arr - phi_1.arr).abs().max() / phi_1.arr.abs().max())
-print(f"[rank {rank}] MAP_marg distributed vs single: max rel diff {err:.2e}")
-assert err < 1e-9
-# sample_joint: 4 chains over the ranks, one file written by rank 0
-nch = 4
+if not SKIP_MARG:
+    # MAP_marg: 6 sims over the ranks vs all on one rank
+    mm = dict(nsteps=2, nsteps_with_meanfield_update=2, alpha=0.2, Nsims=6, sims_per_batch=1, base_seed=3, cg_tol=0.0, cg_nsteps=10)
+    phi_d, _ = C.MAP_marg(ds, dist=dist if world > 1 else None, **mm)
+    phi_1, _ = C.MAP_marg(ds, dist=None, **mm)
+    err = float((phi_d.arr - phi_1.arr).abs().max() / phi_1.arr.abs().max())
+    print(f"[rank {rank}] MAP_marg distributed vs single: max rel diff {err:.2e}")
+    assert err < 1e-9
+# sample_joint: NCH chains over the ranks, one file written by rank 0
+nch = NCH
 ids = C.partition_chains(nch, world, rank)
-sb = C.load_sim(3.0, (64, 64), "P", synthetic_cls(), Nbatch=len(ids), Nphi="flat", T=torch.float64, beam_fwhm=1.0)
+sb = C.load_sim(3.0, (64, 64), POL, synthetic_cls(), Nbatch=len(ids), Nphi="flat", T=torch.float64, beam_fwhm=1.0)
 d0 = s["d"].arr[:1].repeat(len(ids), 1, 1, 1).contiguous()
 sb["ds"].set_data(C.Field(sb["proj"], d0, C.HARMONIC))
-fn = os.path.join(tempfile.gettempdir(), "cmbl_dist_chain.zip")
+fn = os.path.join(tempfile.gettempdir(), f"cmbl_dist_chain_{POL}_{nch}.zip")
 if rank == 0 and os.path.exists(fn):
     os.remove(fn)
 if world > 1:
@@ -41,11 +45,14 @@ if rank == 0:
     assert len(ch) == nch and ch["step"].shape == (nch, 4)
     np.testing.assert_allclose(ch["logpdf"], out["logpdf"].T, rtol=1e-12)
     # every chain equals the same chain run alone in one process
-    one = C.load_sim(3.0, (64, 64), "P", synthetic_cls(), Nbatch=1, Nphi="flat", T=torch.float64, beam_fwhm=1.0)
+    one = C.load_sim(3.0, (64, 64), POL, synthetic_cls(), Nbatch=1, Nphi="flat", T=torch.float64, beam_fwhm=1.0)
     one["ds"].set_data(C.Field(one["proj"], d0[:1].contiguous(), C.HARMONIC))
-    for c in range(nch):
+    for c in range(0, nch, max(1, nch // 4)):
         r1 = C.sample_joint(one["ds"], 4, chain_ids=(c,), base_seed=9, N=3, eps=0.01, rng="device")
-        np.testing.assert_allclose(r1["logpdf"][:, 0], ch[c, "logpdf"], rtol=1e-6)
-    print("[rank 0] sample_joint: chain file holds all %d chains; each equals its single-process run" % nch)
+        # chains that share a dataset as batch slots share the Wiener-filter CG's stopping test (`all(res < tol)`,
+        # src/numerical_algorithms.jl:111,122), so a chain run alone stops a few iterations apart: tolerance-level differences
+        np.testing.assert_allclose(r1["logpdf"][:, 0], ch[c, "logpdf"], rtol=1e-6 if len(ids) == 1 else 1e-3)
+    print("[rank 0] sample_joint (%s, %d ranks): chain file holds all %d chains; each checked chain equals its single-process run" % (POL, world, nch))
+    print("DIST_CHECK_OK")
 if world > 1:
     dist.destroy_process_group()
