@@ -97,6 +97,102 @@ template <typename T> __device__ __forceinline__ cx<T> mul_il(cx<T> v, T l) { re
 template <typename T> __device__ __forceinline__ cx<T> pmul(cx<T> a, cx<T> b) { return mk<T>(a.x * b.x, a.y * b.y); }   // elementwise on a pair
 
 // ---------------------------------------------------------------------------------------------
+// N-point (pair) transforms of a column tile with the TOP radix-2 level fused into the register phase, like the row kernels:
+// a thread that owns the packed pairs jj and jj + M/2 of a column holds samples a and a + M (a = 2jj, 2jj+1), so it can
+//   * after the inverse sub-stages combine the two halves:  z[a] = u[a] + conj(W_N^a) v[a],  z[a + M] = u[a] - conj(W_N^a) v[a]
+//   * before the forward sub-stages split them:             u[a] = z[a] + z[a + M],          v[a] = (z[a] - z[a + M]) W_N^a
+// and the remaining levels run on the 2C half-columns, one per wavefront (WorkRows<NT/C, C>: 1024 points = 2 waves x 3 radix-8
+// stages of one butterfly per lane; no barrier between the stages, every thread busy -- the cooperative radix-16 stages had 256
+// butterflies for 512 threads).  PairMap gives the pair ownership: split tiles own (jj, jj + M/2) of R/2 columns, the others the
+// interleaved pairs tid + i*NT as before.
+#ifndef CMBL_COL_SPLIT
+#define CMBL_COL_SPLIT 1
+#endif
+template <int R, int NT, int LGM> struct PairMap {
+  static constexpr int M = 1 << LGM, MH = M >> 1, C = (R * NT) >> LGM;
+  static constexpr bool split = CMBL_COL_SPLIT && (R % 2 == 0) && (NT % MH == 0) && (NT % C == 0) && (NT / C == 64 || NT / C == 128) && M >= 32;
+  static constexpr int XLG = LGM + 1 >= 11 ? 4 : 3;            // sub-stage radix of the split N-point transforms
+  __device__ static __forceinline__ int e(int i) {
+    if constexpr (split) {
+      const int g = threadIdx.x / MH, q = threadIdx.x % MH;
+      return ((g * (R / 2) + (i >> 1)) << LGM) + q + MH * (i & 1);
+    } else return threadIdx.x + i * NT;
+  }
+};
+// samples (x + i y)[a], a = 2jj, 2jj+1 and a + M from the two halves u (slots a) and v (slots a + M) of an N-point column
+template <typename T>
+__device__ __forceinline__ void read_pair_dit(const cx<T>* col, int jj, int M, const cx<T>* tw, T scale, cx<T>& x0, cx<T>& y0, cx<T>& x1, cx<T>& y1) {
+  using V = typename vreg<T>::type;
+  const cx<T>* p = col + pad(2 * jj);
+  const V u0 = vload(p), u1 = vload(p + 1);
+  const V t0 = vmulc(vload(p + pad(M)), vload(tw + 2 * jj)), t1 = vmulc(vload(p + pad(M) + 1), vload(tw + 2 * jj + 1));
+  const cx<T> a0 = vcx(vscale(vadd(u0, t0), scale)), a1 = vcx(vscale(vadd(u1, t1), scale));
+  const cx<T> b0 = vcx(vscale(vsub(u0, t0), scale)), b1 = vcx(vscale(vsub(u1, t1), scale));
+  x0 = mk<T>(a0.x, a1.x); y0 = mk<T>(a0.y, a1.y); x1 = mk<T>(b0.x, b1.x); y1 = mk<T>(b0.y, b1.y);
+}
+template <typename T>
+__device__ __forceinline__ void write_pair_dif(cx<T>* col, int jj, int M, const cx<T>* tw, cx<T> x0, cx<T> y0, cx<T> x1, cx<T> y1) {
+  using V = typename vreg<T>::type;
+  cx<T>* p = col + pad(2 * jj);
+  const V za0 = vmake(x0.x, y0.x), za1 = vmake(x0.y, y0.y), zb0 = vmake(x1.x, y1.x), zb1 = vmake(x1.y, y1.y);
+  vstore(p, vadd(za0, zb0));
+  vstore(p + 1, vadd(za1, zb1));
+  vstore(p + pad(M), vmul(vsub(za0, zb0), vload(tw + 2 * jj)));
+  vstore(p + pad(M) + 1, vmul(vsub(za1, zb1), vload(tw + 2 * jj + 1)));
+}
+// inverse N-point transform of the tile (bit-reversed input already committed and synchronised) -> (x, y) pairs, scaled
+template <typename T, int R, int NT, int LGM, int LD>
+__device__ __forceinline__ void npt_inverse_read(cx<T>* s, const cx<T>* tw, T scale, cx<T> (&x)[R], cx<T> (&y)[R]) {
+  using PM = PairMap<R, NT, LGM>;
+  constexpr int M = 1 << LGM, LGN = LGM + 1, C = PM::C;
+  if constexpr (PM::split) {
+    fft_dit_w<T, LD, LGN, LGN, PM::XLG, 1>(s, WorkRows<NT / C, C>{1, C}, tw);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; i += 2) {
+      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      read_pair_dit(s + c * LD, jj, M, tw, scale, x[i], y[i], x[i + 1], y[i + 1]);
+    }
+  } else {
+    fft_dit<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      read_pair(s + c * LD, jj, scale, x[i], y[i]);
+    }
+  }
+}
+// (x, y) pairs -> forward N-point transform of the tile (bit-reversed output, synchronised); the tile must be free (sync before)
+// xy(i, x, y) yields pair i of the thread
+template <typename T, int R, int NT, int LGM, int LD, typename XY>
+__device__ __forceinline__ void npt_write_forward(cx<T>* s, const cx<T>* tw, XY&& xy) {
+  using PM = PairMap<R, NT, LGM>;
+  constexpr int M = 1 << LGM, LGN = LGM + 1, C = PM::C;
+  if constexpr (PM::split) {
+#pragma unroll
+    for (int i = 0; i < R; i += 2) {
+      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      cx<T> x0, y0, x1, y1;
+      xy(i, x0, y0); xy(i + 1, x1, y1);
+      write_pair_dif(s + c * LD, jj, M, tw, x0, y0, x1, y1);
+    }
+    __syncthreads();
+    fft_dif_w<T, LD, LGN, LGN, PM::XLG, 1>(s, WorkRows<NT / C, C>{1, C}, tw);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      cx<T> x, y;
+      xy(i, x, y);
+      write_pair(s + c * LD, jj, x, y);
+    }
+    __syncthreads();
+    fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Forward / inverse flow, column kernel.  grid (Nx/C, P*B).  LDS: twY[M] + C*tile_ld(2M).
 //   in : A  = rfft_y(f_s)  (mixed), Gx = d/dx f_s y-transformed (mixed; from k_x_fft<MODE 2>)
 //   out: y0/acc updated, Anext = rfft_y(f_{s+1}) (mixed)
@@ -131,10 +227,11 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   const size_t pbase = ((size_t)bphi * Nx + x0) * M, mbase = (sl * Nx + x0) * (size_t)M;
   cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
   cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
+  using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R], y0[R], acc[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT;
+    const int e = PM::e(i);
     load_p_only(a.ph, pbase + e, a.rk.t, px[i], py[i]);
     y0[i] = y0p[e];
     acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
@@ -142,14 +239,12 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   twr.commit(tw);
   ps.template commit<LD>(s);
   __syncthreads();
-  fft_dit<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
-  cx<T> fn[R];
+  cx<T> fn[R], dx[R], dy[R];
+  npt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, dx, dy);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
-    cx<T> dx, dy;
-    read_pair(s + c * LD, jj, invNy, dx, dy);
-    const cx<T> kv = pmul(px[i], dx) + pmul(py[i], dy);
+    const int e = PM::e(i);
+    const cx<T> kv = pmul(px[i], dx[i]) + pmul(py[i], dy[i]);
     fn[i] = rk_update(a.rk, kv, y0[i], acc[i]);
     if (a.rk.stage == 4) y0p[e] = y0[i]; else accp[e] = acc[i];
   }
@@ -157,7 +252,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
     s[c * LD + pad(jj)] = fn[i];
   }
   __syncthreads();
@@ -195,9 +290,10 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   twr.issue(a.twY);
   tl.issue(a.H + moff, Nx, x0);
   const size_t pbase = ((size_t)bphi * Nx + x0) * M;
+  using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + threadIdx.x + i * NT, a.t, px[i], py[i]);
+  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + PM::e(i), a.t, px[i], py[i]);
   T lyr[G::RZ];                                               // ly of this thread's half-spectrum entries (used after the last transform)
 #pragma unroll
   for (int i = 0; i < G::RZ; ++i) { const int e = threadIdx.x + i * NT; if (e < C * (M + 1)) lyr[i] = a.ly[e >> LGC]; }
@@ -209,17 +305,11 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   cx<T> yv[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
     yv[i] = invNy * s[c * LD + pad(jj)];
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
-    write_pair(s + c * LD, jj, pmul(px[i], yv[i]), pmul(py[i], yv[i]));
-  }
-  __syncthreads();
-  fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
+  npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], yv[i]); y = pmul(py[i], yv[i]); });
   cx<T>* Wx = a.Wx + moff; cx<T>* Wy = a.Wy + moff;
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
     const size_t gi = mix_idx(k, x0 + c, NyhP);
@@ -375,21 +465,17 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, x0);
   twr.commit(tw);
   ps.template commit<LD>(s);
+  using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + threadIdx.x + i * NT, a.rk.t, px[i], py[i]);
+  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + PM::e(i), a.rk.t, px[i], py[i]);
   th.issue(d.H + moff, Nx, x0);
   __syncthreads();
   CMBL_STAMP(1);
   // (d/dx f, d/dy f) from one N-point inverse transform
-  fft_dit<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
-  CMBL_STAMP(2);
   cx<T> dx[R], dy[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
-    read_pair(s + c * LD, jj, invNy, dx[i], dy[i]);
-  }
+  npt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, dx, dy);
+  CMBL_STAMP(2);
   __syncthreads();
   CMBL_STAMP(3);
   // L(delta f) = irfft2(delta f)
@@ -399,7 +485,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   cx<T> fn[R], ldf[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {                               // RK state: requested now, used after the second transform
-    const int e = threadIdx.x + i * NT;
+    const int e = PM::e(i);
     fn[i] = y0p[e];
     ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
   }
@@ -410,7 +496,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   CMBL_STAMP(5);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
+    const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
     cx<T> y0 = fn[i], acc = ldf[i];
     ldf[i] = invNy * s[c * LD + pad(jj)];
     reinterpret_cast<cx<T>*>(d.w1p)[mbase + e] = pmul(ldf[i], dx[i]);
@@ -422,14 +508,8 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   __syncthreads();
   CMBL_STAMP(6);
   // (Wx, Wy') from one N-point forward transform of px*Ldf + i*py*Ldf
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1);
-    write_pair(s + c * LD, jj, pmul(px[i], ldf[i]), pmul(py[i], ldf[i]));
-  }
-  __syncthreads();
   CMBL_STAMP(7);
-  fft_dif<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
+  npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], ldf[i]); y = pmul(py[i], ldf[i]); });
   CMBL_STAMP(8);
   {
     cx<T>* Wx = d.Wx + moff; cx<T>* Wy = d.Wy + moff;
@@ -443,7 +523,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   __syncthreads();
   // next-stage f : rfft_y
 #pragma unroll
-  for (int i = 0; i < R; ++i) { const int e = threadIdx.x + i * NT, c = e >> LGM, jj = e & (M - 1); s[c * LD + pad(jj)] = fn[i]; }
+  for (int i = 0; i < R; ++i) { const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1); s[c * LD + pad(jj)] = fn[i]; }
   __syncthreads();
   CMBL_STAMP(10);
   fft_dif<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
