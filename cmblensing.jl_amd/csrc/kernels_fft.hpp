@@ -165,6 +165,132 @@ __device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx
   }
 }
 
+#ifndef CMBL_COL_SPLIT
+#define CMBL_COL_SPLIT 1
+#endif
+template <int R, int NT, int LGM> struct PairMap {
+  static constexpr int M = 1 << LGM, MH = M >> 1, C = (R * NT) >> LGM;
+  static constexpr bool split = CMBL_COL_SPLIT && (R % 2 == 0) && (NT % MH == 0) && (NT % C == 0) && (NT / C == 64 || NT / C == 128) && M >= 32;
+  static constexpr int XLG = LGM + 1 >= 11 ? 4 : 3;            // sub-stage radix of the split N-point transforms
+  __device__ static __forceinline__ int e(int i) {
+    if constexpr (split) {
+      const int g = threadIdx.x / MH, q = threadIdx.x % MH;
+      return ((g * (R / 2) + (i >> 1)) << LGM) + q + MH * (i & 1);
+    } else return threadIdx.x + i * NT;
+  }
+};
+
+// ---- packed-real (M-point) transforms of a column tile, with everything around the butterflies fused ------------------------
+// HalfStage: the half-spectrum tile loader that pairs A[k] with A[M-k] and does the c2r preparation while committing
+//   Z[k] = (A[k] + conj A[M-k]) + i conj(w^k) (A[k] - conj A[M-k]),  Z[M-k] = conj(...)      (Im A[0], Im A[M] dropped: FFTW c2r)
+// straight to the bit-reversed slots of the M-point inverse transform (twiddles w^k = exp(-2 pi i k / N) read from the global table:
+// the LDS copy is not synchronised yet).  Replaces TileStage + c2r_pre: one LDS pass and one barrier less.
+template <typename T, int NT, int LGM, int LGC> struct HalfStage {
+  static constexpr int M = 1 << LGM, C = 1 << LGC, NP = (M >> 1) + 1, TOT = C * NP, K = (TOT + NT - 1) / NT, NyhP = mixed_rows(M + 1);
+  cx<T> a[K], b[K], w[K];
+  __device__ __forceinline__ void issue(const cx<T>* __restrict__ g /*slice base*/, const cx<T>* __restrict__ twg, int x0) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int u = threadIdx.x + i * NT;
+      if (TOT % NT == 0 || u < TOT) {
+        const int k = u >> LGC, x = x0 + (u & (C - 1));
+        a[i] = g[mix_idx(k, x, NyhP)]; b[i] = g[mix_idx(M - k, x, NyhP)]; w[i] = twg[k];
+      }
+    }
+  }
+  template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int u = threadIdx.x + i * NT;
+      if (TOT % NT == 0 || u < TOT) {
+        const int k = u >> LGC, k2 = M - k;
+        cx<T>* p = s + (u & (C - 1)) * LD;
+        if (k == 0) p[0] = mk<T>(a[i].x + b[i].x, a[i].x - b[i].x);
+        else {
+          const cx<T> e = mk<T>(a[i].x + b[i].x, a[i].y - b[i].y), o = mk<T>(a[i].x - b[i].x, a[i].y + b[i].y);
+          const cx<T> wo = mul_i(cmulconj(o, w[i]));
+          p[pad(brevc<LGM>(k))] = e + wo;
+          if (k2 != k) p[pad(brevc<LGM>(k2))] = conj(e - wo);
+        }
+      }
+    }
+  }
+};
+// the r2c finish fused into the store: Z (bit-reversed slots, after the M-point forward transform) -> A[k], A[M-k] -> mixed layout
+template <typename T, int NT, int LD, int LGM, int LGC>
+__device__ __forceinline__ void half_store(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, const cx<T>* __restrict__ tw, int x0) {
+  constexpr int M = 1 << LGM, C = 1 << LGC, NP = (M >> 1) + 1, NyhP = mixed_rows(M + 1);
+  for (int u = threadIdx.x; u < C * NP; u += NT) {
+    const int k = u >> LGC, k2 = M - k, x = x0 + (u & (C - 1));
+    const cx<T>* p = s + (u & (C - 1)) * LD;
+    if (k == 0) {
+      const cx<T> z = p[0];
+      g[mix_idx(0, x, NyhP)] = mk<T>(z.x + z.y, 0); g[mix_idx(M, x, NyhP)] = mk<T>(z.x - z.y, 0);
+    } else {
+      const cx<T> a = p[pad(brevc<LGM>(k))], b = p[pad(brevc<LGM>(k2))];
+      const cx<T> e = mk<T>(T(0.5) * (a.x + b.x), T(0.5) * (a.y - b.y)), o = mk<T>(T(0.5) * (a.x - b.x), T(0.5) * (a.y + b.y));
+      const cx<T> wo = mul_mi(o * tw[k]);
+      g[mix_idx(k, x, NyhP)] = e + wo;
+      if (k2 != k) g[mix_idx(k2, x, NyhP)] = conj(e - wo);
+    }
+  }
+}
+// M-point inverse (input committed to bit-reversed slots and synchronised) -> the thread's packed pairs z[jj] = f[2jj] + i f[2jj+1],
+// scaled.  Split tiles: sub-stages per half-column (WorkRows, no barriers) and the last level while reading:
+//   z[jj] = u[jj] + conj(W_M^jj) v[jj],  z[jj + M/2] = u[jj] - conj(W_M^jj) v[jj]         (W_M^jj = tw[2 jj], tw = exp(-2 pi i k / N))
+template <typename T, int R, int NT, int LGM, int LD>
+__device__ __forceinline__ void mpt_inverse_read(cx<T>* s, const cx<T>* tw, T scale, cx<T> (&z)[R]) {
+  using PM = PairMap<R, NT, LGM>;
+  using V = typename vreg<T>::type;
+  constexpr int M = 1 << LGM, MH = M >> 1, C = PM::C;
+  if constexpr (PM::split) {
+    fft_dit_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<NT / C, C>{1, C}, tw);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; i += 2) {
+      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const cx<T>* p = s + c * LD + pad(jj);
+      const V u = vload(p), t = vmulc(vload(p + pad(MH)), vload(tw + 2 * jj));
+      z[i] = vcx(vscale(vadd(u, t), scale)); z[i + 1] = vcx(vscale(vsub(u, t), scale));
+    }
+  } else {
+    fft_dit<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      z[i] = scale * s[c * LD + pad(jj)];
+    }
+  }
+}
+// packed pairs z(i) of the thread -> M-point forward transform (bit-reversed slots, synchronised); the tile must be free
+template <typename T, int R, int NT, int LGM, int LD, typename ZF>
+__device__ __forceinline__ void mpt_write_forward(cx<T>* s, const cx<T>* tw, ZF&& zf) {
+  using PM = PairMap<R, NT, LGM>;
+  using V = typename vreg<T>::type;
+  constexpr int M = 1 << LGM, MH = M >> 1, C = PM::C;
+  if constexpr (PM::split) {
+#pragma unroll
+    for (int i = 0; i < R; i += 2) {
+      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      cx<T>* p = s + c * LD + pad(jj);
+      const V za = vfrom(zf(i)), zb = vfrom(zf(i + 1));
+      vstore(p, vadd(za, zb));
+      vstore(p + pad(MH), vmul(vsub(za, zb), vload(tw + 2 * jj)));
+    }
+    __syncthreads();
+    fft_dif_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<NT / C, C>{1, C}, tw);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      s[c * LD + pad(jj)] = zf(i);
+    }
+    __syncthreads();
+    fft_dif<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
+  }
+}
+
 // Two real sequences per complex transform.  Z = X + iY with X, Y the (Hermitian-extended) half spectra:
 //   Z[k] = X[k] + i Y[k],  Z[N-k] = conj(X[k]) + i conj(Y[k])  (0<k<M);  Z[0], Z[M] from the real parts only (c2r semantics).
 // After the N-point DIT the tile holds N*(x[n] + i y[n]).  Frequency k sits at slot pad(brev_N(k)).
@@ -367,20 +493,15 @@ __global__ __launch_bounds__(NT) void k_y_r2c(const T* __restrict__ in, cx<T>* _
   const size_t sl = blockIdx.y;
   TwStage<T, NT, 2 * M> twr;
   twr.issue(twY);
+  using PM = PairMap<R, NT, LGM>;
   const cx<T>* src = reinterpret_cast<const cx<T>*>(in) + (sl * Nx + x0) * (size_t)M;
   cx<T> v[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) v[i] = src[threadIdx.x + i * NT];
+  for (int i = 0; i < R; ++i) v[i] = src[PM::e(i)];
   twr.commit(tw);
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, j = e & (M - 1);
-    s[c * LD + pad(j)] = v[i];
-  }
   __syncthreads();
-  fft_dif<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
-  r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)mixed_rows(G::Nyh) * Nx, Nx, x0);
+  mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return v[i]; });
+  half_store<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)mixed_rows(G::Nyh) * Nx, tw, x0);
 }
 
 // y pass, inverse: mixed -> map, scaled by `scale` (1/Ny; the x pass already carries 1/Nx)
@@ -393,21 +514,19 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
   cx<T>* s = tw + 2 * M;
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
+  using PM = PairMap<R, NT, LGM>;
   TwStage<T, NT, 2 * M> twr;
-  TileStage<T, NT, LGM, G::LGC> tl;
+  HalfStage<T, NT, LGM, G::LGC> tl;
   twr.issue(twY);
-  tl.issue(in + sl * (size_t)mixed_rows(G::Nyh) * Nx, Nx, x0);
+  tl.issue(in + sl * (size_t)mixed_rows(G::Nyh) * Nx, twY, x0);
   twr.commit(tw);
   tl.template commit<LD>(s);
   __syncthreads();
-  c2r_pre<T, NT, LD, LGM>(s, C, tw);
-  fft_dit<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
+  cx<T> z[R];
+  mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, scale, z);
   cx<T>* dst = reinterpret_cast<cx<T>*>(out) + (sl * Nx + x0) * (size_t)M;
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = threadIdx.x + i * NT, c = e >> LGM, j = e & (M - 1);
-    dst[e] = scale * s[c * LD + pad(j)];
-  }
+  for (int i = 0; i < R; ++i) dst[PM::e(i)] = z[i];
 }
 
 // y pass of the pixel-mask sandwich  rfft2( m .* irfft2(x) )  (M = Mfourier * Mpix, src/dataset.jl:279-285): mixed -> map (in LDS /
@@ -422,29 +541,23 @@ __global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<
   cx<T>* s = tw + 2 * M;
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
+  using PM = PairMap<R, NT, LGM>;
   TwStage<T, NT, 2 * M> twr;
-  TileStage<T, NT, LGM, G::LGC> tl;
+  HalfStage<T, NT, LGM, G::LGC> tl;
   twr.issue(twY);
-  tl.issue(in + sl * (size_t)mixed_rows(G::Nyh) * Nx, Nx, x0);
+  tl.issue(in + sl * (size_t)mixed_rows(G::Nyh) * Nx, twY, x0);
   const cx<T>* mk2 = reinterpret_cast<const cx<T>*>(mask) + (size_t)x0 * M;       // the mask is one (Nx, Ny) map for all slices
   cx<T> mv[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) mv[i] = mk2[threadIdx.x + i * NT];
+  for (int i = 0; i < R; ++i) mv[i] = mk2[PM::e(i)];
   twr.commit(tw);
   tl.template commit<LD>(s);
   __syncthreads();
-  c2r_pre<T, NT, LD, LGM>(s, C, tw);
-  fft_dit<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
-#pragma unroll
-  for (int i = 0; i < R; ++i) {                       // each thread scales the packed pairs it owns: same slots read and written
-    const int e = threadIdx.x + i * NT, c = e >> LGM, j = e & (M - 1);
-    const cx<T> v = s[c * LD + pad(j)];
-    s[c * LD + pad(j)] = mk<T>(scale * mv[i].x * v.x, scale * mv[i].y * v.y);
-  }
+  cx<T> z[R];
+  mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, scale, z);
   __syncthreads();
-  fft_dif<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
-  r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)mixed_rows(G::Nyh) * Nx, Nx, x0);
+  mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return mk<T>(mv[i].x * z[i].x, mv[i].y * z[i].y); });
+  half_store<T, NT, LD, LGM, G::LGC>(s, out + sl * (size_t)mixed_rows(G::Nyh) * Nx, tw, x0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -105,20 +105,6 @@ template <typename T> __device__ __forceinline__ cx<T> pmul(cx<T> a, cx<T> b) { 
 // stages of one butterfly per lane; no barrier between the stages, every thread busy -- the cooperative radix-16 stages had 256
 // butterflies for 512 threads).  PairMap gives the pair ownership: split tiles own (jj, jj + M/2) of R/2 columns, the others the
 // interleaved pairs tid + i*NT as before.
-#ifndef CMBL_COL_SPLIT
-#define CMBL_COL_SPLIT 1
-#endif
-template <int R, int NT, int LGM> struct PairMap {
-  static constexpr int M = 1 << LGM, MH = M >> 1, C = (R * NT) >> LGM;
-  static constexpr bool split = CMBL_COL_SPLIT && (R % 2 == 0) && (NT % MH == 0) && (NT % C == 0) && (NT / C == 64 || NT / C == 128) && M >= 32;
-  static constexpr int XLG = LGM + 1 >= 11 ? 4 : 3;            // sub-stage radix of the split N-point transforms
-  __device__ static __forceinline__ int e(int i) {
-    if constexpr (split) {
-      const int g = threadIdx.x / MH, q = threadIdx.x % MH;
-      return ((g * (R / 2) + (i >> 1)) << LGM) + q + MH * (i & 1);
-    } else return threadIdx.x + i * NT;
-  }
-};
 // samples (x + i y)[a], a = 2jj, 2jj+1 and a + M from the two halves u (slots a) and v (slots a + M) of an N-point column
 template <typename T>
 __device__ __forceinline__ void read_pair_dit(const cx<T>* col, int jj, int M, const cx<T>* tw, T scale, cx<T>& x0, cx<T>& y0, cx<T>& x1, cx<T>& y1) {
@@ -250,15 +236,8 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   }
   if (a.rk.last) return;
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
-    s[c * LD + pad(jj)] = fn[i];
-  }
-  __syncthreads();
-  fft_dif<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
-  r2c_post<T, NT, LD, LGM>(s, C, tw);
-  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0);
+  mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
+  half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,9 +265,9 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   constexpr int NyhP = mixed_rows(Nyh);
   const size_t moff = sl * (size_t)NyhP * Nx;
   TwStage<T, NT, 2 * M> twr;
-  TileStage<T, NT, LGM, LGC> tl;
+  HalfStage<T, NT, LGM, LGC> tl;
   twr.issue(a.twY);
-  tl.issue(a.H + moff, Nx, x0);
+  tl.issue(a.H + moff, a.twY, x0);
   const size_t pbase = ((size_t)bphi * Nx + x0) * M;
   using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R];
@@ -300,14 +279,8 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   twr.commit(tw);
   tl.template commit<LD>(s);
   __syncthreads();
-  c2r_pre<T, NT, LD, LGM>(s, C, tw);
-  fft_dit<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
   cx<T> yv[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
-    yv[i] = invNy * s[c * LD + pad(jj)];
-  }
+  mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, yv);
   __syncthreads();
   npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], yv[i]); y = pmul(py[i], yv[i]); });
   cx<T>* Wx = a.Wx + moff; cx<T>* Wy = a.Wy + moff;
@@ -460,7 +433,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   // the delta-f tile fly during the first transform; the RK state during the second.
   TwStage<T, NT, 2 * M> twr;
   PairStage<T, NT, LGN, LGC> ps;
-  TileStage<T, NT, LGM, LGC> th;
+  HalfStage<T, NT, LGM, LGC> th;
   twr.issue(a.twY);
   ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, x0);
   twr.commit(tw);
@@ -469,7 +442,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   cx<T> px[R], py[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + PM::e(i), a.rk.t, px[i], py[i]);
-  th.issue(d.H + moff, Nx, x0);
+  th.issue(d.H + moff, a.twY, x0);
   __syncthreads();
   CMBL_STAMP(1);
   // (d/dx f, d/dy f) from one N-point inverse transform
@@ -491,14 +464,14 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   }
   __syncthreads();
   CMBL_STAMP(4);
-  c2r_pre<T, NT, LD, LGM>(s, C, tw);
-  fft_dit<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
+  cx<T> lz[R];
+  mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, lz);
   CMBL_STAMP(5);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+    const int e = PM::e(i);
     cx<T> y0 = fn[i], acc = ldf[i];
-    ldf[i] = invNy * s[c * LD + pad(jj)];
+    ldf[i] = lz[i];
     reinterpret_cast<cx<T>*>(d.w1p)[mbase + e] = pmul(ldf[i], dx[i]);
     reinterpret_cast<cx<T>*>(d.w2p)[mbase + e] = pmul(ldf[i], dy[i]);
     const cx<T> kv = pmul(px[i], dx[i]) + pmul(py[i], dy[i]);
@@ -522,14 +495,9 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   if (a.rk.last) { CMBL_WSTAMP(15); return; }
   __syncthreads();
   // next-stage f : rfft_y
-#pragma unroll
-  for (int i = 0; i < R; ++i) { const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1); s[c * LD + pad(jj)] = fn[i]; }
-  __syncthreads();
-  CMBL_STAMP(10);
-  fft_dif<T, NT, LD, LGM, LGN, CMBL_YLGM>(s, C, tw);
-  r2c_post<T, NT, LD, LGM>(s, C, tw);
+  mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
   CMBL_STAMP(11);
-  tile_store_mixed<T, NT, LD, LGM, LGC>(s, a.Anext + moff, Nx, x0);
+  half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);
   CMBL_STAMP(12);
   CMBL_WSTAMP(15);
 }

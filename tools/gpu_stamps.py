@@ -20,8 +20,8 @@ lib.cmbl_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.cmbl_debug_stamps(buf, nb * 16) == 0
 st = np.array(buf[:], dtype=np.uint64).reshape(nb, 16).astype(np.int64)
 rel = st[:, :13] - st[:, :1]
-names = ["start", "loads committed (pair tile)", "N-pt inverse (dx,dy)", "read pair", "commit H tile", "M-pt inverse (L df)", "pointwise + RK + stores", "write pair",
-         "N-pt forward", "pair split + Wx,Wy stores", "write fn", "M-pt forward + r2c_post", "Anext store"]
+names = ["start", "loads committed (pair tile)", "N-pt inverse + read (dx,dy)", "barrier", "commit H tile", "M-pt inverse + read (L df)",
+         "pointwise + RK + stores", "-", "N-pt write + forward", "pair split + Wx,Wy stores", "-", "M-pt write + forward", "Anext store"]
 prev = 0
 for i in range(13):
     m = rel[:, i]
