@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -11,6 +12,7 @@
 #include "kernels_fft.hpp"
 #include "kernels_pointwise.hpp"
 #include "kernels_flow.hpp"
+#include "kernels_generic.hpp"
 
 namespace cmbl {
 
@@ -31,9 +33,10 @@ inline void raise_lds_limit(const void* fn, size_t bytes) {
 }
 // kernel classes for the optional per-launch event timing (cmbl_prof_*)
 enum KernelId { K_LAYOUT = 0, K_Y_R2C, K_Y_C2R, K_X_FFT, K_X_GRAD, K_FLOW_Y, K_ADJ_Y, K_ADJ_X, K_DELTA_Y, K_DELTA_ROWS, K_DPHI_Y, K_DPHI_X,
-                K_GRADHESS, K_HARM, K_LINCOMB, K_MASK, K_REDUCE, K_COUNT };
+                K_GRADHESS, K_HARM, K_LINCOMB, K_MASK, K_REDUCE, K_GEN_DFT, K_GEN_POINT, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_cols", "delta_rows",
-                                                  "dphi_reduce", "dphi_combine", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce"};
+                                                  "dphi_reduce", "dphi_combine", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce",
+                                                  "generic_dft", "generic_pointwise"};
 
 #define CMBL_LAUNCH_NT(ctxp, kid, nthreads, kernel, grid, lds, stream, ...)            \
   do {                                                                                \
@@ -54,11 +57,16 @@ static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x
 #ifndef CMBL_ROW_LIST
 #define CMBL_ROW_LIST(X) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 #endif
+// convolution lengths 2^lg of the any-size transforms (kernels_generic.hpp)
+#ifndef CMBL_GEN_LIST
+#define CMBL_GEN_LIST(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#endif
 
 inline int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
 
 struct CtxBase {
   int Ny = 0, Nx = 0, Nyh = 0, M = 0, lgM = 0, lgNx = 0, dtype = 0, device = 0, num_cus = 256;
+  bool generic = false;                   // any-size path (kernels_generic.hpp): Ny or Nx not a power of two (or < 32)
   int sum_mode = 1;                       // SUM_FLOAT64 (see kernels_pointwise.hpp; the reference's default is SUM_WORKING)
   double theta = 0;
   hipStream_t stream = nullptr;
@@ -112,9 +120,10 @@ struct Ctx : CtxBase {
 
   Ctx(int Ny_, int Nx_, double theta_, int device_, void* stream_) {
     Ny = Ny_; Nx = Nx_; theta = theta_; device = device_; dtype = sizeof(T) == 4 ? 0 : 1;
-    CMBL_REQUIRE(ispow2(Ny) && ispow2(Nx) && Ny >= 32 && Nx >= 32 && Ny <= 4096 && Nx <= 4096, ERR_SHAPE,
-                 "Ny and Nx must be powers of two in [32, 4096]");
+    CMBL_REQUIRE(Ny >= 2 && Nx >= 2 && Ny <= 4096 && Nx <= 4096, ERR_SHAPE, "Ny and Nx must lie in [2, 4096]");
     CMBL_REQUIRE(theta > 0, ERR_ARG, "theta_pix must be positive");
+    // powers of two >= 32 run the fused kernels; everything else (and everything, with CMBL_FORCE_GENERIC=1) the any-size path
+    generic = !(ispow2(Ny) && ispow2(Nx) && Ny >= 32 && Nx >= 32) || env_int("CMBL_FORCE_GENERIC", 0) != 0;
     Nyh = Ny / 2 + 1; M = Ny / 2; lgM = ilog2(M); lgNx = ilog2(Nx);
     CMBL_HIP(hipSetDevice(device));
     { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) num_cus = n; }
@@ -133,7 +142,7 @@ struct Ctx : CtxBase {
     std::vector<T> lx(Nx), lyv(Nyh), lamv(Nyh, (T)2);
     for (int i = 0; i < Nx; ++i) { int k = i < (Nx + 1) / 2 ? i : i - Nx; lx[i] = (T)k * dlx; }      // ifftshift(-N÷2:(N-1)÷2)
     for (int i = 0; i < Nyh; ++i) { int k = i < (Ny + 1) / 2 ? i : i - Ny; lyv[i] = (T)k * dly; }     // last entry negative
-    lamv[0] = 1; lamv[Nyh - 1] = 1;                                                                    // even Ny (util_fft.jl:137-143)
+    lamv[0] = 1; if (Ny % 2 == 0) lamv[Nyh - 1] = 1;                                                    // util_fft.jl:137-143
     std::vector<T> s2((size_t)Nx * Nyh), c2((size_t)Nx * Nyh), lm((size_t)Nx * Nyh);
     for (int x = 0; x < Nx; ++x)
       for (int k = 0; k < Nyh; ++k) {
@@ -143,16 +152,18 @@ struct Ctx : CtxBase {
         lm[(size_t)x * Nyh + k] = std::sqrt(lx[x] * lx[x] + lyv[k] * lyv[k]);
       }
     // sin2ϕ[end, end:-1:(Nx÷2+2)] .= sin2ϕ[end, 2:Nx÷2]  (1-based; proj_lambert.jl:69-71)
-    for (int i = 0; i < Nx / 2 - 1; ++i) s2[(size_t)(Nx - 1 - i) * Nyh + (Nyh - 1)] = s2[(size_t)(1 + i) * Nyh + (Nyh - 1)];
+    if (Ny % 2 == 0) for (int i = 0; i < Nx / 2 - 1; ++i) s2[(size_t)(Nx - 1 - i) * Nyh + (Nyh - 1)] = s2[(size_t)(1 + i) * Nyh + (Nyh - 1)];
     h_lx.assign(lx.begin(), lx.end()); h_ly.assign(lyv.begin(), lyv.end()); h_lam.assign(lamv.begin(), lamv.end());
     h_sin2.assign(s2.begin(), s2.end()); h_cos2.assign(c2.begin(), c2.end()); h_lmag.assign(lm.begin(), lm.end());
     // internal tables
+    // x slot i of the F layout holds frequency index xfreq(i): bit-reversed on the fused path, natural on the any-size path
+    auto xfreq = [&](int i) { if (generic) return (unsigned)i; unsigned r = 0; for (int b = 0; b < lgNx; ++b) r |= ((i >> b) & 1u) << (lgNx - 1 - b); return r; };
     std::vector<T> lxr(Nx);
-    for (int i = 0; i < Nx; ++i) { unsigned r = 0; for (int b = 0; b < lgNx; ++b) r |= ((i >> b) & 1u) << (lgNx - 1 - b); lxr[i] = lx[r]; }
+    for (int i = 0; i < Nx; ++i) lxr[i] = lx[xfreq(i)];
     std::vector<T> s2F((size_t)Nx * Nyh), c2F((size_t)Nx * Nyh);
     for (int k = 0; k < Nyh; ++k)
       for (int i = 0; i < Nx; ++i) {
-        unsigned r = 0; for (int b = 0; b < lgNx; ++b) r |= ((i >> b) & 1u) << (lgNx - 1 - b);
+        const unsigned r = xfreq(i);
         s2F[(size_t)k * Nx + i] = s2[(size_t)r * Nyh + k];
         c2F[(size_t)k * Nx + i] = c2[(size_t)r * Nyh + k];
       }
@@ -162,6 +173,81 @@ struct Ctx : CtxBase {
     upload(twY, ty); upload(twX, tx); upload(lx_r, lxr); upload(ly, lyv); upload(lam, lamv); upload(cos2F, c2F); upload(sin2F, s2F);
     red_part.ensure(sizeof(double) * RED_BLOCKS * 64 * 2);
     red_out.ensure(sizeof(double) * 64);
+    if (generic) { build_axis(genY, Ny); build_axis(genX, Nx); }
+  }
+
+  // ---- any-size transforms (kernels_generic.hpp) -------------------------------------------------
+  struct GenAxis { int N = 0, lgL = 0; DevBuf chirp, bhat, tw; };
+  GenAxis genY, genX;
+  static void host_fft(std::vector<std::complex<double>>& v) {             // in-place radix-2, e^{-i}; table set-up only
+    const size_t n = v.size();
+    for (size_t i = 1, j = 0; i < n; ++i) { size_t bit = n >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) std::swap(v[i], v[j]); }
+    for (size_t len = 2; len <= n; len <<= 1) {
+      const double ang = -2.0 * M_PI / (double)len;
+      for (size_t i = 0; i < n; i += len)
+        for (size_t k = 0; k < len / 2; ++k) {
+          const std::complex<double> w(std::cos(ang * (double)k), std::sin(ang * (double)k)), u = v[i + k], t = v[i + k + len / 2] * w;
+          v[i + k] = u + t; v[i + k + len / 2] = u - t;
+        }
+    }
+  }
+  void build_axis(GenAxis& ax, int N) {
+    ax.N = N; ax.lgL = std::max(3, ilog2(2 * N - 1));
+    const int L = 1 << ax.lgL;
+    std::vector<std::complex<double>> w(N), b(L, 0.0);
+    for (int n = 0; n < N; ++n) {                                           // exp(-i pi n^2 / N), the phase reduced exactly
+      const double a = -M_PI * (double)(((long)n * n) % (2L * N)) / (double)N;
+      w[n] = {std::cos(a), std::sin(a)};
+    }
+    b[0] = std::conj(w[0]);
+    for (int n = 1; n < N; ++n) b[n] = b[L - n] = std::conj(w[n]);
+    host_fft(b);
+    std::vector<cx<T>> wc(N), bh(L), tw(L);
+    for (int n = 0; n < N; ++n) wc[n] = mk<T>((T)w[n].real(), (T)w[n].imag());
+    for (int s = 0; s < L; ++s) {                                           // slot s of a DIF output holds frequency brev(s)
+      unsigned r = 0; for (int bb = 0; bb < ax.lgL; ++bb) r |= ((s >> bb) & 1u) << (ax.lgL - 1 - bb);
+      bh[s] = mk<T>((T)(b[r].real() / L), (T)(b[r].imag() / L));
+    }
+    for (int k = 0; k < L; ++k) { const double a = -2.0 * M_PI * k / L; tw[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
+    upload(ax.chirp, wc); upload(ax.bhat, bh); upload(ax.tw, tw);
+  }
+  void gen_dft(const GenAxis& ax, GenDft<T> a, long slices) {
+    const int L = 1 << ax.lgL;
+    a.chirp = ax.chirp.template as<cx<T>>(); a.bhat = ax.bhat.template as<cx<T>>(); a.tw = ax.tw.template as<cx<T>>(); a.N = ax.N;
+    a.S = std::max(1, std::min(8, 2048 / L));
+    const size_t lds = (size_t)a.S * tile_ld(L) * sizeof(cx<T>);
+    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
+    bool done = false;
+#define CMBL_X(lg) if (!done && ax.lgL == lg) { CMBL_LAUNCH(this, K_GEN_DFT, (k_gen_dft<T, lg>), grid, lds, stream, a); done = true; }
+    CMBL_GEN_LIST(CMBL_X)
+#undef CMBL_X
+    if (!done) fail(ERR_SHAPE, "unsupported transform length");
+  }
+  void gen_rfft2(const T* map, cx<T>* F, long slices) {
+    cx<T>* tmp = mixed_scratch(slices);
+    GenDft<T> a{};                                                          // y: map [x][y] -> tmp [ky][x]
+    a.in = map; a.out = tmp; a.in_real = 1; a.nin = Ny; a.nout = Nyh; a.nseq = Nx; a.scale = 1;
+    a.in_seq = Ny; a.in_elem = 1; a.in_slice = npix(); a.out_seq = 1; a.out_elem = Nx; a.out_slice = plane();
+    gen_dft(genY, a, slices);
+    GenDft<T> b{};                                                          // x: tmp [ky][x] -> F [ky][kx]
+    b.in = tmp; b.out = F; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1;
+    b.in_seq = Nx; b.in_elem = 1; b.in_slice = plane(); b.out_seq = Nx; b.out_elem = 1; b.out_slice = plane();
+    gen_dft(genX, b, slices);
+  }
+  void gen_irfft2(const cx<T>* F, T* map, long slices) {
+    cx<T>* tmp = mixed_scratch(slices);
+    GenDft<T> b{};                                                          // x (inverse): F [ky][kx] -> tmp [ky][x]
+    b.in = F; b.out = tmp; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1; b.inverse = 1;
+    b.in_seq = Nx; b.in_elem = 1; b.in_slice = plane(); b.out_seq = Nx; b.out_elem = 1; b.out_slice = plane();
+    gen_dft(genX, b, slices);
+    GenDft<T> a{};                                                          // y (c2r): tmp [ky][x] -> map [x][y]
+    a.in = tmp; a.out = map; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx;
+    a.scale = (T)(1.0 / ((double)Ny * Nx));
+    a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
+    gen_dft(genY, a, slices);
+  }
+  template <typename V> void transpose(const V* in, V* out, int R, int C, long slices) {
+    CMBL_LAUNCH(this, K_LAYOUT, (k_transpose<V>), dim3((C + 31) / 32, (R + 31) / 32, (unsigned)slices), 0, stream, in, out, R, C);
   }
   template <typename V> void upload(DevBuf& b, const std::vector<V>& v) {
     b.ensure(v.size() * sizeof(V));
@@ -225,15 +311,19 @@ struct Ctx : CtxBase {
 
   // ---- layout / transform primitives (all on `stream`) -----------------------------------------
   void ref2F(const cx<T>* in, cx<T>* out, long slices) {
+    if (generic) return transpose(in, out, Nx, Nyh, slices);
     CMBL_LAUNCH(this, K_LAYOUT, (k_ref2F<cx<T>>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
   }
   void F2ref(const cx<T>* in, cx<T>* out, long slices) {
+    if (generic) return transpose(in, out, Nyh, Nx, slices);
     CMBL_LAUNCH(this, K_LAYOUT, (k_F2ref<cx<T>>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
   }
   void ref2F_real(const T* in, T* out, long slices) {
+    if (generic) return transpose(in, out, Nx, Nyh, slices);
     CMBL_LAUNCH(this, K_LAYOUT, (k_ref2F<T>), dim3(Nx / 32, (Nyh + 31) / 32, (unsigned)slices), 0, stream, in, out, Nx, lgNx, Nyh);
   }
   void y_r2c(const T* map, cx<T>* mixed, long slices) {
+    CMBL_REQUIRE(!generic, ERR_STATE, "fused column pass called on the any-size path");
     const TileY t = tileY(slices, false);
     dispatch_col(t, [&](auto lgm, auto r, auto nt) {
       constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
@@ -241,6 +331,7 @@ struct Ctx : CtxBase {
     });
   }
   void y_c2r(const cx<T>* mixed, T* map, long slices) {
+    CMBL_REQUIRE(!generic, ERR_STATE, "fused column pass called on the any-size path");
     const TileY t = tileY(slices, false);
     dispatch_col(t, [&](auto lgm, auto r, auto nt) {
       constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
@@ -249,6 +340,7 @@ struct Ctx : CtxBase {
   }
   // mixed -> (map x mask) -> mixed, for the pixel-mask sandwich (in place allowed)
   void y_mask(const cx<T>* in, cx<T>* out, const T* mask, long slices) {
+    CMBL_REQUIRE(!generic, ERR_STATE, "fused column pass called on the any-size path");
     const TileY t = tileY(slices, false);
     dispatch_col(t, [&](auto lgm, auto r, auto nt) {
       constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
@@ -259,6 +351,7 @@ struct Ctx : CtxBase {
   template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices, hipStream_t st = nullptr) {
     if (!st) st = stream;
     CMBL_REQUIRE(in != out, ERR_ARG, "x pass cannot run in place (tiled mixed layout on one side)");
+    CMBL_REQUIRE(!generic, ERR_STATE, "fused row pass called on the any-size path");
     dispatch_row([&](auto lgnx) {
       constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 1);
       if constexpr (RPW > 0) {
@@ -270,9 +363,9 @@ struct Ctx : CtxBase {
   // map -> F  (m_rfft, src/util_fft.jl:20)
   // (the x pass reads the tiled mixed layout and writes F rows, or the reverse: it cannot run in place -- `xtmp` holds the mixed side)
   cx<T>* mixed_scratch(long slices) { xtmp.ensure(sizeof(cx<T>) * slices * mplane()); return xtmp.as<cx<T>>(); }
-  void rfft2_F(const T* map, cx<T>* F, long slices) { cx<T>* m = mixed_scratch(slices); y_r2c(map, m, slices); x_pass<0>(m, F, slices); }
+  void rfft2_F(const T* map, cx<T>* F, long slices) { if (generic) return gen_rfft2(map, F, slices); cx<T>* m = mixed_scratch(slices); y_r2c(map, m, slices); x_pass<0>(m, F, slices); }
   // F -> map without a caller-provided scratch (F is left intact)
-  void F_to_map(const cx<T>* F, T* map, long slices) { cx<T>* m = mixed_scratch(slices); x_pass<1>(F, m, slices); y_c2r(m, map, slices); }
+  void F_to_map(const cx<T>* F, T* map, long slices) { if (generic) return gen_irfft2(F, map, slices); cx<T>* m = mixed_scratch(slices); x_pass<1>(F, m, slices); y_c2r(m, map, slices); }
 
   // harmonic-operator application (see k_harm_apply)
   void harm(const cx<T>* in, cx<T>* out, int P, int B, int kind, const T* const* d, bool transpose, bool in_qu, bool out_qu,
@@ -328,7 +421,7 @@ struct Ctx : CtxBase {
     CMBL_HIP(hipStreamSynchronize(stream));
   }
   void dot_F_dev(const cx<T>* a, const cx<T>* b, int P, int B, double* out_dev) {
-    reduce_dev(TermDotF<T>{a, b, lam.as<T>(), (long)P * plane(), lgNx, Nyh}, (long)P * plane(), B, 1.0 / ((double)Ny * Nx), out_dev);
+    reduce_dev(TermDotF<T>{a, b, lam.as<T>(), (long)P * plane(), Nx, Nyh}, (long)P * plane(), B, 1.0 / ((double)Ny * Nx), out_dev);
   }
   void dot_F(const cx<T>* a, const cx<T>* b, int P, int B, double* out_host) {
     dot_F_dev(a, b, P, B, red_out.as<double>()); fetch(out_host, red_out.as<double>(), B);
@@ -339,16 +432,16 @@ struct Ctx : CtxBase {
   }
   // logdet of real operator planes in F layout (all planes of one operator: one "batch slot")
   void logdet_F(const T* d, int nplanes, double* out_host) {
-    reduce_dev(TermLogdetF<T>{d, lam.as<T>(), (long)nplanes * plane(), lgNx, Nyh}, (long)nplanes * plane(), 1, 1.0, red_out.as<double>());
+    reduce_dev(TermLogdetF<T>{d, lam.as<T>(), (long)nplanes * plane(), Nx, Nyh}, (long)nplanes * plane(), 1, 1.0, red_out.as<double>());
     fetch(out_host, red_out.as<double>(), 1);
   }
   // logdet / tr of Diagonal(field): complex Fourier field in F layout, or real map
   void logdet_Fc(const cx<T>* d, int P, int B, double* out_host) {
-    reduce_dev(TermLogdetFc<T>{d, lam.as<T>(), (long)P * plane(), lgNx, Nyh}, (long)P * plane(), B, 1.0, red_out.as<double>());
+    reduce_dev(TermLogdetFc<T>{d, lam.as<T>(), (long)P * plane(), Nx, Nyh}, (long)P * plane(), B, 1.0, red_out.as<double>());
     fetch(out_host, red_out.as<double>(), B);
   }
   void tr_Fc(const cx<T>* d, int P, int B, double* out_host) {
-    reduce_dev(TermTrFc<T>{d, lam.as<T>(), (long)P * plane(), lgNx, Nyh}, (long)P * plane(), B, 1.0, red_out.as<double>());
+    reduce_dev(TermTrFc<T>{d, lam.as<T>(), (long)P * plane(), Nx, Nyh}, (long)P * plane(), B, 1.0, red_out.as<double>());
     fetch(out_host, red_out.as<double>(), B);
   }
   void tr_map(const T* d, int P, int B, double* out_host) {
@@ -369,7 +462,7 @@ struct Ctx : CtxBase {
     tmpA.ensure(sizeof(cx<T>) * B * plane());
     cx<T>* F = tmpA.as<cx<T>>();
     ref2F(in_ref, F, B);
-    CMBL_LAUNCH(this, K_HARM, (k_qe_leg<T>), dim3((unsigned)((plane() + NTP - 1) / NTP)), 0, stream, F, F, lx_r.as<T>(), ly.as<T>(), lgNx, plane(), B, n, p1, p2, 0);
+    CMBL_LAUNCH(this, K_HARM, (k_qe_leg<T>), dim3((unsigned)((plane() + NTP - 1) / NTP)), 0, stream, F, F, lx_r.as<T>(), ly.as<T>(), Nx, plane(), B, n, p1, p2, 0);
     F_to_map(F, out_map, B);
   }
   // (i lx)^p1 (i ly)^p2 * rfft2(map)  (or its modulus, stored in the real part) -> Fourier reference layout
@@ -377,7 +470,7 @@ struct Ctx : CtxBase {
     tmpA.ensure(sizeof(cx<T>) * B * plane());
     cx<T>* F = tmpA.as<cx<T>>();
     rfft2_F(in_map, F, B);
-    CMBL_LAUNCH(this, K_HARM, (k_qe_leg<T>), dim3((unsigned)((plane() + NTP - 1) / NTP)), 0, stream, F, F, lx_r.as<T>(), ly.as<T>(), lgNx, plane(), B, 0, p1, p2, take_abs ? 1 : 0);
+    CMBL_LAUNCH(this, K_HARM, (k_qe_leg<T>), dim3((unsigned)((plane() + NTP - 1) / NTP)), 0, stream, F, F, lx_r.as<T>(), ly.as<T>(), Nx, plane(), B, 0, p1, p2, take_abs ? 1 : 0);
     F2ref(F, out_ref, B);
   }
   void map_fma(T* out, const T* a, const T* b, double scale, bool accumulate, long n) {
@@ -508,7 +601,7 @@ struct Flow {
     phimaps.ensure(sizeof(T) * 5 * nb * c->npix());
     // multipliers: out[comp][b][plane]
     CMBL_LAUNCH(c, K_GRADHESS, (k_gradhess_mult<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
-                c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
+                c->ly.template as<T>(), c->Nx, c->Nyh, nb);
     c->F_to_map(gh.as<cx<T>>(), phimaps.as<T>(), 5L * nb);
     // p(t) at the 2n+1 stage times (the reference caches p and M^-1, src/lenseflow.jl:45-46,88-90): 2(2n+1) maps per phi slot,
     // 120 MB at 1024^2 fp32 n = 7.  M^-1(t), needed only by the delta-phi kernel, is still formed on the fly.
@@ -532,7 +625,7 @@ struct Flow {
     const long pl = c->plane();
     gh.ensure(sizeof(cx<T>) * 5 * nb * pl);
     CMBL_LAUNCH(c, K_GRADHESS, (k_gradhess_mult<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, phi_F, gh.as<cx<T>>(), c->lx_r.template as<T>(),
-                c->ly.template as<T>(), c->lgNx, c->Nyh, nb);
+                c->ly.template as<T>(), c->Nx, c->Nyh, nb);
     c->F_to_map(gh.as<cx<T>>(), maps, 5L * nb);
   }
   // get_max_lensing_step (src/lenseflow.jl:242-256); does not touch the flow's own phi cache
@@ -566,9 +659,105 @@ struct Flow {
     CMBL_REQUIRE(Bphi == 1 || Bphi == B, ERR_SHAPE, "nbatch of phi must be 1 or equal to nbatch of f");
   }
 
+
+  // ---- any-size path: the reference's pass structure on k_gen_dft + pointwise kernels (kernels_generic.hpp) ----------------------
+  DevBuf gF, gFx, gFy, gmx, gmy, gms, gYs;
+  dim3 pgrid(long n, long slices) const { return dim3((unsigned)std::min<long>((n + NTP - 1) / NTP, 4096), (unsigned)slices); }
+  dim3 fgrid(long slices) const { return dim3((unsigned)((c->plane() + NTP - 1) / NTP), (unsigned)slices); }
+  // (gx, gy) = grad of the map `ys`  (rfft2, i l multiplies, two irfft2)
+  void gen_grad(const T* ys, long slices) {
+    const long pl = c->plane(), np = c->npix();
+    gF.ensure(sizeof(cx<T>) * slices * pl); gFx.ensure(sizeof(cx<T>) * slices * pl); gFy.ensure(sizeof(cx<T>) * slices * pl);
+    gmx.ensure(sizeof(T) * slices * np); gmy.ensure(sizeof(T) * slices * np);
+    c->rfft2_F(ys, gF.as<cx<T>>(), slices);
+    CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_lmul2<T>), fgrid(slices), 0, c->stream, gF.as<cx<T>>(), gFx.as<cx<T>>(), gFy.as<cx<T>>(), c->lx_r.template as<T>(),
+                c->ly.template as<T>(), c->Nx, pl);
+    c->F_to_map(gFx.as<cx<T>>(), gmx.as<T>(), slices); c->F_to_map(gFy.as<cx<T>>(), gmy.as<T>(), slices);
+  }
+  // d(Fourier state)/dt from the maps (Wx, Wy): two rfft2 + the RK update with k = i lx Fx + i ly Fy
+  void gen_adj_update(const T* Wx_, const T* Wy_, cx<T>* Y0, cx<T>* Yacc_, cx<T>* Ys, const RKCoef<T>& rk, long slices) {
+    const long pl = c->plane();
+    gFx.ensure(sizeof(cx<T>) * slices * pl); gFy.ensure(sizeof(cx<T>) * slices * pl);
+    c->rfft2_F(Wx_, gFx.as<cx<T>>(), slices); c->rfft2_F(Wy_, gFy.as<cx<T>>(), slices);
+    CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFx.as<cx<T>>(), gFy.as<cx<T>>(), c->lx_r.template as<T>(), c->ly.template as<T>(),
+                c->Nx, Y0, Yacc_, Ys, rk, pl);
+  }
+  void gen_flow_map(const T* in, T* out, int P, int B, bool inverse) {
+    const long slices = (long)P * B, np = c->npix();
+    acc.ensure(sizeof(T) * slices * np); gms.ensure(sizeof(T) * slices * np);
+    if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
+    CMBL_HIP(hipMemcpyAsync(gms.p, out, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
+    const double t0 = inverse ? 1.0 : 0.0, h = (inverse ? -1.0 : 1.0) / n;
+    for (int step = 0; step < n; ++step)
+      for (int stage = 1; stage <= 4; ++stage) {
+        const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
+        gen_grad(gms.as<T>(), slices);
+        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_vel_rk<T>), pgrid(np, slices), 0, c->stream, gmx.as<T>(), gmy.as<T>(), ph(rk.t), out, acc.as<T>(), gms.as<T>(), rk, np, P);
+      }
+  }
+  void gen_flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse) {
+    const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    Yacc.ensure(sizeof(cx<T>) * slices * pl); gYs.ensure(sizeof(cx<T>) * slices * pl);
+    gms.ensure(sizeof(T) * slices * np); gmx.ensure(sizeof(T) * slices * np); gmy.ensure(sizeof(T) * slices * np);
+    if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
+    CMBL_HIP(hipMemcpyAsync(gYs.p, out, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
+    const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
+    for (int step = 0; step < n; ++step)
+      for (int stage = 1; stage <= 4; ++stage) {
+        const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
+        c->F_to_map(gYs.as<cx<T>>(), gms.as<T>(), slices);
+        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_pmul<T>), pgrid(np, slices), 0, c->stream, gms.as<T>(), ph(rk.t), rk.t, gmx.as<T>(), gmy.as<T>(), np, P);
+        gen_adj_update(gmx.as<T>(), gmy.as<T>(), out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
+      }
+  }
+  DevBuf gLdf, gWx, gWy;
+  void gen_flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
+    const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+    const int nst = 4 * n;
+    acc.ensure(sizeof(T) * slices * np); gms.ensure(sizeof(T) * slices * np); gLdf.ensure(sizeof(T) * slices * np);
+    gWx.ensure(sizeof(T) * slices * np); gWy.ensure(sizeof(T) * slices * np);
+    Yacc.ensure(sizeof(cx<T>) * slices * pl); gYs.ensure(sizeof(cx<T>) * slices * pl);
+    Wst.ensure(sizeof(T) * (size_t)nst * 2 * slices * np);
+    U5.ensure(sizeof(T) * 5 * B * np); F5.ensure(sizeof(cx<T>) * 5 * B * pl); tcbuf.ensure(sizeof(T) * 2 * nst);
+    CMBL_HIP(hipMemcpyAsync(gms.p, f, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
+    CMBL_HIP(hipMemcpyAsync(gYs.p, df, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
+    const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
+    tc_host.resize(2 * (size_t)nst);
+    int it = 0;
+    for (int step = 0; step < n; ++step)
+      for (int stage = 1; stage <= 4; ++stage, ++it) {
+        const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
+        tc_host[2 * it] = rk.t;
+        tc_host[2 * it + 1] = (T)((stage == 1 || stage == 4 ? 1.0 : 2.0) * h / 6);
+        c->F_to_map(gYs.as<cx<T>>(), gLdf.as<T>(), slices);                   // L(df)
+        gen_grad(gms.as<T>(), slices);                                       // grad f -> (gmx, gmy)
+        T* w1p = Wst.as<T>() + (size_t)(2 * it) * slices * np;
+        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_delta<T>), pgrid(np, slices), 0, c->stream, gLdf.as<T>(), gmx.as<T>(), gmy.as<T>(), ph(rk.t), gWx.as<T>(), gWy.as<T>(),
+                    w1p, w1p + (size_t)slices * np, f, acc.as<T>(), gms.as<T>(), rk, np, P);
+        gen_adj_update(gWx.as<T>(), gWy.as<T>(), df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
+      }
+    dphi_finish(dphi, P, B, nst, alias_quirk);
+  }
+  // delta-phi: quadrature over the stored stages, five real transforms, the l-multipliers (shared by both paths)
+  void dphi_finish(cx<T>* dphi, int P, int B, int nst, bool alias_quirk) {
+    const long pl = c->plane(), np = c->npix();
+    CMBL_HIP(hipMemcpyAsync(tcbuf.p, tc_host.data(), sizeof(T) * 2 * nst, hipMemcpyHostToDevice, c->stream));
+    constexpr int V = 16 / (int)sizeof(T);
+    if (np % V == 0)
+      CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T, V>), dim3((unsigned)std::min<long>((np / V + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
+                  tcbuf.as<T>(), U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
+    else
+      CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T, 1>), dim3((unsigned)std::min<long>((np + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
+                  tcbuf.as<T>(), U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
+    c->rfft2_F(U5.as<T>(), F5.as<cx<T>>(), 5L * B);
+    CMBL_LAUNCH(c, K_DPHI_X, (k_dphi_combine<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, F5.as<cx<T>>(), dphi, c->lx_r.template as<T>(),
+                c->ly.template as<T>(), c->Nx, pl, B);
+  }
+
   // L*f (inverse=false) or L\f (inverse=true) on maps; out may alias in
   void flow_map(const T* in, T* out, int P, int B, bool inverse) {
     check_ready(B);
+    if (c->generic) return gen_flow_map(in, out, P, B, inverse);
     const long slices = (long)P * B, pl = c->mplane(), np = c->npix();          // A, Gx: mixed layout
     A.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
     acc.ensure(sizeof(T) * slices * np);
@@ -606,6 +795,7 @@ struct Flow {
   // L'*g (inverse=false, t 1->0) or L'\g (inverse=true, t 0->1); F layout, QU-Fourier basis; out may alias in
   void flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse) {
     check_ready(B);
+    if (c->generic) return gen_flow_adj_F(in, out, P, B, inverse);
     const long slices = (long)P * B, pl = c->plane(), mpl = c->mplane();
     H.ensure(sizeof(cx<T>) * slices * mpl); Wx.ensure(sizeof(cx<T>) * slices * mpl); Wy.ensure(sizeof(cx<T>) * slices * mpl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
@@ -650,6 +840,7 @@ struct Flow {
   // per-stage buffer and delta-phi -- a pure quadrature over the stages -- is formed once at the end (k_dphi_reduce, 5 rffts, combine).
   void flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
     check_ready(B);
+    if (c->generic) return gen_flow_delta(f, df, dphi, P, B, forward_primal, alias_quirk);
     const long slices = (long)P * B, pl = c->plane(), mpl = c->mplane(), np = c->npix();
     const int nst = 4 * n;
     A.ensure(sizeof(cx<T>) * slices * mpl); A2.ensure(sizeof(cx<T>) * slices * mpl); Gx.ensure(sizeof(cx<T>) * slices * mpl);
@@ -705,13 +896,7 @@ struct Flow {
         std::swap(a_cur, a_nxt);
       }
     join(K);
-    // delta-phi: quadrature over the stages, then five real transforms and the l-multipliers
-    CMBL_HIP(hipMemcpyAsync(tcbuf.p, tc_host.data(), sizeof(T) * 2 * nst, hipMemcpyHostToDevice, c->stream));
-    CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T>), dim3((unsigned)std::min<long>((np / (16 / (long)sizeof(T)) + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
-                tcbuf.as<T>(), U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
-    c->rfft2_F(U5.as<T>(), F5.as<cx<T>>(), 5L * B);
-    CMBL_LAUNCH(c, K_DPHI_X, (k_dphi_combine<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, F5.as<cx<T>>(), dphi, c->lx_r.template as<T>(),
-                c->ly.template as<T>(), c->lgNx, pl, B);
+    dphi_finish(dphi, P, B, nst, alias_quirk);
   }
 
   // ---- boundary-level entry points ---------------------------------------------------------------
@@ -806,6 +991,11 @@ struct Dataset {
 
   // x (QU Fourier, F layout) <- rfft2(mask .* irfft2(x)): x pass, column kernel (c2r, mask, r2c in LDS), x pass
   void pixel_mask(cx<T>* x, long sl) {
+    if (c->generic) {
+      mp.ensure(sizeof(T) * sl * c->npix());
+      c->F_to_map(x, mp.template as<T>(), sl); c->mask_mul(mp.template as<T>(), mp.template as<T>(), ops[OP_MPIX].d[0], sl); c->rfft2_F(mp.template as<T>(), x, sl);
+      return;
+    }
     cx<T>* m = c->mixed_scratch(sl);
     c->template x_pass<1>(x, m, sl); c->y_mask(m, m, ops[OP_MPIX].d[0], sl); c->template x_pass<0>(m, x, sl);
   }

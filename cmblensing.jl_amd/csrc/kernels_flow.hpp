@@ -519,12 +519,12 @@ typedef double nt_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nt_load16(const float* p, float (&o)[4]) { const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 __device__ __forceinline__ void nt_load16(const double* p, double (&o)[2]) { const nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p)); o[0] = v.x; o[1] = v.y; }
 
-template <typename T>
+// V = pixels per thread: 16-byte loads when npix allows it, 1 for the any-size path (odd pixel counts)
+template <typename T, int V = 16 / (int)sizeof(T)>
 __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __restrict__ W /*[nst][2][slices][npix]*/,
                                                     const T* __restrict__ tc /*[nst][2] = (t_s, c_s)*/, T* __restrict__ out /*[5][B][npix]*/,
                                                     long npix, int P, int B, int nst, int alias_quirk) {
-  constexpr int V = 16 / sizeof(T);                            // pixels per thread: 16-byte loads
-  struct alignas(16) Vec { T v[V]; };
+  struct alignas(V * sizeof(T)) Vec { T v[V]; };
   const int b = blockIdx.y;
   const size_t slices = (size_t)P * B, pb = (size_t)(ph.Bphi == 1 ? 0 : b) * npix;
   const long nv = npix / V;
@@ -544,8 +544,10 @@ __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __r
         if (s0 + j < nst)
           for (int p = 0; p < P; ++p) {
             Vec a1, a2;
-            nt_load16(W + ((size_t)(2 * (s0 + j)) * slices + (size_t)b * P + p) * npix + i, a1.v);
-            nt_load16(W + ((size_t)(2 * (s0 + j) + 1) * slices + (size_t)b * P + p) * npix + i, a2.v);
+            const T* q1 = W + ((size_t)(2 * (s0 + j)) * slices + (size_t)b * P + p) * npix + i;
+            const T* q2 = W + ((size_t)(2 * (s0 + j) + 1) * slices + (size_t)b * P + p) * npix + i;
+            if constexpr (V * sizeof(T) == 16) { nt_load16(q1, a1.v); nt_load16(q2, a2.v); }
+            else { a1 = *reinterpret_cast<const Vec*>(q1); a2 = *reinterpret_cast<const Vec*>(q2); }
 #pragma unroll
             for (int k = 0; k < V; ++k) { w1[j].v[k] += a1.v[k]; w2[j].v[k] += a2.v[k]; }
           }
@@ -588,10 +590,10 @@ __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __r
 // dphi = i lx F1 + i ly F2 - lx^2 FA - lx ly FB - ly^2 FC   (F layout, [5][B][plane] in, [B][plane] out)
 template <typename T>
 __global__ __launch_bounds__(NTP) void k_dphi_combine(const cx<T>* __restrict__ F5, cx<T>* __restrict__ out, const T* __restrict__ lx_r,
-                                                     const T* __restrict__ ly, int lgNx, long plane, int B) {
+                                                     const T* __restrict__ ly, int Nx, long plane, int B) {
   const long i = (long)blockIdx.x * NTP + threadIdx.x;
   if (i >= plane) return;
-  const T lx = lx_r[i & ((1 << lgNx) - 1)], l_y = ly[i >> lgNx];
+  const T lx = lx_r[(unsigned)i % (unsigned)Nx], l_y = ly[(unsigned)i / (unsigned)Nx];
   const long cs = (long)B * plane;
   for (int b = 0; b < B; ++b) {
     const cx<T>* f = F5 + (long)b * plane + i;
@@ -623,11 +625,11 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_delta_rows(
 template <typename T>
 __global__ __launch_bounds__(NTP) void k_gradhess_mult(const cx<T>* __restrict__ phi, cx<T>* __restrict__ out,
                                                       const T* __restrict__ lx_r, const T* __restrict__ ly,
-                                                      int lgNx, int Nyh, int B) {
-  const long plane = (long)Nyh << lgNx;
+                                                      int Nx, int Nyh, int B) {
+  const long plane = (long)Nyh * Nx;
   const long i = (long)blockIdx.x * NTP + threadIdx.x;
   if (i >= plane) return;
-  const T lx = lx_r[i & ((1 << lgNx) - 1)], l_y = ly[i >> lgNx];
+  const T lx = lx_r[(unsigned)i % (unsigned)Nx], l_y = ly[(unsigned)i / (unsigned)Nx];
   for (int b = 0; b < B; ++b) {
     const cx<T> v = phi[(long)b * plane + i];
     const cx<T> gx = mk<T>(-lx * v.y, lx * v.x), gy = mk<T>(-l_y * v.y, l_y * v.x);

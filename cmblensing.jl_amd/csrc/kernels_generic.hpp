@@ -1,0 +1,185 @@
+// Any-size path: Ny, Nx that are not powers of two (the reference takes any size through FFTW plans, src/util_fft.jl:32-35).
+//
+// The fused row / column kernels are compiled for power-of-two sizes (bit-reversed slot maps, compile-time strides).  Other sizes run
+// the reference's own pass structure (src/lenseflow.jl:150-214: transform, multiply, transform, pointwise) on two building blocks:
+//   * k_gen_dft: batched 1-D DFT of any length N <= 4096 along either axis as a chirp-z (Bluestein) convolution,
+//         X[k] = w[k] sum_n (x[n] w[n]) conj(w[k-n]),   w[n] = exp(-i pi n^2 / N),
+//     evaluated with the power-of-two in-LDS transforms of fft_lds.hpp at length L >= 2N-1: forward DIF (natural -> bit-reversed),
+//     multiply with the precomputed transform of the chirp filter (stored bit-reversed), inverse DIT (bit-reversed -> natural); no
+//     reordering pass, any prime factors.  Real input / Hermitian input with FFTW's c2r semantics (imaginary parts of the ky = 0 and
+//     Nyquist entries dropped AFTER the x pass, src/util_fft.jl:21-25) / real output are options of the same kernel.
+//   * pointwise kernels for the multiplies, products and RK4 bookkeeping of a stage.
+// The internal F layout keeps its meaning ([slice][ky][kx]) with kx in natural order instead of bit-reversed, so every
+// table-driven pointwise kernel (operators, reductions, QE legs, gradhess, the delta-phi quadrature) is shared with the fast path.
+#pragma once
+#include "kernels_flow.hpp"
+
+namespace cmbl {
+
+// in [slice][R][C] -> out [slice][C][R]; grid (ceil(C/32), ceil(R/32), slices)
+template <typename V>
+__global__ __launch_bounds__(NTP) void k_transpose(const V* __restrict__ in, V* __restrict__ out, int R, int C) {
+  __shared__ V tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t sl = blockIdx.z;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < R && c < C) tile[ty + 8 * i][tx] = in[(sl * R + r) * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < C) out[(sl * C + c) * R + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+// One launch = `nseq` sequences per slice (blockIdx.y), S per workgroup.  Element n of sequence q of slice s is at
+// in[s*in_slice + q*in_seq + n*in_elem] (real T or cx<T>), likewise for the output.
+template <typename T> struct GenDft {
+  const void* in; void* out;
+  const cx<T>* chirp;                // w[n], n < N
+  const cx<T>* bhat;                 // DFT_L of the chirp filter / L, bit-reversed slot order
+  const cx<T>* tw;                   // exp(-2 pi i k / L), k < L
+  int N, nin, nout, nseq, S;
+  long in_seq, in_elem, in_slice, out_seq, out_elem, out_slice;
+  int in_real, out_real, inverse, herm;
+  T scale;
+};
+
+template <typename T, int LGL>
+__global__ __launch_bounds__(NTP) void k_gen_dft(GenDft<T> a) {
+  constexpr int L = 1 << LGL, LD = tile_ld(L);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* s = reinterpret_cast<cx<T>*>(smem);
+  const int S = a.S, seq0 = blockIdx.x * S;
+  const size_t sl = blockIdx.y;
+  // consecutive threads walk whichever of (element, sequence) is contiguous in memory
+  const bool in_by_seq = a.in_elem != 1 && S > 1, out_by_seq = a.out_elem != 1 && S > 1;
+  for (int q = threadIdx.x; q < S * L; q += NTP) {
+    int sq, n;
+    if (in_by_seq) { sq = q % S; n = q / S; } else { sq = q >> LGL; n = q & (L - 1); }
+    const int seq = seq0 + sq;
+    cx<T> v = mk<T>(T(0), T(0));
+    if (seq < a.nseq && n < a.N) {
+      const size_t base = sl * a.in_slice + (size_t)seq * a.in_seq;
+      if (a.in_real) v = mk<T>(reinterpret_cast<const T*>(a.in)[base + (size_t)n * a.in_elem], T(0));
+      else if (!a.herm) v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
+      else if (n < a.nin) {
+        v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
+        if (n == 0 || 2 * n == a.N) v.y = T(0);                       // FFTW c2r: these imaginary parts are never read
+      } else v = conj(reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)(a.N - n) * a.in_elem]);
+      if (a.inverse) v = conj(v);                                     // e^{+i} transform = conj(forward(conj x))
+      v = v * a.chirp[n];
+    }
+    s[sq * LD + pad(n)] = v;
+  }
+  __syncthreads();
+  fft_dif<T, NTP, LD, LGL, LGL>(s, S, a.tw);
+  for (int q = threadIdx.x; q < S * L; q += NTP) {
+    const int sq = q >> LGL, n = q & (L - 1);
+    cx<T>* p = s + sq * LD + pad(n);
+    *p = *p * a.bhat[n];
+  }
+  __syncthreads();
+  fft_dit<T, NTP, LD, LGL, LGL>(s, S, a.tw);
+  for (int q = threadIdx.x; q < S * a.nout; q += NTP) {
+    int sq, k;
+    if (out_by_seq) { sq = q % S; k = q / S; } else { sq = q / a.nout; k = q - sq * a.nout; }
+    const int seq = seq0 + sq;
+    if (seq >= a.nseq) continue;
+    cx<T> y = s[sq * LD + pad(k)] * a.chirp[k];
+    if (a.inverse) y = conj(y);
+    const size_t o = sl * a.out_slice + (size_t)seq * a.out_seq + (size_t)k * a.out_elem;
+    if (a.out_real) reinterpret_cast<T*>(a.out)[o] = a.scale * y.x;
+    else reinterpret_cast<cx<T>*>(a.out)[o] = mk<T>(a.scale * y.x, a.scale * y.y);
+  }
+}
+
+// ---- pointwise pieces of a flow stage ----------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void gen_p(const PhiMaps<T>& ph, size_t gi, T t, T& px, T& py) {
+  if (ph.pcx) { px = ph.pcx[gi]; py = ph.pcy[gi]; }
+  else { T m11, m12, m22; flow_pm(t, ph.gx[gi], ph.gy[gi], ph.hxx[gi], ph.hyx[gi], ph.hyy[gi], px, py, m11, m12, m22); }
+}
+
+// (Fx, Fy) = (i lx F, i ly F)        F layout, grid (blocks, slices)     (src/lenseflow.jl:155, src/specialops.jl:184-188)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_gen_lmul2(const cx<T>* __restrict__ F, cx<T>* __restrict__ Fx, cx<T>* __restrict__ Fy,
+                                                  const T* __restrict__ lx_r, const T* __restrict__ ly, int Nx, long plane) {
+  const long i = (long)blockIdx.x * NTP + threadIdx.x;
+  if (i >= plane) return;
+  const size_t o = (size_t)blockIdx.y * plane + i;
+  const T lx = lx_r[(unsigned)i % (unsigned)Nx], l_y = ly[(unsigned)i / (unsigned)Nx];
+  const cx<T> v = F[o];
+  Fx[o] = mul_il(v, lx); Fy[o] = mul_il(v, l_y);
+}
+
+// velocity k = p_x gx + p_y gy and the RK4 bookkeeping of the Map state (src/lenseflow.jl:150-161, src/numerical_algorithms.jl:15-21)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_gen_vel_rk(const T* __restrict__ gx, const T* __restrict__ gy, PhiMaps<T> ph, T* __restrict__ y0,
+                                                   T* __restrict__ acc, T* __restrict__ ys, RKCoef<T> rk, long npix, int P) {
+  const size_t sl = blockIdx.y, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
+    const size_t o = sl * npix + i;
+    T px, py; gen_p(ph, pb + i, rk.t, px, py);
+    const T k = px * gx[o] + py * gy[o];
+    T y = y0[o], a = rk.stage == 1 ? T(0) : acc[o];
+    const T nxt = rk_update(rk, k, y, a);
+    if (rk.stage == 4) y0[o] = y; else acc[o] = a;
+    ys[o] = nxt;
+  }
+}
+
+// (Wx, Wy) = (p_x y, p_y y)          (src/lenseflow.jl:166-170)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_gen_pmul(const T* __restrict__ y, PhiMaps<T> ph, T t, T* __restrict__ Wx, T* __restrict__ Wy, long npix, int P) {
+  const size_t sl = blockIdx.y, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
+    const size_t o = sl * npix + i;
+    T px, py; gen_p(ph, pb + i, t, px, py);
+    const T v = y[o];
+    Wx[o] = px * v; Wy[o] = py * v;
+  }
+}
+
+// adjoint velocity k = i lx Fx + i ly Fy and the RK4 bookkeeping of the Fourier state (src/lenseflow.jl:163-174)
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_gen_adj_rk(const cx<T>* __restrict__ Fx, const cx<T>* __restrict__ Fy, const T* __restrict__ lx_r,
+                                                   const T* __restrict__ ly, int Nx, cx<T>* __restrict__ Y0, cx<T>* __restrict__ acc,
+                                                   cx<T>* __restrict__ Ys, RKCoef<T> rk, long plane) {
+  const long i = (long)blockIdx.x * NTP + threadIdx.x;
+  if (i >= plane) return;
+  const size_t o = (size_t)blockIdx.y * plane + i;
+  const T lx = lx_r[(unsigned)i % (unsigned)Nx], l_y = ly[(unsigned)i / (unsigned)Nx];
+  const cx<T> k = mul_il(Fx[o], lx) + mul_il(Fy[o], l_y);
+  cx<T> y = Y0[o], a = rk.stage == 1 ? mk<T>(T(0), T(0)) : acc[o];
+  const cx<T> nxt = rk_update(rk, k, y, a);
+  if (rk.stage == 4) Y0[o] = y; else acc[o] = a;
+  Ys[o] = nxt;
+}
+
+// pointwise part of a delta-flow stage (src/lenseflow.jl:184-200): products for the delta-f velocity, the f velocity with its RK
+// update, and the per-slice spin-adjoint partial products w_k = L(df) d_k f for the end-of-flow delta-phi quadrature
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_gen_delta(const T* __restrict__ Ldf, const T* __restrict__ gfx, const T* __restrict__ gfy, PhiMaps<T> ph,
+                                                  T* __restrict__ Wx, T* __restrict__ Wy, T* __restrict__ w1p, T* __restrict__ w2p,
+                                                  T* __restrict__ y0, T* __restrict__ acc, T* __restrict__ ys, RKCoef<T> rk, long npix, int P) {
+  const size_t sl = blockIdx.y, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
+    const size_t o = sl * npix + i;
+    T px, py; gen_p(ph, pb + i, rk.t, px, py);
+    const T l = Ldf[o], ax = gfx[o], ay = gfy[o];
+    Wx[o] = px * l; Wy[o] = py * l;
+    w1p[o] = l * ax; w2p[o] = l * ay;
+    const T k = px * ax + py * ay;
+    T y = y0[o], a = rk.stage == 1 ? T(0) : acc[o];
+    const T nxt = rk_update(rk, k, y, a);
+    if (rk.stage == 4) y0[o] = y; else acc[o] = a;
+    ys[o] = nxt;
+  }
+}
+
+}  // namespace cmbl

@@ -145,10 +145,10 @@ __device__ __forceinline__ A block_sum(A v) {
 // Element functors: value of term i of batch slot bt, formed in T exactly like the reference's broadcast.
 //   Fourier dot  z = real(conj(a) b) .* lam   (src/proj_lambert.jl:322-325; the 1/(Ny Nx) is applied to the sum)
 template <typename T> struct TermDotF {
-  const cx<T>* a; const cx<T>* b; const T* lam; long n; int lgNx, Nyh;
+  const cx<T>* a; const cx<T>* b; const T* lam; long n; int Nx, Nyh;
   __device__ __forceinline__ T operator()(int bt, long i) const {
     const cx<T> u = a[(long)bt * n + i], v = b[(long)bt * n + i];
-    return (u.x * v.x + u.y * v.y) * lam[(int)((i >> lgNx) % Nyh)];
+    return (u.x * v.x + u.y * v.y) * lam[(int)(((unsigned)i / (unsigned)Nx) % (unsigned)Nyh)];
   }
 };
 //   Map dot  z = a .* b   (src/proj_lambert.jl:318-321)
@@ -158,24 +158,24 @@ template <typename T> struct TermDotMap {
 };
 //   logdet of a Fourier diagonal, real planes or complex field: nan2zero(log|d| * lam)   (src/proj_lambert.jl:331-336)
 template <typename T> struct TermLogdetF {
-  const T* d; const T* lam; long n; int lgNx, Nyh;
+  const T* d; const T* lam; long n; int Nx, Nyh;
   __device__ __forceinline__ T operator()(int bt, long i) const {
-    const T v = log(fabs(d[(long)bt * n + i])) * lam[(int)((i >> lgNx) % Nyh)];
+    const T v = log(fabs(d[(long)bt * n + i])) * lam[(int)(((unsigned)i / (unsigned)Nx) % (unsigned)Nyh)];
     return isfinite(v) ? v : T(0);
   }
 };
 template <typename T> struct TermLogdetFc {
-  const cx<T>* d; const T* lam; long n; int lgNx, Nyh;
+  const cx<T>* d; const T* lam; long n; int Nx, Nyh;
   __device__ __forceinline__ T operator()(int bt, long i) const {
     const cx<T> z = d[(long)bt * n + i];
-    const T v = log(hypot(z.x, z.y)) * lam[(int)((i >> lgNx) % Nyh)];
+    const T v = log(hypot(z.x, z.y)) * lam[(int)(((unsigned)i / (unsigned)Nx) % (unsigned)Nyh)];
     return isfinite(v) ? v : T(0);
   }
 };
 //   tr of a Fourier diagonal: real(d .* lam)   (src/proj_lambert.jl:346-350)
 template <typename T> struct TermTrFc {
-  const cx<T>* d; const T* lam; long n; int lgNx, Nyh;
-  __device__ __forceinline__ T operator()(int bt, long i) const { return d[(long)bt * n + i].x * lam[(int)((i >> lgNx) % Nyh)]; }
+  const cx<T>* d; const T* lam; long n; int Nx, Nyh;
+  __device__ __forceinline__ T operator()(int bt, long i) const { return d[(long)bt * n + i].x * lam[(int)(((unsigned)i / (unsigned)Nx) % (unsigned)Nyh)]; }
 };
 //   tr / logdet of a Map diagonal (src/proj_lambert.jl:337-342,351-353): d, and log|d| (the sign term is k_sign_map's)
 template <typename T> struct TermTrMap {
@@ -306,10 +306,10 @@ __global__ __launch_bounds__(NTP) void k_cg_keep_best(T* __restrict__ bx, const 
 //   out = nan2zero( in * (i lx)^p1 * (i ly)^p2 / |l|^n )      in F layout (S0, batched); caller inverse-transforms it.
 template <typename T>
 __global__ __launch_bounds__(NTP) void k_qe_leg(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, const T* __restrict__ lx_r,
-                                                const T* __restrict__ ly, int lgNx, long plane, int B, int n, int p1, int p2, int take_abs) {
+                                                const T* __restrict__ ly, int Nx, long plane, int B, int n, int p1, int p2, int take_abs) {
   const long i = (long)blockIdx.x * NTP + threadIdx.x;
   if (i >= plane) return;
-  const T lx = lx_r[i & ((1 << lgNx) - 1)], l_y = ly[i >> lgNx];
+  const T lx = lx_r[(unsigned)i % (unsigned)Nx], l_y = ly[(unsigned)i / (unsigned)Nx];
   T mag = T(1);
   for (int k = 0; k < p1; ++k) mag *= lx;
   for (int k = 0; k < p2; ++k) mag *= l_y;

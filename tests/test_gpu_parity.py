@@ -300,7 +300,7 @@ def test_logpdf_mixed_and_gradient(prec, pol, Nside):
 def test_errors_are_status_codes():
     C = _pkg()
     with pytest.raises(C.CmblError) as e:
-        C.ProjLambert(100, 64, 1.0)
+        C.ProjLambert(8192, 64, 1.0)                # sides above 4096 do not fit the in-LDS transforms
     assert e.value.code == 2                       # CMBL_ERR_SHAPE
     p = C.ProjLambert(64, 64, 1.0)
     L = C.LenseFlow(p, 7)
