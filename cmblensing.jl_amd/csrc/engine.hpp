@@ -177,7 +177,7 @@ struct Ctx : CtxBase {
   }
 
   // ---- any-size transforms (kernels_generic.hpp) -------------------------------------------------
-  struct GenAxis { int N = 0, lgL = 0; DevBuf chirp, bhat, tw; };
+  struct GenAxis { int N = 0, lgL = 0; DevBuf chirp, bhat, tw, twN; GenPlan plan{}; };
   GenAxis genY, genX;
   static void host_fft(std::vector<std::complex<double>>& v) {             // in-place radix-2, e^{-i}; table set-up only
     const size_t n = v.size();
@@ -193,6 +193,21 @@ struct Ctx : CtxBase {
   }
   void build_axis(GenAxis& ax, int N) {
     ax.N = N; ax.lgL = std::max(3, ilog2(2 * N - 1));
+    // mixed-radix plan when N has no prime factor above 13 (odd radices first, then 4s, then a 2); otherwise chirp-z
+    ax.plan = GenPlan{};
+    if (env_int("CMBL_GEN_BLUESTEIN", 0) == 0) {
+      int rem = N, nf = 0, f[32];
+      for (int p : {13, 11, 7, 5, 3}) while (rem % p == 0 && nf < 14) { f[nf++] = p; rem /= p; }
+      while (rem % 4 == 0 && nf < 14) { f[nf++] = 4; rem /= 4; }
+      if (rem % 2 == 0 && nf < 14) { f[nf++] = 2; rem /= 2; }
+      if (rem == 1) { ax.plan.nf = nf; for (int i = 0; i < nf; ++i) ax.plan.radix[i] = f[i]; }
+    }
+    if (ax.plan.nf > 0) {
+      std::vector<cx<T>> t(N);
+      for (int k = 0; k < N; ++k) { const double a = -2.0 * M_PI * k / N; t[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
+      upload(ax.twN, t);
+      return;
+    }
     const int L = 1 << ax.lgL;
     std::vector<std::complex<double>> w(N), b(L, 0.0);
     for (int n = 0; n < N; ++n) {                                           // exp(-i pi n^2 / N), the phase reduced exactly
@@ -212,6 +227,16 @@ struct Ctx : CtxBase {
     upload(ax.chirp, wc); upload(ax.bhat, bh); upload(ax.tw, tw);
   }
   void gen_dft(const GenAxis& ax, GenDft<T> a, long slices) {
+    if (ax.plan.nf > 0) {
+      a.N = ax.N; a.tw = ax.twN.template as<cx<T>>();
+      a.S = std::max(1, std::min(16, 2048 / ax.N));
+      auto lds_of = [&](int S, bool tw) { return ((size_t)2 * S * ax.N + (tw ? ax.N : 0)) * sizeof(cx<T>); };
+      while (a.S > 1 && lds_of(a.S, true) > 64 * 1024) --a.S;
+      const bool tw_lds = lds_of(a.S, true) <= 160 * 1024;
+      const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
+      CMBL_LAUNCH(this, K_GEN_DFT, (k_gen_dft_mr<T>), grid, lds_of(a.S, tw_lds), stream, a, ax.plan, tw_lds ? 1 : 0);
+      return;
+    }
     const int L = 1 << ax.lgL;
     a.chirp = ax.chirp.template as<cx<T>>(); a.bhat = ax.bhat.template as<cx<T>>(); a.tw = ax.tw.template as<cx<T>>(); a.N = ax.N;
     a.S = std::max(1, std::min(8, 2048 / L));

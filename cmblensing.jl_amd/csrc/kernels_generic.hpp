@@ -49,6 +49,28 @@ template <typename T> struct GenDft {
   T scale;
 };
 
+
+// input element n of a sequence: real / complex / Hermitian-extended half spectrum, conjugated for the e^{+i} transform
+template <typename T>
+__device__ __forceinline__ cx<T> gen_fetch(const GenDft<T>& a, size_t sl, int seq, int n) {
+  const size_t base = sl * a.in_slice + (size_t)seq * a.in_seq;
+  cx<T> v;
+  if (a.in_real) v = mk<T>(reinterpret_cast<const T*>(a.in)[base + (size_t)n * a.in_elem], T(0));
+  else if (!a.herm) v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
+  else if (n < a.nin) {
+    v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
+    if (n == 0 || 2 * n == a.N) v.y = T(0);                           // FFTW c2r: these imaginary parts are never read
+  } else v = conj(reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)(a.N - n) * a.in_elem]);
+  return a.inverse ? conj(v) : v;                                     // e^{+i} transform = conj(forward(conj x))
+}
+template <typename T>
+__device__ __forceinline__ void gen_put(const GenDft<T>& a, size_t sl, int seq, int k, cx<T> y) {
+  if (a.inverse) y = conj(y);
+  const size_t o = sl * a.out_slice + (size_t)seq * a.out_seq + (size_t)k * a.out_elem;
+  if (a.out_real) reinterpret_cast<T*>(a.out)[o] = a.scale * y.x;
+  else reinterpret_cast<cx<T>*>(a.out)[o] = mk<T>(a.scale * y.x, a.scale * y.y);
+}
+
 template <typename T, int LGL>
 __global__ __launch_bounds__(NTP) void k_gen_dft(GenDft<T> a) {
   constexpr int L = 1 << LGL, LD = tile_ld(L);
@@ -63,17 +85,7 @@ __global__ __launch_bounds__(NTP) void k_gen_dft(GenDft<T> a) {
     if (in_by_seq) { sq = q % S; n = q / S; } else { sq = q >> LGL; n = q & (L - 1); }
     const int seq = seq0 + sq;
     cx<T> v = mk<T>(T(0), T(0));
-    if (seq < a.nseq && n < a.N) {
-      const size_t base = sl * a.in_slice + (size_t)seq * a.in_seq;
-      if (a.in_real) v = mk<T>(reinterpret_cast<const T*>(a.in)[base + (size_t)n * a.in_elem], T(0));
-      else if (!a.herm) v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
-      else if (n < a.nin) {
-        v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
-        if (n == 0 || 2 * n == a.N) v.y = T(0);                       // FFTW c2r: these imaginary parts are never read
-      } else v = conj(reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)(a.N - n) * a.in_elem]);
-      if (a.inverse) v = conj(v);                                     // e^{+i} transform = conj(forward(conj x))
-      v = v * a.chirp[n];
-    }
+    if (seq < a.nseq && n < a.N) v = gen_fetch(a, sl, seq, n) * a.chirp[n];
     s[sq * LD + pad(n)] = v;
   }
   __syncthreads();
@@ -90,11 +102,120 @@ __global__ __launch_bounds__(NTP) void k_gen_dft(GenDft<T> a) {
     if (out_by_seq) { sq = q % S; k = q / S; } else { sq = q / a.nout; k = q - sq * a.nout; }
     const int seq = seq0 + sq;
     if (seq >= a.nseq) continue;
-    cx<T> y = s[sq * LD + pad(k)] * a.chirp[k];
-    if (a.inverse) y = conj(y);
-    const size_t o = sl * a.out_slice + (size_t)seq * a.out_seq + (size_t)k * a.out_elem;
-    if (a.out_real) reinterpret_cast<T*>(a.out)[o] = a.scale * y.x;
-    else reinterpret_cast<cx<T>*>(a.out)[o] = mk<T>(a.scale * y.x, a.scale * y.y);
+    gen_put(a, sl, seq, k, s[sq * LD + pad(k)] * a.chirp[k]);
+  }
+}
+
+
+// ---- mixed-radix transforms for N = 2^a 3^b 5^c 7^d 11^e 13^f ----------------------------------------------------------------
+// Stockham autosort network (natural order in and out, ping-pong between two LDS buffers): a stage of radix R with Ns = product of
+// the earlier radices does, for every j < N/R with k = j mod Ns,
+//     v[m] = X[j + m N/R] W_{Ns R}^{m k},   v <- DFT_R(v),   Y[(j div Ns) Ns R + k + m Ns] = v[m].
+// Radices 2, 3, 4, 5 are written out; 7, 11, 13 are direct sums with table twiddles.  Sizes with larger prime factors use k_gen_dft.
+struct GenPlan { int nf; int radix[14]; };
+
+template <typename T, int R> struct Bfly;
+template <typename T> struct Bfly<T, 2> { static __device__ __forceinline__ void run(cx<T>* v, const cx<T>*, int) { const cx<T> a = v[0], b = v[1]; v[0] = a + b; v[1] = a - b; } };
+template <typename T> struct Bfly<T, 4> {
+  static __device__ __forceinline__ void run(cx<T>* v, const cx<T>*, int) {
+    const cx<T> a = v[0] + v[2], b = v[0] - v[2], c = v[1] + v[3], d = mul_mi(v[1] - v[3]);
+    v[0] = a + c; v[1] = b + d; v[2] = a - c; v[3] = b - d;
+  }
+};
+template <typename T> struct Bfly<T, 3> {
+  static __device__ __forceinline__ void run(cx<T>* v, const cx<T>*, int) {
+    const cx<T> t = v[1] + v[2], m = v[0] - T(0.5) * t, sd = T(0.86602540378443864676) * (v[1] - v[2]);
+    v[0] = v[0] + t; v[1] = m + mul_mi(sd); v[2] = m + mul_i(sd);
+  }
+};
+template <typename T> struct Bfly<T, 5> {
+  static __device__ __forceinline__ void run(cx<T>* v, const cx<T>*, int) {
+    constexpr T c1 = T(0.30901699437494742410), c2 = T(-0.80901699437494742410), s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);
+    const cx<T> t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
+    const cx<T> a1 = v[0] + c1 * t1 + c2 * t2, a2 = v[0] + c2 * t1 + c1 * t2;
+    const cx<T> b1 = s1 * t3 + s2 * t4, b2 = s2 * t3 - s1 * t4;
+    v[0] = v[0] + t1 + t2;
+    v[1] = a1 + mul_mi(b1); v[4] = a1 + mul_i(b1); v[2] = a2 + mul_mi(b2); v[3] = a2 + mul_i(b2);
+  }
+};
+// direct R-point sum; tw is the full-circle table W_N, step = N / R
+template <typename T, int R> struct Bfly {
+  static __device__ __forceinline__ void run(cx<T>* v, const cx<T>* tw, int step) {
+    cx<T> o[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      cx<T> acc = v[0];
+#pragma unroll
+      for (int m = 1; m < R; ++m) acc = acc + v[m] * tw[((m * k) % R) * step];
+      o[k] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = o[k];
+  }
+};
+
+template <typename T, int R>
+__device__ __forceinline__ void mr_stage(const cx<T>* __restrict__ X, cx<T>* __restrict__ Y, int N, int Ns, const cx<T>* __restrict__ tw, int S) {
+  const int nb = N / R, tstep = N / (Ns * R);
+  for (int q = threadIdx.x; q < S * nb; q += NTP) {
+    const int sq = q / nb, j = q - sq * nb, blk = j / Ns, k = j - blk * Ns;
+    const cx<T>* x = X + sq * N + j;
+    cx<T> v[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = x[m * nb];
+    if (Ns > 1) {
+#pragma unroll
+      for (int m = 1; m < R; ++m) v[m] = v[m] * tw[m * k * tstep];
+    }
+    Bfly<T, R>::run(v, tw, nb);
+    cx<T>* y = Y + sq * N + blk * Ns * R + k;
+#pragma unroll
+    for (int m = 0; m < R; ++m) y[m * Ns] = v[m];
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_gen_dft_mr(GenDft<T> a, GenPlan plan, int tw_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = a.N, S = a.S, seq0 = blockIdx.x * S;
+  cx<T>* X = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* Y = X + (size_t)S * N;
+  const cx<T>* tw = a.tw;                                              // W_N, N entries
+  if (tw_in_lds) {
+    cx<T>* t = Y + (size_t)S * N;
+    for (int i = threadIdx.x; i < N; i += NTP) t[i] = a.tw[i];
+    tw = t;
+  }
+  const size_t sl = blockIdx.y;
+  const bool in_by_seq = a.in_elem != 1 && S > 1, out_by_seq = a.out_elem != 1 && S > 1;
+  for (int q = threadIdx.x; q < S * N; q += NTP) {
+    int sq, n;
+    if (in_by_seq) { sq = q % S; n = q / S; } else { sq = q / N; n = q - sq * N; }
+    const int seq = seq0 + sq;
+    X[sq * N + n] = seq < a.nseq ? gen_fetch(a, sl, seq, n) : mk<T>(T(0), T(0));
+  }
+  __syncthreads();
+  int Ns = 1;
+  for (int f = 0; f < plan.nf; ++f) {
+    const int R = plan.radix[f];
+    switch (R) {
+      case 2: mr_stage<T, 2>(X, Y, N, Ns, tw, S); break;
+      case 3: mr_stage<T, 3>(X, Y, N, Ns, tw, S); break;
+      case 4: mr_stage<T, 4>(X, Y, N, Ns, tw, S); break;
+      case 5: mr_stage<T, 5>(X, Y, N, Ns, tw, S); break;
+      case 7: mr_stage<T, 7>(X, Y, N, Ns, tw, S); break;
+      case 11: mr_stage<T, 11>(X, Y, N, Ns, tw, S); break;
+      default: mr_stage<T, 13>(X, Y, N, Ns, tw, S); break;
+    }
+    Ns *= R;
+    cx<T>* t = X; X = Y; Y = t;
+  }
+  for (int q = threadIdx.x; q < S * a.nout; q += NTP) {
+    int sq, k;
+    if (out_by_seq) { sq = q % S; k = q / S; } else { sq = q / a.nout; k = q - sq * a.nout; }
+    const int seq = seq0 + sq;
+    if (seq < a.nseq) gen_put(a, sl, seq, k, X[sq * N + k]);
   }
 }
 

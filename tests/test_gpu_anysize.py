@@ -1,6 +1,7 @@
 """Any-size path (Ny, Nx not powers of two; csrc/kernels_generic.hpp): the same parity tests as the fused path, on sizes the
 reference takes through FFTW plans (src/util_fft.jl:32-35) -- even and odd, with prime factors 3, 5, 7, 13 -- plus a cross-check of
 the two device implementations against each other at a power-of-two size (CMBL_FORCE_GENERIC=1 routes it through the any-size path).
+Sizes whose prime factors are all <= 13 run mixed-radix Stockham transforms, the others (here 51 = 3*17, 38 = 2*19, 34 = 2*17) chirp-z.
 Tolerances are those of tests/test_gpu_parity.py."""
 import os
 import numpy as np
@@ -20,13 +21,13 @@ def camb():
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("Ny,Nx", [(96, 160), (160, 96), (45, 75), (100, 128), (360, 360), (52, 26), (6, 10)])
+@pytest.mark.parametrize("Ny,Nx", [(96, 160), (160, 96), (45, 75), (100, 128), (360, 360), (52, 26), (6, 10), (77, 44), (51, 38), (1000, 34)])
 def test_geometry_and_basis_transforms(prec, Ny, Nx):
     TP.test_geometry_and_basis_transforms(prec, Ny, Nx)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(96, 160, 2, 1, 1), (160, 96, 3, 1, 1), (45, 75, 2, 2, 2), (100, 128, 1, 2, 1), (91, 60, 2, 1, 1)])
+@pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(96, 160, 2, 1, 1), (160, 96, 3, 1, 1), (45, 75, 2, 2, 2), (100, 128, 1, 2, 1), (91, 60, 2, 1, 1), (51, 38, 2, 1, 1)])
 @pytest.mark.parametrize("n", [7, 10])
 def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi, n):
     TP.test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi, n)
