@@ -229,12 +229,19 @@ struct Ctx : CtxBase {
   void gen_dft(const GenAxis& ax, GenDft<T> a, long slices) {
     if (ax.plan.nf > 0) {
       a.N = ax.N; a.tw = ax.twN.template as<cx<T>>();
-      a.S = std::max(1, std::min(16, 2048 / ax.N));
+      // sequences per workgroup: enough of them for coalesced strided access, but not so many that the launch has fewer than a few
+      // workgroups per CU (small maps); the two LDS buffers + the twiddle table within 64 KB
       auto lds_of = [&](int S, bool tw) { return ((size_t)2 * S * ax.N + (tw ? ax.N : 0)) * sizeof(cx<T>); };
+      const long total = (long)a.nseq * slices;
+      a.S = (int)std::max<long>(1, std::min<long>(std::min(16, 2048 / ax.N), total / (4L * num_cus)));
       while (a.S > 1 && lds_of(a.S, true) > 64 * 1024) --a.S;
       const bool tw_lds = lds_of(a.S, true) <= 160 * 1024;
+      int minR = 13; bool big = false;
+      for (int i = 0; i < ax.plan.nf; ++i) { minR = std::min(minR, ax.plan.radix[i]); big = big || ax.plan.radix[i] > 5; }
+      const int nthr = std::max(64, std::min(NTP, ((a.S * ax.N / minR + 63) / 64) * 64));
       const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
-      CMBL_LAUNCH(this, K_GEN_DFT, (k_gen_dft_mr<T>), grid, lds_of(a.S, tw_lds), stream, a, ax.plan, tw_lds ? 1 : 0);
+      if (big) CMBL_LAUNCH_NT(this, K_GEN_DFT, nthr, (k_gen_dft_mr<T, true>), grid, lds_of(a.S, tw_lds), stream, a, ax.plan, tw_lds ? 1 : 0);
+      else CMBL_LAUNCH_NT(this, K_GEN_DFT, nthr, (k_gen_dft_mr<T, false>), grid, lds_of(a.S, tw_lds), stream, a, ax.plan, tw_lds ? 1 : 0);
       return;
     }
     const int L = 1 << ax.lgL;
@@ -686,26 +693,26 @@ struct Flow {
 
 
   // ---- any-size path: the reference's pass structure on k_gen_dft + pointwise kernels (kernels_generic.hpp) ----------------------
-  DevBuf gF, gFx, gFy, gmx, gmy, gms, gYs;
+  // (x, y) pairs live in the two halves of ONE buffer so that both members go through a transform in one launch
+  DevBuf gF, gFxy, gmxy, gms, gYs, gLdf, gWxy;
   dim3 pgrid(long n, long slices) const { return dim3((unsigned)std::min<long>((n + NTP - 1) / NTP, 4096), (unsigned)slices); }
   dim3 fgrid(long slices) const { return dim3((unsigned)((c->plane() + NTP - 1) / NTP), (unsigned)slices); }
-  // (gx, gy) = grad of the map `ys`  (rfft2, i l multiplies, two irfft2)
+  // (gmx, gmy) = grad of the map `ys`  (rfft2, i l multiplies, irfft2 of both components)
   void gen_grad(const T* ys, long slices) {
     const long pl = c->plane(), np = c->npix();
-    gF.ensure(sizeof(cx<T>) * slices * pl); gFx.ensure(sizeof(cx<T>) * slices * pl); gFy.ensure(sizeof(cx<T>) * slices * pl);
-    gmx.ensure(sizeof(T) * slices * np); gmy.ensure(sizeof(T) * slices * np);
+    gF.ensure(sizeof(cx<T>) * slices * pl); gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gmxy.ensure(sizeof(T) * 2 * slices * np);
     c->rfft2_F(ys, gF.as<cx<T>>(), slices);
-    CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_lmul2<T>), fgrid(slices), 0, c->stream, gF.as<cx<T>>(), gFx.as<cx<T>>(), gFy.as<cx<T>>(), c->lx_r.template as<T>(),
-                c->ly.template as<T>(), c->Nx, pl);
-    c->F_to_map(gFx.as<cx<T>>(), gmx.as<T>(), slices); c->F_to_map(gFy.as<cx<T>>(), gmy.as<T>(), slices);
+    CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_lmul2<T>), fgrid(slices), 0, c->stream, gF.as<cx<T>>(), gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl,
+                c->lx_r.template as<T>(), c->ly.template as<T>(), c->Nx, pl);
+    c->F_to_map(gFxy.as<cx<T>>(), gmxy.as<T>(), 2 * slices);
   }
-  // d(Fourier state)/dt from the maps (Wx, Wy): two rfft2 + the RK update with k = i lx Fx + i ly Fy
-  void gen_adj_update(const T* Wx_, const T* Wy_, cx<T>* Y0, cx<T>* Yacc_, cx<T>* Ys, const RKCoef<T>& rk, long slices) {
+  // d(Fourier state)/dt from the maps (Wx, Wy) = the halves of Wxy: rfft2 of both + the RK update with k = i lx Fx + i ly Fy
+  void gen_adj_update(const T* Wxy, cx<T>* Y0, cx<T>* Yacc_, cx<T>* Ys, const RKCoef<T>& rk, long slices) {
     const long pl = c->plane();
-    gFx.ensure(sizeof(cx<T>) * slices * pl); gFy.ensure(sizeof(cx<T>) * slices * pl);
-    c->rfft2_F(Wx_, gFx.as<cx<T>>(), slices); c->rfft2_F(Wy_, gFy.as<cx<T>>(), slices);
-    CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFx.as<cx<T>>(), gFy.as<cx<T>>(), c->lx_r.template as<T>(), c->ly.template as<T>(),
-                c->Nx, Y0, Yacc_, Ys, rk, pl);
+    gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl);
+    c->rfft2_F(Wxy, gFxy.as<cx<T>>(), 2 * slices);
+    CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
+                c->ly.template as<T>(), c->Nx, Y0, Yacc_, Ys, rk, pl);
   }
   void gen_flow_map(const T* in, T* out, int P, int B, bool inverse) {
     const long slices = (long)P * B, np = c->npix();
@@ -717,13 +724,14 @@ struct Flow {
       for (int stage = 1; stage <= 4; ++stage) {
         const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
         gen_grad(gms.as<T>(), slices);
-        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_vel_rk<T>), pgrid(np, slices), 0, c->stream, gmx.as<T>(), gmy.as<T>(), ph(rk.t), out, acc.as<T>(), gms.as<T>(), rk, np, P);
+        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_vel_rk<T>), pgrid(np, slices), 0, c->stream, gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t), out, acc.as<T>(),
+                    gms.as<T>(), rk, np, P);
       }
   }
   void gen_flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse) {
     const long slices = (long)P * B, pl = c->plane(), np = c->npix();
     Yacc.ensure(sizeof(cx<T>) * slices * pl); gYs.ensure(sizeof(cx<T>) * slices * pl);
-    gms.ensure(sizeof(T) * slices * np); gmx.ensure(sizeof(T) * slices * np); gmy.ensure(sizeof(T) * slices * np);
+    gms.ensure(sizeof(T) * slices * np); gmxy.ensure(sizeof(T) * 2 * slices * np);
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     CMBL_HIP(hipMemcpyAsync(gYs.p, out, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
@@ -731,16 +739,15 @@ struct Flow {
       for (int stage = 1; stage <= 4; ++stage) {
         const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
         c->F_to_map(gYs.as<cx<T>>(), gms.as<T>(), slices);
-        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_pmul<T>), pgrid(np, slices), 0, c->stream, gms.as<T>(), ph(rk.t), rk.t, gmx.as<T>(), gmy.as<T>(), np, P);
-        gen_adj_update(gmx.as<T>(), gmy.as<T>(), out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
+        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_pmul<T>), pgrid(np, slices), 0, c->stream, gms.as<T>(), ph(rk.t), rk.t, gmxy.as<T>(), gmxy.as<T>() + slices * np, np, P);
+        gen_adj_update(gmxy.as<T>(), out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
       }
   }
-  DevBuf gLdf, gWx, gWy;
   void gen_flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
     const long slices = (long)P * B, pl = c->plane(), np = c->npix();
     const int nst = 4 * n;
     acc.ensure(sizeof(T) * slices * np); gms.ensure(sizeof(T) * slices * np); gLdf.ensure(sizeof(T) * slices * np);
-    gWx.ensure(sizeof(T) * slices * np); gWy.ensure(sizeof(T) * slices * np);
+    gWxy.ensure(sizeof(T) * 2 * slices * np);
     Yacc.ensure(sizeof(cx<T>) * slices * pl); gYs.ensure(sizeof(cx<T>) * slices * pl);
     Wst.ensure(sizeof(T) * (size_t)nst * 2 * slices * np);
     U5.ensure(sizeof(T) * 5 * B * np); F5.ensure(sizeof(cx<T>) * 5 * B * pl); tcbuf.ensure(sizeof(T) * 2 * nst);
@@ -755,11 +762,11 @@ struct Flow {
         tc_host[2 * it] = rk.t;
         tc_host[2 * it + 1] = (T)((stage == 1 || stage == 4 ? 1.0 : 2.0) * h / 6);
         c->F_to_map(gYs.as<cx<T>>(), gLdf.as<T>(), slices);                   // L(df)
-        gen_grad(gms.as<T>(), slices);                                       // grad f -> (gmx, gmy)
+        gen_grad(gms.as<T>(), slices);                                       // grad f -> gmxy
         T* w1p = Wst.as<T>() + (size_t)(2 * it) * slices * np;
-        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_delta<T>), pgrid(np, slices), 0, c->stream, gLdf.as<T>(), gmx.as<T>(), gmy.as<T>(), ph(rk.t), gWx.as<T>(), gWy.as<T>(),
-                    w1p, w1p + (size_t)slices * np, f, acc.as<T>(), gms.as<T>(), rk, np, P);
-        gen_adj_update(gWx.as<T>(), gWy.as<T>(), df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
+        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_delta<T>), pgrid(np, slices), 0, c->stream, gLdf.as<T>(), gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t),
+                    gWxy.as<T>(), gWxy.as<T>() + slices * np, w1p, w1p + (size_t)slices * np, f, acc.as<T>(), gms.as<T>(), rk, np, P);
+        gen_adj_update(gWxy.as<T>(), df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
       }
     dphi_finish(dphi, P, B, nst, alias_quirk);
   }

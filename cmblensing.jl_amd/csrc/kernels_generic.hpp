@@ -156,8 +156,8 @@ template <typename T, int R> struct Bfly {
 
 template <typename T, int R>
 __device__ __forceinline__ void mr_stage(const cx<T>* __restrict__ X, cx<T>* __restrict__ Y, int N, int Ns, const cx<T>* __restrict__ tw, int S) {
-  const int nb = N / R, tstep = N / (Ns * R);
-  for (int q = threadIdx.x; q < S * nb; q += NTP) {
+  const int nb = N / R, tstep = N / (Ns * R), nt = blockDim.x;
+  for (int q = threadIdx.x; q < S * nb; q += nt) {
     const int sq = q / nb, j = q - sq * nb, blk = j / Ns, k = j - blk * Ns;
     const cx<T>* x = X + sq * N + j;
     cx<T> v[R];
@@ -175,21 +175,23 @@ __device__ __forceinline__ void mr_stage(const cx<T>* __restrict__ X, cx<T>* __r
   __syncthreads();
 }
 
-template <typename T>
+// BIG: the plan contains a radix above 5 (direct-sum butterflies: many registers), compiled apart so that the common
+// 2/3/4/5 kernel keeps a small register footprint.  Launched with 64..256 threads (a multiple of 64).
+template <typename T, bool BIG>
 __global__ __launch_bounds__(NTP) void k_gen_dft_mr(GenDft<T> a, GenPlan plan, int tw_in_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int N = a.N, S = a.S, seq0 = blockIdx.x * S;
+  const int N = a.N, S = a.S, seq0 = blockIdx.x * S, nt = blockDim.x;
   cx<T>* X = reinterpret_cast<cx<T>*>(smem);
   cx<T>* Y = X + (size_t)S * N;
   const cx<T>* tw = a.tw;                                              // W_N, N entries
   if (tw_in_lds) {
     cx<T>* t = Y + (size_t)S * N;
-    for (int i = threadIdx.x; i < N; i += NTP) t[i] = a.tw[i];
+    for (int i = threadIdx.x; i < N; i += nt) t[i] = a.tw[i];
     tw = t;
   }
   const size_t sl = blockIdx.y;
   const bool in_by_seq = a.in_elem != 1 && S > 1, out_by_seq = a.out_elem != 1 && S > 1;
-  for (int q = threadIdx.x; q < S * N; q += NTP) {
+  for (int q = threadIdx.x; q < S * N; q += nt) {
     int sq, n;
     if (in_by_seq) { sq = q % S; n = q / S; } else { sq = q / N; n = q - sq * N; }
     const int seq = seq0 + sq;
@@ -199,19 +201,25 @@ __global__ __launch_bounds__(NTP) void k_gen_dft_mr(GenDft<T> a, GenPlan plan, i
   int Ns = 1;
   for (int f = 0; f < plan.nf; ++f) {
     const int R = plan.radix[f];
+    if constexpr (BIG) {
+      switch (R) {
+        case 7: mr_stage<T, 7>(X, Y, N, Ns, tw, S); break;
+        case 11: mr_stage<T, 11>(X, Y, N, Ns, tw, S); break;
+        case 13: mr_stage<T, 13>(X, Y, N, Ns, tw, S); break;
+        default: break;
+      }
+    }
     switch (R) {
       case 2: mr_stage<T, 2>(X, Y, N, Ns, tw, S); break;
       case 3: mr_stage<T, 3>(X, Y, N, Ns, tw, S); break;
       case 4: mr_stage<T, 4>(X, Y, N, Ns, tw, S); break;
       case 5: mr_stage<T, 5>(X, Y, N, Ns, tw, S); break;
-      case 7: mr_stage<T, 7>(X, Y, N, Ns, tw, S); break;
-      case 11: mr_stage<T, 11>(X, Y, N, Ns, tw, S); break;
-      default: mr_stage<T, 13>(X, Y, N, Ns, tw, S); break;
+      default: break;
     }
     Ns *= R;
     cx<T>* t = X; X = Y; Y = t;
   }
-  for (int q = threadIdx.x; q < S * a.nout; q += NTP) {
+  for (int q = threadIdx.x; q < S * a.nout; q += nt) {
     int sq, k;
     if (out_by_seq) { sq = q % S; k = q / S; } else { sq = q / a.nout; k = q - sq * a.nout; }
     const int seq = seq0 + sq;
