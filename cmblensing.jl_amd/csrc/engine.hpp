@@ -232,13 +232,17 @@ struct Ctx : CtxBase {
       // sequences per workgroup: enough of them for coalesced strided access, but not so many that the launch has fewer than a few
       // workgroups per CU (small maps); the two LDS buffers + the twiddle table within 64 KB
       auto lds_of = [&](int S, bool tw) { return ((size_t)2 * S * ax.N + (tw ? ax.N : 0)) * sizeof(cx<T>); };
-      const long total = (long)a.nseq * slices;
-      a.S = (int)std::max<long>(1, std::min<long>(std::min(16, 2048 / ax.N), total / (4L * num_cus)));
-      while (a.S > 1 && lds_of(a.S, true) > 64 * 1024) --a.S;
-      const bool tw_lds = lds_of(a.S, true) <= 160 * 1024;
       int minR = 13; bool big = false;
       for (int i = 0; i < ax.plan.nf; ++i) { minR = std::min(minR, ax.plan.radix[i]); big = big || ax.plan.radix[i] > 5; }
-      const int nthr = std::max(64, std::min(NTP, ((a.S * ax.N / minR + 63) / 64) * 64));
+      const long total = (long)a.nseq * slices;
+      const bool strided = a.in_elem != 1 || a.out_elem != 1;
+      a.S = (int)std::max<long>(1, std::min<long>(std::min(16, 2048 / ax.N), total / (4L * num_cus)));
+      while (a.S > 1 && lds_of(a.S, true) > 64 * 1024) --a.S;
+      // a strided side is read / written in pieces of S elements: at least 64 bytes of them, in one large workgroup per CU
+      const int Smin = 64 / (int)sizeof(cx<T>);
+      if (strided && !big && a.S < Smin && total >= (long)Smin * num_cus / 2 && lds_of(Smin, false) <= 150 * 1024) a.S = Smin;
+      const bool tw_lds = lds_of(a.S, true) <= 158 * 1024;
+      const int nthr = std::max(64, std::min(big ? NTP : 1024, ((a.S * ax.N / minR + 63) / 64) * 64));
       const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
       if (big) CMBL_LAUNCH_NT(this, K_GEN_DFT, nthr, (k_gen_dft_mr<T, true>), grid, lds_of(a.S, tw_lds), stream, a, ax.plan, tw_lds ? 1 : 0);
       else CMBL_LAUNCH_NT(this, K_GEN_DFT, nthr, (k_gen_dft_mr<T, false>), grid, lds_of(a.S, tw_lds), stream, a, ax.plan, tw_lds ? 1 : 0);

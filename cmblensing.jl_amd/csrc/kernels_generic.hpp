@@ -176,9 +176,9 @@ __device__ __forceinline__ void mr_stage(const cx<T>* __restrict__ X, cx<T>* __r
 }
 
 // BIG: the plan contains a radix above 5 (direct-sum butterflies: many registers), compiled apart so that the common
-// 2/3/4/5 kernel keeps a small register footprint.  Launched with 64..256 threads (a multiple of 64).
+// 2/3/4/5 kernel keeps a small register footprint and can run 1024 threads.  Launched with a multiple of 64 threads.
 template <typename T, bool BIG>
-__global__ __launch_bounds__(NTP) void k_gen_dft_mr(GenDft<T> a, GenPlan plan, int tw_in_lds) {
+__global__ __launch_bounds__(BIG ? NTP : 1024) void k_gen_dft_mr(GenDft<T> a, GenPlan plan, int tw_in_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = a.N, S = a.S, seq0 = blockIdx.x * S, nt = blockDim.x;
   cx<T>* X = reinterpret_cast<cx<T>*>(smem);

@@ -15,8 +15,9 @@
  *       fourier : complex (Ny/2+1, Nx, npol, nbatch)   interleaved (re,im)
  *     npol = 1 (I), 2 (QU), 3 (IQU).  Operators diagonal in l are real (Ny/2+1, Nx) planes.
  *   - dtype: CMBL_F32 or CMBL_F64 (the whole context works in one precision).
- *   - Ny, Nx must be powers of two in [32, 4096] (the reference accepts any size through FFTW;
- *     other sizes return CMBL_ERR_SHAPE).
+ *   - Ny, Nx: any integers in [2, 4096], like the reference's FFTW plans (src/util_fft.jl:32-35).  Powers of two >= 32 on both
+ *     sides run the fused kernels; other sizes the any-size path (mixed-radix / chirp-z transforms, csrc/kernels_generic.hpp),
+ *     same results, ~5x slower per pixel.  Sides above 4096 return CMBL_ERR_SHAPE.
  *   - a handle is used by one host thread at a time; different contexts are independent.
  *   - calls are asynchronous on the context's stream unless they return host values (`*_host` outputs), i.e. every
  *     field-to-field entry point is already the `_async` form; cmbl_ctx_synchronize() waits for the stream.
