@@ -94,6 +94,24 @@ template <int RT, int RPW> struct WorkRows {
   }
 };
 
+// External twiddles of a stage, W^(j k) for k = 1..r-1.  CMBL_TW_REC = 1 (single precision only): ONE table read, W^j, and the powers by
+// multiplication (depth-3 product tree) instead of r-1 table reads -- the transforms are bound by LDS throughput at the CU and the
+// twiddle reads are a quarter of a radix-8 stage's LDS traffic; the products cost 2 packed instructions each on a VALU that has room.
+#ifndef CMBL_TW_REC
+#define CMBL_TW_REC 1
+#endif
+template <typename T, int r, typename V>
+__device__ __forceinline__ void stage_twiddles(const cx<T>* __restrict__ tw, int j, int sh, V (&w)[r]) {
+  if constexpr ((CMBL_TW_REC == 2 || (CMBL_TW_REC == 1 && sizeof(T) == 4)) && r >= 4) {
+    w[1] = vload(tw + (j << sh));
+#pragma unroll
+    for (int k = 2; k < r; ++k) w[k] = vmul(w[k >> 1], w[k - (k >> 1)]);
+  } else {
+#pragma unroll
+    for (int k = 1; k < r; ++k) w[k] = vload(tw + ((j * k) << sh));
+  }
+}
+
 // One fused DIF stage = LG radix-2 levels with spans h = 2^LGH (top) ... hmin = 2^(LGH-LG+1), evaluated as ONE r-point DFT per
 // thread (r = 2^LG, fft_core.hpp) followed by the external twiddles: with a[m] = x[b0 + m hmin], n = r hmin,
 //     x[b0 + brev_LG(k) hmin] <- W_n^(j k) * sum_m a[m] W_r^(m k),     W_n = exp(-2 pi i / n),  j = b0 mod hmin
@@ -108,11 +126,13 @@ __device__ __forceinline__ void dif_stage(cx<T>* __restrict__ s, const W& wk, co
     V v[r];
 #pragma unroll
     for (int m = 0; m < r; ++m) v[m] = vload(p + pad(m << lghmin));     // pad(base + m*hmin) == pad(base) + pad(m*hmin) here
+    V w[r];
+    if constexpr (hmin > 1) stage_twiddles<T, r>(tw, j, sh, w);
     dft<T, LG, false>(v);
 #pragma unroll
     for (int k = 0; k < r; ++k) {
       V x = v[dft_loc<LG>(k)];
-      if (hmin > 1 && k > 0) x = vmul(x, vload(tw + ((j * k) << sh)));
+      if (hmin > 1 && k > 0) x = vmul(x, w[k]);
       vstore(p + pad(brevc<LG>(k) << lghmin), x);
     }
   });
@@ -131,12 +151,13 @@ __device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, const W& wk, co
     const int blk = rr >> LGH, j = rr & (hmin - 1);
     const int b0 = (blk << (LGH + LG)) + j;                          // logical (unpadded) index of element m = 0
     cx<T>* p = s + seq * LD + pad(b0);
-    V v[r];
+    V v[r], w[r];
+    if constexpr (hmin > 1) stage_twiddles<T, r>(tw, j, sh, w);
 #pragma unroll
     for (int k = 0; k < r; ++k) {                                    // frequency k of the group sits at position brev(k)
       const int m = brevc<LG>(k);
       V x = vfrom(pre(*(p + pad(m << LGH)), b0 + (m << LGH)));       // pre: pointwise op fused into the first stage
-      if (hmin > 1 && k > 0) x = vmulc(x, vload(tw + ((j * k) << sh)));
+      if (hmin > 1 && k > 0) x = vmulc(x, w[k]);
       v[k] = x;
     }
     dft<T, LG, true>(v);
@@ -146,15 +167,38 @@ __device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, const W& wk, co
   wk.sync();
 }
 
+// Last forward stage + pointwise operation + first inverse stage in ONE LDS round trip.  The last DIF stage (spans 2^(LG-1) .. 1) and
+// the first DIT stage act on the same 2^LG adjacent slots, so a forward / multiply / inverse chain keeps them in registers:
+//     v = DFT_r(slots b0 .. b0+r-1);  X_k (at slot b0 + brev(k)) <- mid(seq, slot, X_k);  slots <- IDFT_r(X)
+// (one stage's LDS traffic and one stage's latency less per chain; LG = levels of the LAST stage of the schedule).
+template <typename T, int LD, int LGN, int LG, typename W, typename MID>
+__device__ __forceinline__ void dif_mid_dit_stage(cx<T>* __restrict__ s, const W& wk, MID&& mid) {
+  using V = typename vreg<T>::type;
+  constexpr int r = 1 << LG, lgnb = LGN - LG;
+  wk.template each<lgnb>([&](int seq, int rr) {
+    cx<T>* p = s + seq * LD + pad(rr << LG);                          // r <= 16 adjacent slots: pad(b0 + m) == pad(b0) + m
+    V v[r], u[r];
+#pragma unroll
+    for (int m = 0; m < r; ++m) v[m] = vload(p + m);
+    dft<T, LG, false>(v);
+#pragma unroll
+    for (int k = 0; k < r; ++k) u[k] = mid(seq, (rr << LG) + brevc<LG>(k), v[dft_loc<LG>(k)]);
+    dft<T, LG, true>(u);
+#pragma unroll
+    for (int m = 0; m < r; ++m) vstore(p + m, u[dft_loc<LG>(m)]);
+  });
+  wk.sync();
+}
 // ---- forward, DIF: natural -> bit-reversed -------------------------------------------------------
 // SKIP = 1: the top level (span N/2) is done by the caller; the stages cover the remaining LGN - 1 levels, i.e. both halves
-template <typename T, int LD, int LGN, int LGNTW, int MAXLG, int SKIP, typename W, int I = 0>
+// DROP = 1: the last stage is left to the caller (dif_mid_dit_stage fuses it with the first inverse stage)
+template <typename T, int LD, int LGN, int LGNTW, int MAXLG, int SKIP, typename W, int I = 0, int DROP = 0>
 __device__ __forceinline__ void fft_dif_w(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw) {
-  if constexpr (I < num_stages(LGN - SKIP, MAXLG)) {
+  if constexpr (I < num_stages(LGN - SKIP, MAXLG) - DROP) {
     constexpr int LG = stage_lg(LGN - SKIP, I, MAXLG);
     constexpr int LGH = levels_after(LGN - SKIP, I, MAXLG) + LG - 1;      // top span index of this stage
     dif_stage<T, LD, LGN, LGNTW, LGH, LG>(s, wk, tw);
-    fft_dif_w<T, LD, LGN, LGNTW, MAXLG, SKIP, W, I + 1>(s, wk, tw);
+    fft_dif_w<T, LD, LGN, LGNTW, MAXLG, SKIP, W, I + 1, DROP>(s, wk, tw);
   }
 }
 template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4>
@@ -176,6 +220,15 @@ __device__ __forceinline__ void fft_dit_w(cx<T>* __restrict__ s, const W& wk, co
 template <typename T, int NT, int LD, int LGN, int LGNTW, int MAXLG = 4, typename PRE = NoPre>
 __device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T>* __restrict__ tw, PRE pre = PRE()) {
   fft_dit_w<T, LD, LGN, LGNTW, MAXLG, 0, WorkCoop<NT>, PRE>(s, WorkCoop<NT>{S}, tw, pre);
+}
+
+// forward transform, mid(seq, slot, value) on the bit-reversed spectrum, inverse transform (unnormalised), SKIP top levels left to the caller
+template <typename T, int LD, int LGN, int LGNTW, int MAXLG, int SKIP, typename W, typename MID>
+__device__ __forceinline__ void fft_dif_mid_dit_w(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw, MID&& mid) {
+  constexpr int NS = num_stages(LGN - SKIP, MAXLG);
+  fft_dif_w<T, LD, LGN, LGNTW, MAXLG, SKIP, W, 0, 1>(s, wk, tw);
+  dif_mid_dit_stage<T, LD, LGN, stage_lg(LGN - SKIP, NS - 1, MAXLG)>(s, wk, mid);
+  fft_dit_w<T, LD, LGN, LGNTW, MAXLG, SKIP, W, NoPre, NS - 2>(s, wk, tw);
 }
 
 // ---- packed real <-> half spectrum, in place on the tile ------------------------------------------

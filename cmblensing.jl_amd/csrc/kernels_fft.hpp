@@ -168,6 +168,13 @@ __device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx
 #ifndef CMBL_COL_SPLIT
 #define CMBL_COL_SPLIT 1
 #endif
+// threads that run the sub-stages of one column of a packed-real (M-point) transform: NT/C (two wavefronts, one per half-column; a
+// radix-8 stage then has 32 butterflies per wave, half the lanes idle) or 64 (one wavefront per column, every lane busy, the other
+// wavefronts of the workgroup wait at the barrier and leave the LDS / VALU pipes to the co-resident workgroup)
+#ifndef CMBL_MPT_RT
+#define CMBL_MPT_RT 0
+#endif
+template <int NT, int C> constexpr int mpt_rt() { return CMBL_MPT_RT ? CMBL_MPT_RT : NT / C; }
 template <int R, int NT, int LGM> struct PairMap {
   static constexpr int M = 1 << LGM, MH = M >> 1, C = (R * NT) >> LGM;
   static constexpr bool split = CMBL_COL_SPLIT && (R % 2 == 0) && (NT % MH == 0) && (NT % C == 0) && (NT / C == 64 || NT / C == 128) && M >= 32;
@@ -244,7 +251,7 @@ __device__ __forceinline__ void mpt_inverse_read(cx<T>* s, const cx<T>* tw, T sc
   using V = typename vreg<T>::type;
   constexpr int M = 1 << LGM, MH = M >> 1, C = PM::C;
   if constexpr (PM::split) {
-    fft_dit_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<NT / C, C>{1, C}, tw);
+    fft_dit_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<mpt_rt<NT, C>(), C>{1, C}, tw);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < R; i += 2) {
@@ -278,7 +285,7 @@ __device__ __forceinline__ void mpt_write_forward(cx<T>* s, const cx<T>* tw, ZF&
       vstore(p + pad(MH), vmul(vsub(za, zb), vload(tw + 2 * jj)));
     }
     __syncthreads();
-    fft_dif_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<NT / C, C>{1, C}, tw);
+    fft_dif_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<mpt_rt<NT, C>(), C>{1, C}, tw);
     __syncthreads();
   } else {
 #pragma unroll
@@ -590,15 +597,16 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   __syncthreads();
   CMBL_XSTAMP(1);
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
-  if (MODE == 0 || MODE == 2) fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
+  if (MODE == 0) fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
   CMBL_XSTAMP(2);
   if (MODE == 2) {
-    // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
+    // i*lx/Nx multiply between the last forward and the first inverse butterfly, in registers: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
     const T dl = dlx_over_Nx;
-    fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](cx<T> v, int i) {
+    fft_dif_mid_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](int, int i, typename vreg<T>::type v) {
       const int kx = brevc<LGNX>(i);
       const T l = dl * T(kx < (Nx >> 1) ? kx : kx - Nx);
-      return mk<T>(-l * v.y, l * v.x);
+      const cx<T> c = vcx(v);
+      return vfrom(mk<T>(-l * c.y, l * c.x));
     });
   }
   if (MODE == 1) fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);

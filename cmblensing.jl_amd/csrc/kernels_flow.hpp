@@ -317,49 +317,58 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   }
   twr.commit(tw);
   __syncthreads();
-  fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
-  // RK update: wave w of a row updates the slots of half w (the ones it transformed; F layout: contiguous in x)
-  const int row = threadIdx.x / ROW_RT, w = (threadIdx.x % ROW_RT) >> 6, lane = threadIdx.x & 63;
-  const T inv = T(1) / T(Nx);
-  if (row < rg.nr) {
-    const size_t g0 = ((size_t)rg.sl * a.Nyh + rg.ky0 + row) * Nx + w * NH;
-    cx<T>* sr = s + row * LD + pad(w * NH); const cx<T>* sr2 = s2 + row * LD + pad(w * NH);
-    if constexpr (NH >= 64) {
-      constexpr int CH = PF > 8 ? 8 : PF;                     // state loads in flight per thread: CH values of Y0 and of acc
-      for (int i0 = 0; i0 < PF; i0 += CH) {
-        cx<T> y0[CH], acc[CH]; T lxr[CH];
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const int x = lane + (i0 + i) * 64;
-          y0[i] = a.Y0[g0 + x];
-          acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[g0 + x];
-          lxr[i] = a.lx_r[w * NH + x];
-        }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const int x = lane + (i0 + i) * 64, si = pad(x);
-          const cx<T> kv = mul_il(sr[si], lxr[i]) + sr2[si];
-          const cx<T> fn = rk_update(a.rk, kv, y0[i], acc[i]);
-          if (a.rk.stage == 4) a.Y0[g0 + x] = y0[i]; else a.acc[g0 + x] = acc[i];
-          sr[si] = inv * fn;
-        }
-      }
-    } else {
-      for (int x = lane; x < NH; x += 64) {
-        const int si = pad(x);
-        const cx<T> kv = mul_il(sr[si], a.lx_r[w * NH + x]) + sr2[si];
-        cx<T> y0 = a.Y0[g0 + x];
-        cx<T> acc = a.rk.stage == 1 ? mk<T>(0, 0) : a.acc[g0 + x];
-        const cx<T> fn = rk_update(a.rk, kv, y0, acc);
-        if (a.rk.stage == 4) a.Y0[g0 + x] = y0; else a.acc[g0 + x] = acc;
-        sr[si] = inv * fn;
-      }
-    }
-  }
-  if (a.rk.last) return;
+  // all forward stages but the last on both row sets; the last forward butterfly of Wx and Wy, the velocity  k = i lx Wx^ + Wy^,
+  // the RK update of the Fourier state and the first inverse butterfly of the next stage input then share one register phase:
+  // a butterfly owns r adjacent slots = r adjacent x of the F layout (64 bytes of Y0 / acc per lane, requested before the LDS reads)
+  using V = typename vreg<T>::type;
+  constexpr int XLG = row_xlg(LGNX), NS = num_stages(LGNX - 1, XLG), LG = stage_lg(LGNX - 1, NS - 1, XLG), r = 1 << LG;
+  constexpr int VE = 16 / (int)sizeof(cx<T>), NV = r / VE;
+  fft_dif_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW>, 0, 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
+  const T inv = T(1) / T(Nx);
+  const bool last = a.rk.last;
+  wk.template each<LGNX - LG>([&](int row, int rr) {
+    const int b0 = rr << LG;
+    const size_t g0 = ((size_t)rg.sl * a.Nyh + rg.ky0 + row) * Nx + b0;
+    CxVec<T> y0v[NV], acv[NV];
+    T lxr[r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      y0v[i] = *reinterpret_cast<const CxVec<T>*>(a.Y0 + g0 + i * VE);
+      if (a.rk.stage != 1) acv[i] = *reinterpret_cast<const CxVec<T>*>(a.acc + g0 + i * VE);
+    }
+#pragma unroll
+    for (int i = 0; i < r; ++i) lxr[i] = a.lx_r[b0 + i];
+    cx<T>* p1 = s + row * LD + pad(b0);
+    const cx<T>* p2 = s2 + row * LD + pad(b0);
+    V va[r], vb[r], u[r];
+#pragma unroll
+    for (int m = 0; m < r; ++m) { va[m] = vload(p1 + m); vb[m] = vload(p2 + m); }
+    dft<T, LG, false>(va);
+    dft<T, LG, false>(vb);
+#pragma unroll
+    for (int k = 0; k < r; ++k) {
+      const int j = brevc<LG>(k);                               // X_k sits at slot b0 + j
+      const cx<T> kv = mul_il(vcx(va[dft_loc<LG>(k)]), lxr[j]) + vcx(vb[dft_loc<LG>(k)]);
+      cx<T> y0 = y0v[j / VE].v[j % VE], acc = a.rk.stage == 1 ? mk<T>(0, 0) : acv[j / VE].v[j % VE];
+      const cx<T> fn = rk_update(a.rk, kv, y0, acc);
+      y0v[j / VE].v[j % VE] = y0; acv[j / VE].v[j % VE] = acc;
+      u[k] = vfrom(inv * fn);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (a.rk.stage == 4) *reinterpret_cast<CxVec<T>*>(a.Y0 + g0 + i * VE) = y0v[i];
+      else *reinterpret_cast<CxVec<T>*>(a.acc + g0 + i * VE) = acv[i];
+    }
+    if (!last) {
+      dft<T, LG, true>(u);
+#pragma unroll
+      for (int m = 0; m < r; ++m) vstore(p1 + m, u[dft_loc<LG>(m)]);
+    }
+  });
+  if (last) return;
   wk.sync();
-  fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
+  fft_dit_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW>, NoPre, NS - 2>(s, wk, tw);
   __syncthreads();
   rows_store_mixed_dit<T, LGNX, RPW>(s, a.Hnext + mo, tw, NyhP, rg.ky0, rg.nr, T(1));
 }
@@ -390,12 +399,11 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
   twr.commit(tw);
   __syncthreads();
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
-  fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
-  // i*lx/Nx multiply fused into the loads of the first inverse stage: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
+  // i*lx/Nx multiply between the last forward and the first inverse butterfly, in registers: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
   const T dl = g.dlx_over_Nx;
-  fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](cx<T> v, int i) {
+  fft_dif_mid_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](int, int i, typename vreg<T>::type v) {
     const int kx = brevc<LGNX>(i);
-    return mul_il(v, dl * T(kx < (Nx >> 1) ? kx : kx - Nx));
+    return vfrom(mul_il(vcx(v), dl * T(kx < (Nx >> 1) ? kx : kx - Nx)));
   });
   __syncthreads();
   rows_store_mixed_dit<T, LGNX, RPW>(s, g.out + mo, tw, NyhP, rg.ky0, rg.nr, T(1));
