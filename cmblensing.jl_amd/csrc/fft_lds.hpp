@@ -98,7 +98,7 @@ template <int RT, int RPW> struct WorkRows {
 // multiplication (depth-3 product tree) instead of r-1 table reads -- the transforms are bound by LDS throughput at the CU and the
 // twiddle reads are a quarter of a radix-8 stage's LDS traffic; the products cost 2 packed instructions each on a VALU that has room.
 #ifndef CMBL_TW_REC
-#define CMBL_TW_REC 1
+#define CMBL_TW_REC 2
 #endif
 template <typename T, int r, typename V>
 __device__ __forceinline__ void stage_twiddles(const cx<T>* __restrict__ tw, int j, int sh, V (&w)[r]) {
@@ -169,7 +169,7 @@ __device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, const W& wk, co
 
 // Last forward stage + pointwise operation + first inverse stage in ONE LDS round trip.  The last DIF stage (spans 2^(LG-1) .. 1) and
 // the first DIT stage act on the same 2^LG adjacent slots, so a forward / multiply / inverse chain keeps them in registers:
-//     v = DFT_r(slots b0 .. b0+r-1);  X_k (at slot b0 + brev(k)) <- mid(seq, slot, X_k);  slots <- IDFT_r(X)
+//     v = DFT_r(slots b0 .. b0+r-1);  X_k (at slot b0 + j, j = brev(k)) <- mid(seq, b0, j, X_k);  slots <- IDFT_r(X)
 // (one stage's LDS traffic and one stage's latency less per chain; LG = levels of the LAST stage of the schedule).
 template <typename T, int LD, int LGN, int LG, typename W, typename MID>
 __device__ __forceinline__ void dif_mid_dit_stage(cx<T>* __restrict__ s, const W& wk, MID&& mid) {
@@ -182,7 +182,7 @@ __device__ __forceinline__ void dif_mid_dit_stage(cx<T>* __restrict__ s, const W
     for (int m = 0; m < r; ++m) v[m] = vload(p + m);
     dft<T, LG, false>(v);
 #pragma unroll
-    for (int k = 0; k < r; ++k) u[k] = mid(seq, (rr << LG) + brevc<LG>(k), v[dft_loc<LG>(k)]);
+    for (int k = 0; k < r; ++k) u[k] = mid(seq, rr << LG, brevc<LG>(k), v[dft_loc<LG>(k)]);   // slot = b0 + j, j a constant after unrolling
     dft<T, LG, true>(u);
 #pragma unroll
     for (int m = 0; m < r; ++m) vstore(p + m, u[dft_loc<LG>(m)]);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void fft_dit(cx<T>* __restrict__ s, int S, const cx<T
   fft_dit_w<T, LD, LGN, LGNTW, MAXLG, 0, WorkCoop<NT>, PRE>(s, WorkCoop<NT>{S}, tw, pre);
 }
 
-// forward transform, mid(seq, slot, value) on the bit-reversed spectrum, inverse transform (unnormalised), SKIP top levels left to the caller
+// forward transform, mid(seq, b0, j, value) on the bit-reversed spectrum, inverse transform (unnormalised), SKIP top levels left to the caller
 template <typename T, int LD, int LGN, int LGNTW, int MAXLG, int SKIP, typename W, typename MID>
 __device__ __forceinline__ void fft_dif_mid_dit_w(cx<T>* __restrict__ s, const W& wk, const cx<T>* __restrict__ tw, MID&& mid) {
   constexpr int NS = num_stages(LGN - SKIP, MAXLG);

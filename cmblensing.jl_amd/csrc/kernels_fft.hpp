@@ -30,6 +30,8 @@ namespace cmbl {
 // debug builds (-DCMBL_STAMPS): per-workgroup phase timestamps, read back with cmbl_debug_stamps (tools/gpu_stamps.py)
 #ifdef CMBL_STAMPS
 __device__ unsigned long long g_stamps[8192 * 16];
+#endif
+#if defined(CMBL_STAMPS) && !defined(CMBL_STAMPS_ROWS)      // CMBL_STAMPS_ROWS: only k_delta_rows writes (its own slots 14 / 15)
 #define CMBL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = clock64(); } while (0)
 // slots 14 / 15: entry / exit on the 100 MHz wall clock, which all XCDs share (launch timeline across the chip)
 #define CMBL_WSTAMP(i) do { if (threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
@@ -64,6 +66,22 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) { return (nb & 7) ? b : (
 constexpr int MIXW = 4, LGMIXW = 2;
 __host__ __device__ constexpr int mixed_rows(int Nyh) { return (Nyh + 3) & ~3; }
 __device__ __forceinline__ size_t mix_idx(int ky, int x, int NyhP) { return ((size_t)(x >> LGMIXW) * NyhP + ky) * MIXW + (x & (MIXW - 1)); }
+// Addressing: uniform 64-bit base (scalar registers) + 32-bit unsigned byte offset (one vector register) is the form global_load /
+// global_store take directly, with no 64-bit vector arithmetic per access (the fused kernels are partly VALU-issue bound, and a
+// third of their vector instructions was address arithmetic).  Offsets inside one slice of a field stay far below 4 GB.
+template <typename V> __device__ __forceinline__ const V& at32(const V* base, unsigned idx) {
+  return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(V));
+}
+template <typename V> __device__ __forceinline__ V& at32(V* base, unsigned idx) {
+  return *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(V));
+}
+// A column tile of C = MIXW columns is ONE contiguous block of the mixed layout: entry (ky, c) of the tile at x0 sits at
+// tile_base(g, x0) + ky * MIXW + c.  Other widths go through mix_idx.
+template <typename V> __device__ __forceinline__ V* tile_base(V* g, int x0, int NyhP) { return g + (size_t)(x0 >> LGMIXW) * NyhP * MIXW; }
+template <int C> __device__ __forceinline__ unsigned tile_off(int ky, int c, int x0, int NyhP) {
+  if constexpr (C == MIXW) return (unsigned)(ky * MIXW + c);
+  else return (unsigned)(mix_idx(ky, x0 + c, NyhP) - (size_t)(x0 >> LGMIXW) * NyhP * MIXW);
+}
 
 // ---------------------------------------------------------------------------------------------
 // ref <-> F  (transpose + bit reversal of x), V = cx<T> or T.   grid (Nx/32, ceil(Nyh/32), slices), block 256
@@ -142,10 +160,11 @@ template <typename T, int NT, int LGM, int LGC> struct TileStage {           // 
   static constexpr int M = 1 << LGM, C = 1 << LGC, TOT = C * (M + 1), K = (TOT + NT - 1) / NT;
   cx<T> v[K];
   __device__ __forceinline__ void issue(const cx<T>* __restrict__ g /*slice base*/, int Nx, int x0) {
+    const cx<T>* tg = tile_base(g, x0, mixed_rows(M + 1));
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int e = threadIdx.x + i * NT;
-      if (e < TOT) v[i] = g[mix_idx(e >> LGC, x0 + (e & (C - 1)), mixed_rows(M + 1))];
+      if (e < TOT) v[i] = at32(tg, tile_off<C>(e >> LGC, e & (C - 1), x0, mixed_rows(M + 1)));
     }
   }
   template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
@@ -159,9 +178,10 @@ template <typename T, int NT, int LGM, int LGC> struct TileStage {           // 
 template <typename T, int NT, int LD, int LGM, int LGC>
 __device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, int Nx, int x0) {
   constexpr int M = 1 << LGM, C = 1 << LGC;
+  cx<T>* tg = tile_base(g, x0, mixed_rows(M + 1));
   for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
     const int c = e & (C - 1), k = e >> LGC;
-    g[mix_idx(k, x0 + c, mixed_rows(M + 1))] = s[c * LD + hslot<LGM>(k)];
+    at32(tg, tile_off<C>(k, c, x0, mixed_rows(M + 1))) = s[c * LD + hslot<LGM>(k)];
   }
 }
 
@@ -172,7 +192,7 @@ __device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx
 // radix-8 stage then has 32 butterflies per wave, half the lanes idle) or 64 (one wavefront per column, every lane busy, the other
 // wavefronts of the workgroup wait at the barrier and leave the LDS / VALU pipes to the co-resident workgroup)
 #ifndef CMBL_MPT_RT
-#define CMBL_MPT_RT 0
+#define CMBL_MPT_RT 64
 #endif
 template <int NT, int C> constexpr int mpt_rt() { return CMBL_MPT_RT ? CMBL_MPT_RT : NT / C; }
 template <int R, int NT, int LGM> struct PairMap {
@@ -196,12 +216,13 @@ template <typename T, int NT, int LGM, int LGC> struct HalfStage {
   static constexpr int M = 1 << LGM, C = 1 << LGC, NP = (M >> 1) + 1, TOT = C * NP, K = (TOT + NT - 1) / NT, NyhP = mixed_rows(M + 1);
   cx<T> a[K], b[K], w[K];
   __device__ __forceinline__ void issue(const cx<T>* __restrict__ g /*slice base*/, const cx<T>* __restrict__ twg, int x0) {
+    const cx<T>* tg = tile_base(g, x0, NyhP);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int u = threadIdx.x + i * NT;
       if (TOT % NT == 0 || u < TOT) {
-        const int k = u >> LGC, x = x0 + (u & (C - 1));
-        a[i] = g[mix_idx(k, x, NyhP)]; b[i] = g[mix_idx(M - k, x, NyhP)]; w[i] = twg[k];
+        const int k = u >> LGC, c = u & (C - 1);
+        a[i] = at32(tg, tile_off<C>(k, c, x0, NyhP)); b[i] = at32(tg, tile_off<C>(M - k, c, x0, NyhP)); w[i] = at32(twg, (unsigned)k);
       }
     }
   }
@@ -227,18 +248,19 @@ template <typename T, int NT, int LGM, int LGC> struct HalfStage {
 template <typename T, int NT, int LD, int LGM, int LGC>
 __device__ __forceinline__ void half_store(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, const cx<T>* __restrict__ tw, int x0) {
   constexpr int M = 1 << LGM, C = 1 << LGC, NP = (M >> 1) + 1, NyhP = mixed_rows(M + 1);
+  cx<T>* tg = tile_base(g, x0, NyhP);
   for (int u = threadIdx.x; u < C * NP; u += NT) {
-    const int k = u >> LGC, k2 = M - k, x = x0 + (u & (C - 1));
-    const cx<T>* p = s + (u & (C - 1)) * LD;
+    const int k = u >> LGC, k2 = M - k, c = u & (C - 1);
+    const cx<T>* p = s + c * LD;
     if (k == 0) {
       const cx<T> z = p[0];
-      g[mix_idx(0, x, NyhP)] = mk<T>(z.x + z.y, 0); g[mix_idx(M, x, NyhP)] = mk<T>(z.x - z.y, 0);
+      at32(tg, tile_off<C>(0, c, x0, NyhP)) = mk<T>(z.x + z.y, 0); at32(tg, tile_off<C>(M, c, x0, NyhP)) = mk<T>(z.x - z.y, 0);
     } else {
       const cx<T> a = p[pad(brevc<LGM>(k))], b = p[pad(brevc<LGM>(k2))];
       const cx<T> e = mk<T>(T(0.5) * (a.x + b.x), T(0.5) * (a.y - b.y)), o = mk<T>(T(0.5) * (a.x - b.x), T(0.5) * (a.y + b.y));
       const cx<T> wo = mul_mi(o * tw[k]);
-      g[mix_idx(k, x, NyhP)] = e + wo;
-      if (k2 != k) g[mix_idx(k2, x, NyhP)] = conj(e - wo);
+      at32(tg, tile_off<C>(k, c, x0, NyhP)) = e + wo;
+      if (k2 != k) at32(tg, tile_off<C>(k2, c, x0, NyhP)) = conj(e - wo);
     }
   }
 }
@@ -307,13 +329,15 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
   cx<T> X[K], Y[K];
   T l[K];
   __device__ __forceinline__ void issue(const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY, const T* __restrict__ ly, int Nx, int x0) {
+    const cx<T>* tX = tile_base(gX, x0, mixed_rows(M + 1));
+    const cx<T>* tY = tile_base(gY, x0, mixed_rows(M + 1));
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int e = threadIdx.x + i * NT;
       if (e < TOT) {
         const int k = e >> LGC;
-        const size_t gi = mix_idx(k, x0 + (e & (C - 1)), mixed_rows(M + 1));
-        X[i] = gX[gi]; Y[i] = gY[gi]; l[i] = ly[k];
+        const unsigned gi = tile_off<C>(k, e & (C - 1), x0, mixed_rows(M + 1));
+        X[i] = at32(tX, gi); Y[i] = at32(tY, gi); l[i] = at32(ly, (unsigned)k);
       }
     }
   }
@@ -366,55 +390,80 @@ template <typename T> __host__ __device__ constexpr int row_rpw(int lgnx, int na
     if (((size_t)(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024) return rpw;
   return 0;
 }
+// Block -> (slice, first row).  nblk = row groups of the launch (slices * ceil(Nyh / RPW)).  The full groups of all slices come
+// first and the short ones (Nyh = Ny/2 + 1 leaves one Nyquist row per slice) LAST: the launches are one residency wave, so the
+// blocks beyond the CU count share a CU with an earlier block -- a one-row group there costs its host little, a second full group
+// would slow both down by the ratio of their VALU work (measured with in-kernel stamps: 6.3k instead of 3.9k cycles per transform
+// chain, and the launch ends with its slowest workgroup).
 struct RowGroup { int sl, ky0, nr; };
-template <int RPW> __device__ __forceinline__ RowGroup row_group(long blk, int Nyh) {
-  const int G = (Nyh + RPW - 1) / RPW;
+template <int RPW> __device__ __forceinline__ RowGroup row_group(unsigned blk, int Nyh, unsigned nblk) {      // 32-bit: one short division sequence
+  const unsigned G = (unsigned)(Nyh + RPW - 1) / RPW, Gf = (unsigned)Nyh / RPW, rem = (unsigned)Nyh - Gf * RPW;
+  const unsigned slices = nblk / G, nfull = slices * Gf;
   RowGroup g;
-  g.sl = (int)(blk / G); g.ky0 = (int)(blk % G) * RPW; g.nr = Nyh - g.ky0 < RPW ? Nyh - g.ky0 : RPW;
+  if (blk < nfull) { const unsigned sl = blk / Gf; g.sl = (int)sl; g.ky0 = (int)(blk - sl * Gf) * RPW; g.nr = RPW; }
+  else { g.sl = (int)(blk - nfull); g.ky0 = (int)Gf * RPW; g.nr = (int)rem; }
   return g;
 }
 // 16-byte global accesses: 2 single-precision or 1 double-precision complex values
 template <typename T> struct alignas(16) CxVec { cx<T> v[16 / sizeof(cx<T>)]; };
+template <typename T> __device__ __forceinline__ const CxVec<T>& vec32(const cx<T>* base, unsigned idx) {
+  return *reinterpret_cast<const CxVec<T>*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(cx<T>));
+}
+template <typename T> __device__ __forceinline__ CxVec<T>& vec32(cx<T>* base, unsigned idx) {
+  return *reinterpret_cast<CxVec<T>*>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(cx<T>));
+}
 
 // mixed layout (slice bases g[a]) -> the NA row sets in LDS, through the top DIF level:
 //   s[a] <- x[a] + x[a + N/2],   s[a + N/2] <- (x[a] - x[a + N/2]) * W_N^a        (twg: the global twiddle table exp(-2 pi i k / N))
 // All loads of the thread are issued before the first LDS store.
 // (CMBL_ROW_ROT lets every workgroup walk x/4 from its own starting point, so that the workgroups of a launch do not touch the same
 // 16 KB window at the same moment; measured on MI355X: no difference, the default is no rotation)
-template <typename T, int LGNX, int RPW, int NA>
-__device__ __forceinline__ void rows_load_mixed_dif(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr) {
+template <typename T, int LGNX, int RPW, int NA> struct RowsMixedStage {
   using V = typename vreg<T>::type;
-  constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW);
-  constexpr int TOT = RPW * NH / VE, K = (TOT + NT - 1) / NT;
-  const int rot = CMBL_ROW_ROT(ky0);
+  static constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW);
+  static constexpr int TOT = RPW * NH / VE, K = (TOT + NT - 1) / NT;
   CxVec<T> va[NA][K], vb[NA][K], w[K];
+  __device__ __forceinline__ void issue(const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr) {
+    const int rot = CMBL_ROW_ROT(ky0);
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
-    if ((TOT % NT == 0 || u < TOT) && r < nr) {
-      w[i] = *reinterpret_cast<const CxVec<T>*>(twg + xt * MIXW + c);
+    for (int i = 0; i < K; ++i) {
+      const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+      if ((TOT % NT == 0 || u < TOT) && r < nr) {
+        w[i] = vec32(twg, (unsigned)(xt * MIXW + c));
+        const unsigned o = (unsigned)((xt * NyhP + r) * MIXW + c), ob = (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c);
 #pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        va[a][i] = *reinterpret_cast<const CxVec<T>*>(g[a] + ((size_t)xt * NyhP + ky0 + r) * MIXW + c);
-        vb[a][i] = *reinterpret_cast<const CxVec<T>*>(g[a] + ((size_t)(xt + NH / MIXW) * NyhP + ky0 + r) * MIXW + c);
+        for (int a = 0; a < NA; ++a) {
+          const cx<T>* ga = g[a] + (size_t)ky0 * MIXW;                    // uniform part of the address
+          va[a][i] = vec32(ga, o);
+          vb[a][i] = vec32(ga, ob);
+        }
       }
     }
   }
+  // row set a -> the LDS rows at s
+  __device__ __forceinline__ void commit(int a, cx<T>* __restrict__ s, int ky0, int nr) const {
+    const int rot = CMBL_ROW_ROT(ky0);
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
-    if ((TOT % NT == 0 || u < TOT) && r < nr) {
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
+    for (int i = 0; i < K; ++i) {
+      const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+      if ((TOT % NT == 0 || u < TOT) && r < nr) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
           const V xa = vfrom(va[a][i].v[e]), xb = vfrom(vb[a][i].v[e]);
-          cx<T>* p = s[a] + r * LD + pad(xt * MIXW + c) + e;              // c even: pad(x + 1) == pad(x) + 1; pad(x + N/2) == pad(x) + pad(N/2)
+          cx<T>* p = s + r * LD + pad(xt * MIXW + c) + e;                 // c even: pad(x + 1) == pad(x) + 1; pad(x + N/2) == pad(x) + pad(N/2)
           vstore(p, vadd(xa, xb));
           vstore(p + pad(NH), vmul(vsub(xa, xb), vfrom(w[i].v[e])));
         }
+      }
     }
   }
+};
+template <typename T, int LGNX, int RPW, int NA>
+__device__ __forceinline__ void rows_load_mixed_dif(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr) {
+  RowsMixedStage<T, LGNX, RPW, NA> st;
+  st.issue(g, twg, NyhP, ky0, nr);
+#pragma unroll
+  for (int a = 0; a < NA; ++a) st.commit(a, s[a], ky0, nr);
 }
 // LDS rows -> mixed layout through the last DIT level:  x[a] = u[a] + conj(W_N^a) v[a],  x[a + N/2] = u[a] - conj(W_N^a) v[a]  with
 // u, v the two halves of the row in LDS; values scaled by `scale`.  tw: the LDS twiddle table.
@@ -433,8 +482,9 @@ __device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s
         const V uu = vload(p), t = vmulc(vload(p + pad(NH)), vload(tw + xt * MIXW + c + e));
         oa.v[e] = vcx(vscale(vadd(uu, t), scale)); ob.v[e] = vcx(vscale(vsub(uu, t), scale));
       }
-      *reinterpret_cast<CxVec<T>*>(g + ((size_t)xt * NyhP + ky0 + r) * MIXW + c) = oa;
-      *reinterpret_cast<CxVec<T>*>(g + ((size_t)(xt + NH / MIXW) * NyhP + ky0 + r) * MIXW + c) = ob;
+      cx<T>* gk = g + (size_t)ky0 * MIXW;                                  // uniform part of the address
+      vec32(gk, (unsigned)((xt * NyhP + r) * MIXW + c)) = oa;
+      vec32(gk, (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c)) = ob;
     }
   }
 }
@@ -446,7 +496,7 @@ __device__ __forceinline__ void rows_load_F(cx<T>* __restrict__ s, const cx<T>* 
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int u = threadIdx.x + i * NT, r = (u * VE) >> LGNX;
-    if ((TOT % NT == 0 || u < TOT) && r < nr) v[i] = *reinterpret_cast<const CxVec<T>*>(g + (size_t)u * VE);
+    if ((TOT % NT == 0 || u < TOT) && r < nr) v[i] = vec32(g, (unsigned)(u * VE));
   }
 #pragma unroll
   for (int i = 0; i < K; ++i) {
@@ -466,9 +516,20 @@ __device__ __forceinline__ void rows_store_F(const cx<T>* __restrict__ s, cx<T>*
       CxVec<T> v;
 #pragma unroll
       for (int e = 0; e < VE; ++e) v.v[e] = scale * s[r * LD + pad(x) + e];
-      *reinterpret_cast<CxVec<T>*>(g + (size_t)u * VE) = v;
+      vec32(g, (unsigned)(u * VE)) = v;
     }
   }
+}
+// i * lx * v for the value at slot b0 + j of a bit-reversed row (kx = bitrev(slot), lx = dl * signed kx); b0 = first slot of a
+// butterfly of the last stage (low LG bits zero), j < 2^LG a compile-time constant after unrolling.  bitrev(b0 + j) = bitrev(b0) +
+// bitrev(j) without carries, and bitrev(b0) < Nx / 2^LG: one bit reversal and one conversion per butterfly, an exact float addition
+// of a constant and the multiply per slot (the same lx, bit for bit, as dl * float(signed kx)).
+template <typename T, int LGNX, int LG> __device__ __forceinline__ cx<T> mul_il_slot(cx<T> v, int b0, int j, T dl) {
+  constexpr int Nx = 1 << LGNX;
+  const T k0 = T(brevc<LGNX>(b0));
+  const int cj = brevc<LG>(j) << (LGNX - LG);
+  const T l = dl * (k0 + T(cj < (Nx >> 1) ? cj : cj - Nx));
+  return mk<T>(-l * v.y, l * v.x);
 }
 // After the N-point DIF of a + i b (a, b real): A[k] = (Z[k] + conj Z[N-k])/2, B[k] = (Z[k] - conj Z[N-k])/(2i), k = 0..M.
 // f(k, c, A, B) consumes the pair (stores it, or combines it with something held in registers).
@@ -504,7 +565,7 @@ __global__ __launch_bounds__(NT) void k_y_r2c(const T* __restrict__ in, cx<T>* _
   const cx<T>* src = reinterpret_cast<const cx<T>*>(in) + (sl * Nx + x0) * (size_t)M;
   cx<T> v[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) v[i] = src[PM::e(i)];
+  for (int i = 0; i < R; ++i) v[i] = at32(src, (unsigned)PM::e(i));
   twr.commit(tw);
   __syncthreads();
   mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return v[i]; });
@@ -533,7 +594,7 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
   mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, scale, z);
   cx<T>* dst = reinterpret_cast<cx<T>*>(out) + (sl * Nx + x0) * (size_t)M;
 #pragma unroll
-  for (int i = 0; i < R; ++i) dst[PM::e(i)] = z[i];
+  for (int i = 0; i < R; ++i) at32(dst, (unsigned)PM::e(i)) = z[i];
 }
 
 // y pass of the pixel-mask sandwich  rfft2( m .* irfft2(x) )  (M = Mfourier * Mpix, src/dataset.jl:279-285): mixed -> map (in LDS /
@@ -556,7 +617,7 @@ __global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<
   const cx<T>* mk2 = reinterpret_cast<const cx<T>*>(mask) + (size_t)x0 * M;       // the mask is one (Nx, Ny) map for all slices
   cx<T> mv[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) mv[i] = mk2[PM::e(i)];
+  for (int i = 0; i < R; ++i) mv[i] = at32(mk2, (unsigned)PM::e(i));
   twr.commit(tw);
   tl.template commit<LD>(s);
   __syncthreads();
@@ -579,7 +640,7 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + Nx;
-  const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh);
+  const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh, gridDim.x);
   const int NyhP = mixed_rows(Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx, fo = ((size_t)rg.sl * Nyh + rg.ky0) * Nx;
   CMBL_XWSTAMP(14);
@@ -602,11 +663,9 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   if (MODE == 2) {
     // i*lx/Nx multiply between the last forward and the first inverse butterfly, in registers: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
     const T dl = dlx_over_Nx;
-    fft_dif_mid_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](int, int i, typename vreg<T>::type v) {
-      const int kx = brevc<LGNX>(i);
-      const T l = dl * T(kx < (Nx >> 1) ? kx : kx - Nx);
-      const cx<T> c = vcx(v);
-      return vfrom(mk<T>(-l * c.y, l * c.x));
+    fft_dif_mid_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](int, int b0, int j, typename vreg<T>::type v) {
+      constexpr int LGL = stage_lg(LGNX - 1, num_stages(LGNX - 1, row_xlg(LGNX)) - 1, row_xlg(LGNX));
+      return vfrom(mul_il_slot<T, LGNX, LGL>(vcx(v), b0, j, dl));
     });
   }
   if (MODE == 1) fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);

@@ -53,22 +53,22 @@ __device__ __forceinline__ V rk_update(const RKCoef<T>& rk, V k, V& y0, V& acc) 
 // Register-phase helpers.  A thread owns R "pairs": pair e = threadIdx.x + i*NT of the tile, column c = e >> LGM, rows
 // (2jj, 2jj+1) with jj = e & (M-1) -- i.e. the cx<T> at index e of a map column tile viewed as packed pairs.
 template <typename T>
-__device__ __forceinline__ void load_p_pair(const PhiMaps<T>& ph, size_t gi, T t, cx<T>& px, cx<T>& py, cx<T>& m11, cx<T>& m12, cx<T>& m22) {
-  const cx<T> gx = reinterpret_cast<const cx<T>*>(ph.gx)[gi], gy = reinterpret_cast<const cx<T>*>(ph.gy)[gi];
-  const cx<T> hxx = reinterpret_cast<const cx<T>*>(ph.hxx)[gi], hyx = reinterpret_cast<const cx<T>*>(ph.hyx)[gi];
-  const cx<T> hyy = reinterpret_cast<const cx<T>*>(ph.hyy)[gi];
+__device__ __forceinline__ void load_p_pair(const PhiMaps<T>& ph, size_t pbase, unsigned e, T t, cx<T>& px, cx<T>& py, cx<T>& m11, cx<T>& m12, cx<T>& m22) {
+  const cx<T> gx = at32(reinterpret_cast<const cx<T>*>(ph.gx) + pbase, e), gy = at32(reinterpret_cast<const cx<T>*>(ph.gy) + pbase, e);
+  const cx<T> hxx = at32(reinterpret_cast<const cx<T>*>(ph.hxx) + pbase, e), hyx = at32(reinterpret_cast<const cx<T>*>(ph.hyx) + pbase, e);
+  const cx<T> hyy = at32(reinterpret_cast<const cx<T>*>(ph.hyy) + pbase, e);
   flow_pm(t, gx.x, gy.x, hxx.x, hyx.x, hyy.x, px.x, py.x, m11.x, m12.x, m22.x);
   flow_pm(t, gx.y, gy.y, hxx.y, hyx.y, hyy.y, px.y, py.y, m11.y, m12.y, m22.y);
 }
 // p(t) only (forward / adjoint / delta-f parts): two cached maps instead of five -- the phi maps are the larger part of what a
 // column workgroup requests before its first transform
 template <typename T>
-__device__ __forceinline__ void load_p_only(const PhiMaps<T>& ph, size_t gi, T t, cx<T>& px, cx<T>& py) {
+__device__ __forceinline__ void load_p_only(const PhiMaps<T>& ph, size_t pbase, unsigned e, T t, cx<T>& px, cx<T>& py) {
   if (ph.pcx) {
-    px = reinterpret_cast<const cx<T>*>(ph.pcx)[gi]; py = reinterpret_cast<const cx<T>*>(ph.pcy)[gi];
+    px = at32(reinterpret_cast<const cx<T>*>(ph.pcx) + pbase, e); py = at32(reinterpret_cast<const cx<T>*>(ph.pcy) + pbase, e);
   } else {
     cx<T> m11, m12, m22;
-    load_p_pair(ph, gi, t, px, py, m11, m12, m22);
+    load_p_pair(ph, pbase, e, t, px, py, m11, m12, m22);
   }
 }
 // p(t_k), k = 0..n2 (t_k = k/n2, the 2n+1 RK stage times; src/lenseflow.jl:131-142) for every pixel: out[k][2][ntot]
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   cx<T> px[R], py[R], y0[R], acc[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = PM::e(i);
-    load_p_only(a.ph, pbase + e, a.rk.t, px[i], py[i]);
-    y0[i] = y0p[e];
-    acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
+    const unsigned e = PM::e(i);
+    load_p_only(a.ph, pbase, e, a.rk.t, px[i], py[i]);
+    y0[i] = at32(y0p, e);
+    acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : at32(accp, e);
   }
   twr.commit(tw);
   ps.template commit<LD>(s);
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   npt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, dx, dy);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = PM::e(i);
+    const unsigned e = PM::e(i);
     const cx<T> kv = pmul(px[i], dx[i]) + pmul(py[i], dy[i]);
     fn[i] = rk_update(a.rk, kv, y0[i], acc[i]);
-    if (a.rk.stage == 4) y0p[e] = y0[i]; else accp[e] = acc[i];
+    if (a.rk.stage == 4) at32(y0p, e) = y0[i]; else at32(accp, e) = acc[i];
   }
   if (a.rk.last) return;
   __syncthreads();
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + PM::e(i), a.t, px[i], py[i]);
+  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase, (unsigned)PM::e(i), a.t, px[i], py[i]);
   T lyr[G::RZ];                                               // ly of this thread's half-spectrum entries (used after the last transform)
 #pragma unroll
   for (int i = 0; i < G::RZ; ++i) { const int e = threadIdx.x + i * NT; if (e < C * (M + 1)) lyr[i] = a.ly[e >> LGC]; }
@@ -283,10 +283,10 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, yv);
   __syncthreads();
   npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], yv[i]); y = pmul(py[i], yv[i]); });
-  cx<T>* Wx = a.Wx + moff; cx<T>* Wy = a.Wy + moff;
+  cx<T>* Wx = tile_base(a.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(a.Wy + moff, x0, NyhP);
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
-    const size_t gi = mix_idx(k, x0 + c, NyhP);
-    Wx[gi] = A; Wy[gi] = mul_il(B, lyr[i]);
+    const unsigned gi = tile_off<C>(k, c, x0, NyhP);
+    at32(Wx, gi) = A; at32(Wy, gi) = mul_il(B, lyr[i]);
   });
 }
 
@@ -300,12 +300,12 @@ template <typename T> struct AdjXArgs {
 };
 
 template <typename T, int LGNX, int RPW>
-__device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* smem, long blk) {
+__device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* smem, unsigned blk, unsigned nblk) {
   constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), NT = row_nt(RPW), PF = NH >= 64 ? NH / 64 : 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + Nx;
   cx<T>* s2 = s + RPW * LD;                                   // second row set: sequence RPW + row, owned by the same threads
-  const RowGroup rg = row_group<RPW>(blk, a.Nyh);
+  const RowGroup rg = row_group<RPW>(blk, a.Nyh, nblk);
   const int NyhP = mixed_rows(a.Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx;
   TwStage<T, NT, Nx> twr;
@@ -376,17 +376,17 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
 template <typename T, int LGNX, int RPW>
 __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_adj_x(AdjXArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  adj_x_body<T, LGNX, RPW>(a, smem, blockIdx.x);
+  adj_x_body<T, LGNX, RPW>(a, smem, blockIdx.x, gridDim.x);
 }
 
 // x-derivative row pass as a device function (same as k_x_fft<MODE 2>)
 template <typename T> struct GradXArgs { const cx<T>* in; cx<T>* out; const cx<T>* twX; T dlx_over_Nx; int Nyh; };
 template <typename T, int LGNX, int RPW>
-__device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char* smem, long blk) {
+__device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char* smem, unsigned blk, unsigned nblk) {
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + Nx;
-  const RowGroup rg = row_group<RPW>(blk, g.Nyh);
+  const RowGroup rg = row_group<RPW>(blk, g.Nyh, nblk);
   const int NyhP = mixed_rows(g.Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx;
   TwStage<T, NT, Nx> twr;
@@ -401,9 +401,9 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
   // i*lx/Nx multiply between the last forward and the first inverse butterfly, in registers: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
   const T dl = g.dlx_over_Nx;
-  fft_dif_mid_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](int, int i, typename vreg<T>::type v) {
-    const int kx = brevc<LGNX>(i);
-    return vfrom(mul_il(vcx(v), dl * T(kx < (Nx >> 1) ? kx : kx - Nx)));
+  fft_dif_mid_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](int, int b0, int j, typename vreg<T>::type v) {
+    constexpr int LGL = stage_lg(LGNX - 1, num_stages(LGNX - 1, row_xlg(LGNX)) - 1, row_xlg(LGNX));
+    return vfrom(mul_il_slot<T, LGNX, LGL>(vcx(v), b0, j, dl));
   });
   __syncthreads();
   rows_store_mixed_dit<T, LGNX, RPW>(s, g.out + mo, tw, NyhP, rg.ky0, rg.nr, T(1));
@@ -449,7 +449,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase + PM::e(i), a.rk.t, px[i], py[i]);
+  for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase, (unsigned)PM::e(i), a.rk.t, px[i], py[i]);
   th.issue(d.H + moff, a.twY, x0);
   __syncthreads();
   CMBL_STAMP(1);
@@ -466,9 +466,9 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   cx<T> fn[R], ldf[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {                               // RK state: requested now, used after the second transform
-    const int e = PM::e(i);
-    fn[i] = y0p[e];
-    ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : accp[e];
+    const unsigned e = PM::e(i);
+    fn[i] = at32(y0p, e);
+    ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : at32(accp, e);
   }
   __syncthreads();
   CMBL_STAMP(4);
@@ -477,14 +477,14 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   CMBL_STAMP(5);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int e = PM::e(i);
+    const unsigned e = PM::e(i);
     cx<T> y0 = fn[i], acc = ldf[i];
     ldf[i] = lz[i];
-    reinterpret_cast<cx<T>*>(d.w1p)[mbase + e] = pmul(ldf[i], dx[i]);
-    reinterpret_cast<cx<T>*>(d.w2p)[mbase + e] = pmul(ldf[i], dy[i]);
+    at32(reinterpret_cast<cx<T>*>(d.w1p) + mbase, e) = pmul(ldf[i], dx[i]);
+    at32(reinterpret_cast<cx<T>*>(d.w2p) + mbase, e) = pmul(ldf[i], dy[i]);
     const cx<T> kv = pmul(px[i], dx[i]) + pmul(py[i], dy[i]);
     fn[i] = rk_update(a.rk, kv, y0, acc);
-    if (a.rk.stage == 4) y0p[e] = y0; else accp[e] = acc;
+    if (a.rk.stage == 4) at32(y0p, e) = y0; else at32(accp, e) = acc;
   }
   __syncthreads();
   CMBL_STAMP(6);
@@ -493,10 +493,10 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], ldf[i]); y = pmul(py[i], ldf[i]); });
   CMBL_STAMP(8);
   {
-    cx<T>* Wx = d.Wx + moff; cx<T>* Wy = d.Wy + moff;
+    cx<T>* Wx = tile_base(d.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(d.Wy + moff, x0, NyhP);
     pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
-      const size_t gi = mix_idx(k, x0 + c, NyhP);
-      Wx[gi] = A; Wy[gi] = mul_il(B, ps.l[i]);                // ly[k] is still in registers from the pair load (same entry mapping)
+      const unsigned gi = tile_off<C>(k, c, x0, NyhP);
+      at32(Wx, gi) = A; at32(Wy, gi) = mul_il(B, ps.l[i]);    // ly[k] is still in registers from the pair load (same entry mapping)
     });
   }
   CMBL_STAMP(9);
@@ -624,8 +624,24 @@ template <typename T, int LGNX, int RPW>
 __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
-  if (b < nblk_adj) adj_x_body<T, LGNX, RPW>(a, smem, b);
-  else grad_x_body<T, LGNX, RPW>(g, smem, (long)b - nblk_adj);
+#ifdef CMBL_STAMPS_ROWS            // launch timeline of the last launch that has both parts (tools/gpu_stamps_rows.py)
+  if (!a.rk.last && threadIdx.x == 0) g_stamps[(size_t)b * 16 + 14] = wall_clock64();
+#endif
+  // grid order: full row groups of the adjoint part, full groups of the d/dx part, then the short groups of both (see row_group)
+  const int G = (a.Nyh + RPW - 1) / RPW, Gf = a.Nyh / RPW, nfull = (nblk_adj / G) * Gf, nshort = nblk_adj - nfull;
+  const bool both = (int)gridDim.x > nblk_adj;
+  bool adj = true;
+  int blk = b;                                                           // row group within its part
+  if (both && b >= nfull) {
+    if (b < 2 * nfull) { adj = false; blk = b - nfull; }
+    else if (b < 2 * nfull + nshort) blk = b - nfull;
+    else { adj = false; blk = b - nfull - nshort; }
+  }
+  if (adj) adj_x_body<T, LGNX, RPW>(a, smem, (unsigned)blk, (unsigned)nblk_adj);
+  else grad_x_body<T, LGNX, RPW>(g, smem, (unsigned)blk, (unsigned)nblk_adj);
+#ifdef CMBL_STAMPS_ROWS
+  if (!a.rk.last && threadIdx.x == 0) g_stamps[(size_t)b * 16 + 15] = wall_clock64();
+#endif
 }
 
 // gradient / hessian multipliers for precompute (src/specialops.jl:184-188): F layout in, five F-layout outputs
