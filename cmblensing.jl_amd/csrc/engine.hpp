@@ -1092,7 +1092,7 @@ struct Dataset {
   // a0 = gradientf(f=0,d=0) is identically zero for this linear model (all operators finite), so it is not evaluated.
   // The scalars (res, alpha, beta, best residual, history, stop flag) live on the device (CgState): an iteration is enqueued
   // without waiting for its reductions; the host reads the stop flag of iteration i-1 while iteration i runs.
-  DevBuf cg_scal, cg_hist;
+  DevBuf cg_scal, cg_hist, qdev;
   int* cg_flag_host = nullptr;                 // pinned: [slot][done, nan]
   hipEvent_t cg_ev[2] = {nullptr, nullptr};
   ~Dataset() {
@@ -1193,18 +1193,26 @@ struct Dataset {
     mean(L, f_h, z, B);                                                   // leaves f~ = L f in mp2
     CMBL_HIP(hipMemcpyAsync(ftil.p, mp2.p, sizeof(T) * sl * np, hipMemcpyDeviceToDevice, c->stream));
     c->lincomb1((T*)z, (const T*)z, (const T*)d_h.p, 1.0, -1.0, 2 * n / B, B);
-    // quadratic forms
-    std::vector<double> q1(B), q2(B), q3(B);
-    apply(OP_CN_INV, z, w, B);                c->dot_F(z, w, P, B, q3.data());          // w = Cn^-1 z  (kept)
+    // quadratic forms: the three sets of B sums stay on the device and are read back ONCE, after everything else of this call has been
+    // enqueued -- a read-back per term drained the stream three times in the middle of a gradient evaluation
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    qdev.ensure(sizeof(double) * 3 * 64);
+    double* qd = qdev.template as<double>();
+    apply(OP_CN_INV, z, w, B);                c->dot_F_dev(z, w, P, B, qd + 128);       // w = Cn^-1 z  (kept)
     cx<T>* cfif = t2.template as<cx<T>>(); t2.ensure(sizeof(cx<T>) * n); cfif = t2.template as<cx<T>>();
-    apply(OP_CF_INV, f_h, cfif, B);           c->dot_F(f_h, cfif, P, B, q1.data());
+    apply(OP_CF_INV, f_h, cfif, B);           c->dot_F_dev(f_h, cfif, P, B, qd);
     cx<T>* cpip = gphi.template as<cx<T>>();
     apply(OP_CPHI_INV, phi, cpip, B, false, false, false, nullptr, 0, 1, 1);
-    c->dot_F(phi, cpip, 1, B, q2.data());
+    c->dot_F_dev(phi, cpip, 1, B, qd + 64);
     // A NaN logpdf is a VALUE, not an error: MAP_joint's line search penalises it (src/maximization.jl:194-199) and hmc_step
     // rejects the proposal (log(rand()) < NaN is false, src/sampling.jl:414), so it must reach the caller.
-    for (int i = 0; i < B; ++i) lp[i] = -0.5 * (q1[i] + q2[i] + q3[i] + logdet_sum);
-    if (!gfo) return;
+    auto finish_lp = [&]() {
+      double q[3 * 64];
+      CMBL_HIP(hipMemcpyAsync(q, qd, sizeof(double) * 3 * 64, hipMemcpyDeviceToHost, c->stream));
+      CMBL_HIP(hipStreamSynchronize(c->stream));
+      for (int i = 0; i < B; ++i) lp[i] = -0.5 * (q[i] + q[64 + i] + q[128 + i] + logdet_sum);
+    };
+    if (!gfo) { finish_lp(); return; }
     // d/df~ = -B'M'Cn^-1 z  -> QU Fourier
     apply_M(w, B, true);
     apply(OP_B, w, w, B, true, false, true, nullptr, 0, (T)-1);
@@ -1223,6 +1231,7 @@ struct Dataset {
     c->lincomb1((T*)g, (const T*)g, (const T*)dphi2.p, 1.0, 1.0, 2 * pl, B);
     c->lincomb1((T*)g, (const T*)g, (const T*)cpip, 1.0, -1.0, 2 * pl, B);
     apply(OP_G_INV, g, gphio_F, B, true, false, false, nullptr, 0, 1, 1);
+    finish_lp();
   }
 };
 

@@ -39,6 +39,13 @@ __device__ unsigned long long g_stamps[8192 * 16];
 #define CMBL_STAMP(i) do {} while (0)
 #define CMBL_WSTAMP(i) do {} while (0)
 #endif
+// -DCMBL_STAMPS_WAVES: every wavefront of a k_x_fft workgroup records when it starts and ends its transform chain (second half of
+// g_stamps: [block][wave][2]; tools/gpu_stamps_x.py prints the spread over the waves of a workgroup)
+#ifdef CMBL_STAMPS_WAVES
+#define CMBL_WVSTAMP(i) do { if ((threadIdx.x & 63) == 0) g_stamps[4096 * 16 + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + (i)] = clock64(); } while (0)
+#else
+#define CMBL_WVSTAMP(i) do {} while (0)
+#endif
 #ifdef CMBL_STAMPS_X
 #define CMBL_XSTAMP(i) CMBL_STAMP(i)
 #define CMBL_XWSTAMP(i) CMBL_WSTAMP(i)
@@ -657,6 +664,7 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   CMBL_XSTAMP(6);
   __syncthreads();
   CMBL_XSTAMP(1);
+  CMBL_WVSTAMP(0);
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
   if (MODE == 0) fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
   CMBL_XSTAMP(2);
@@ -670,6 +678,7 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   }
   if (MODE == 1) fft_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
   CMBL_XSTAMP(5);
+  CMBL_WVSTAMP(1);
   __syncthreads();
   CMBL_XSTAMP(3);
   if (MODE == 0) rows_store_F<T, LGNX, RPW>(s, out + fo, rg.nr, T(1));

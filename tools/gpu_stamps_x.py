@@ -31,3 +31,17 @@ print("wall clock: block starts after first start: p50 %.2f us p99 %.2f us max %
       % (np.percentile(w[:, 0] - t0, 50) / 100, np.percentile(w[:, 0] - t0, 99) / 100, (w[:, 0] - t0).max() / 100,
          (w[:, 1] - w[:, 0]).mean() / 100, np.percentile(w[:, 1] - w[:, 0], 90) / 100, (w[:, 1] - w[:, 0]).max() / 100, (w[:, 1].max() - t0) / 100))
 print("shader clock estimate: %.2f GHz" % (tot.mean() / ((w[:, 1] - w[:, 0]).mean() * 10)))
+
+if os.environ.get("WAVES"):                                        # -DCMBL_STAMPS_WAVES build: spread over the wavefronts of a workgroup
+    nw = 8
+    big = (ctypes.c_ulonglong * (4096 * 16 + nb * 16 * 2))()
+    assert lib.cmbl_debug_stamps(big, len(big)) == 0
+    wv = np.array(big[4096 * 16:], dtype=np.uint64).reshape(nb, 16, 2).astype(np.int64)[:, :nw, :]
+    wv = wv[: 2 * (513 // 4)]                                      # full row groups only
+    d = wv[:, :, 1] - wv[:, :, 0]
+    print("transform chain per wave [cycles]: mean over workgroups by wave index:", " ".join("%d" % x for x in d.mean(axis=0)))
+    print("   within a workgroup: fastest wave mean %.0f, slowest wave mean %.0f, wave 0 mean %.0f" % (d.min(axis=1).mean(), d.max(axis=1).mean(), d[:, 0].mean()))
+    st0 = wv[:, :, 0] - wv[:, :, 0].min(axis=1, keepdims=True)
+    print("   chain start after the first wave's start, by wave index:", " ".join("%d" % x for x in st0.mean(axis=0)))
+    en = wv[:, :, 1] - wv[:, :, 0].min(axis=1, keepdims=True)
+    print("   chain end after the first wave's start, by wave index:", " ".join("%d" % x for x in en.mean(axis=0)))
