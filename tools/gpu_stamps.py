@@ -34,3 +34,15 @@ t0 = w[:, 0].min()
 print("wall clock (10 ns ticks): block starts after first start: p50 %.2f us p99 %.2f us max %.2f us; block durations mean %.2f us max %.2f us; launch span %.2f us"
       % (np.percentile(w[:, 0] - t0, 50) / 100, np.percentile(w[:, 0] - t0, 99) / 100, (w[:, 0] - t0).max() / 100,
          (w[:, 1] - w[:, 0]).mean() / 100, (w[:, 1] - w[:, 0]).max() / 100, (w[:, 1].max() - t0) / 100))
+
+# where the slow workgroups are: duration by XCD (linear workgroup id % 8), by slice, by position in the grid
+dur = (w[:, 1] - w[:, 0]) / 100.0
+gx = nb // 2
+lin = np.arange(nb)
+print("duration [us] by XCD (linear id % 8):   " + " ".join("%.2f" % dur[lin % 8 == k].mean() for k in range(8)))
+print("duration [us] by slice (blockIdx.y):    " + " ".join("%.2f" % dur[lin // gx == k].mean() for k in range(2)))
+print("duration [us] by blockIdx.x octile:     " + " ".join("%.2f" % dur[(lin % gx) * 8 // gx == k].mean() for k in range(8)))
+srt = np.argsort(-dur)[:12]
+print("slowest: " + ", ".join("wg %d (x %d, y %d) %.2f" % (i, i % gx, i // gx, dur[i]) for i in srt))
+print("first-commit wait [cycles] of the 32 slowest vs all: %.0f vs %.0f; transform phases (stamps 1->9): %.0f vs %.0f"
+      % (rel[np.argsort(-dur)[:32], 1].mean(), rel[:, 1].mean(), (rel[np.argsort(-dur)[:32], 9] - rel[np.argsort(-dur)[:32], 1]).mean(), (rel[:, 9] - rel[:, 1]).mean()))
