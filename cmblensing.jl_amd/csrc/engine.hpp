@@ -777,14 +777,17 @@ struct Flow {
   // delta-phi: quadrature over the stored stages, five real transforms, the l-multipliers (shared by both paths)
   void dphi_finish(cx<T>* dphi, int P, int B, int nst, bool alias_quirk) {
     const long pl = c->plane(), np = c->npix();
-    CMBL_HIP(hipMemcpyAsync(tcbuf.p, tc_host.data(), sizeof(T) * 2 * nst, hipMemcpyHostToDevice, c->stream));
+    TcTab<T> tcv{};
+    const T* tcd = nullptr;
+    if (nst <= TcTab<T>::MAXST) std::copy(tc_host.begin(), tc_host.begin() + 2 * nst, tcv.v);
+    else { CMBL_HIP(hipMemcpyAsync(tcbuf.p, tc_host.data(), sizeof(T) * 2 * nst, hipMemcpyHostToDevice, c->stream)); tcd = tcbuf.as<T>(); }
     constexpr int V = 16 / (int)sizeof(T);
     if (np % V == 0)
       CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T, V>), dim3((unsigned)std::min<long>((np / V + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
-                  tcbuf.as<T>(), U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
+                  tcv, tcd, U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
     else
       CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T, 1>), dim3((unsigned)std::min<long>((np + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
-                  tcbuf.as<T>(), U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
+                  tcv, tcd, U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
     c->rfft2_F(U5.as<T>(), F5.as<cx<T>>(), 5L * B);
     CMBL_LAUNCH(c, K_DPHI_X, (k_dphi_combine<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, F5.as<cx<T>>(), dphi, c->lx_r.template as<T>(),
                 c->ly.template as<T>(), c->Nx, pl, B);
@@ -798,9 +801,8 @@ struct Flow {
     A.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
     acc.ensure(sizeof(T) * slices * np);
     T* y = out;
-    if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
     cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
-    c->y_r2c(y, a_cur, slices);
+    c->y_r2c(in, a_cur, slices);                                             // the first RK step reads the state from `in` (y0r), the rest from `out`
     const int K = groups(P, B);
     const long gs = slices / K;                                            // slices per group
     const auto tile = c->tileY(gs, true);
@@ -814,6 +816,7 @@ struct Flow {
           c->template x_pass<2>(a_cur + so * pl, Gx.as<cx<T>>() + so * pl, gs, st);
           FlowYArgs<T> a{};
           a.A = a_cur + so * pl; a.Gx = Gx.as<cx<T>>() + so * pl; a.Anext = a_nxt + so * pl; a.y0 = y + so * np; a.acc = acc.as<T>() + so * np;
+          a.y0r = (step == 0 ? in : y) + so * np;
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
           a.Nx = c->Nx; a.P = P;
           a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
@@ -907,7 +910,7 @@ struct Flow {
           const long so = g * gs, sp = so * pl, spm = so * mpl, sm = so * np;
           DeltaYArgs<T> d{};
           FlowYArgs<T>& a = d.f;
-          a.A = a_cur + spm; a.Gx = Gx.as<cx<T>>() + spm; a.Anext = a_nxt + spm; a.y0 = f + sm; a.acc = acc.as<T>() + sm; a.ph = ph(rk.t, phi_off(g, K, B));
+          a.A = a_cur + spm; a.Gx = Gx.as<cx<T>>() + spm; a.Anext = a_nxt + spm; a.y0 = f + sm; a.y0r = f + sm; a.acc = acc.as<T>() + sm; a.ph = ph(rk.t, phi_off(g, K, B));
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
           a.Nx = c->Nx; a.P = P; a.rk = rk;
           d.H = H.as<cx<T>>() + spm; d.Wx = Wx.as<cx<T>>() + spm; d.Wy = Wy.as<cx<T>>() + spm;
@@ -1051,13 +1054,15 @@ struct Dataset {
   }
 
   // mu = M B L f : harmonic F in (f may be nullptr == 0) -> harmonic F out (t2); uses mp2 for maps
-  void mean(Flow<T>& L, const cx<T>* f_h, cx<T>* out, int B) {
+  // `ftil_out`: where the lensed maps f~ = L f are left (default: the scratch mp2)
+  void mean(Flow<T>& L, const cx<T>* f_h, cx<T>* out, int B, T* ftil_out = nullptr) {
     const long sl = (long)P * B;
     mp2.ensure(sizeof(T) * sl * c->npix());
+    T* m = ftil_out ? ftil_out : mp2.template as<T>();
     c->harm(f_h, out, P, B, 0, nullptr, false, false, true);
     c->F_to_map(out, mp2.template as<T>(), sl);
-    L.flow_map(mp2.template as<T>(), mp2.template as<T>(), P, B, false);
-    c->rfft2_F(mp2.template as<T>(), out, sl);
+    L.flow_map(mp2.template as<T>(), m, P, B, false);
+    c->rfft2_F(m, out, sl);
     apply(OP_B, out, out, B, false, true, false);
     apply_M(out, B, false);
   }
@@ -1190,8 +1195,7 @@ struct Dataset {
     c->rfft2_F(fhat.template as<T>(), f_h, sl);
     apply(OP_D_INV, f_h, f_h, B, false, true, false);
     // z = M B L f - d
-    mean(L, f_h, z, B);                                                   // leaves f~ = L f in mp2
-    CMBL_HIP(hipMemcpyAsync(ftil.p, mp2.p, sizeof(T) * sl * np, hipMemcpyDeviceToDevice, c->stream));
+    mean(L, f_h, z, B, ftil.template as<T>());                            // leaves f~ = L f in ftil
     c->lincomb1((T*)z, (const T*)z, (const T*)d_h.p, 1.0, -1.0, 2 * n / B, B);
     // quadratic forms: the three sets of B sums stay on the device and are read back ONCE, after everything else of this call has been
     // enqueued -- a read-back per term drained the stream three times in the middle of a gradient evaluation

@@ -49,6 +49,12 @@ __device__ __forceinline__ V rk_update(const RKCoef<T>& rk, V k, V& y0, V& acc) 
   return y0;
 }
 
+// streaming store of one packed pair (the per-stage products are written once and read once, by k_dphi_reduce at the end of the flow:
+// kept out of the caches the stage arrays live in; (∇L)† 1.195 -> 1.180 ms.  Streaming LOADS of the p(t) cache, which both pol slices
+// read, measured slower: L*f 0.579 -> 0.600 ms)
+typedef double nt_d2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store(cx<float>* p, cx<float> v) { __builtin_nontemporal_store(f2{v.x, v.y}, reinterpret_cast<f2*>(p)); }
+__device__ __forceinline__ void nt_store(cx<double>* p, cx<double> v) { __builtin_nontemporal_store(nt_d2s{v.x, v.y}, reinterpret_cast<nt_d2s*>(p)); }
 // ---------------------------------------------------------------------------------------------
 // Register-phase helpers.  A thread owns R "pairs": pair e = threadIdx.x + i*NT of the tile, column c = e >> LGM, rows
 // (2jj, 2jj+1) with jj = e & (M-1) -- i.e. the cx<T> at index e of a map column tile viewed as packed pairs.
@@ -186,6 +192,7 @@ __device__ __forceinline__ void npt_write_forward(cx<T>* s, const cx<T>* tw, XY&
 template <typename T> struct FlowYArgs {
   const cx<T>* A; const cx<T>* Gx; cx<T>* Anext;
   T* y0; T* acc;
+  const T* y0r;             // where the flow state is READ (the caller's input during the first RK step, then y0: no copy for out != in)
   PhiMaps<T> ph;
   const cx<T>* twY; const T* ly;
   int Nx, P;
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, x0);
   const size_t pbase = ((size_t)bphi * Nx + x0) * M, mbase = (sl * Nx + x0) * (size_t)M;
   cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
+  const cx<T>* y0rp = reinterpret_cast<const cx<T>*>(a.y0r) + mbase;
   cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
   using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R], y0[R], acc[R];
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   for (int i = 0; i < R; ++i) {
     const unsigned e = PM::e(i);
     load_p_only(a.ph, pbase, e, a.rk.t, px[i], py[i]);
-    y0[i] = at32(y0p, e);
+    y0[i] = at32(y0rp, e);
     acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : at32(accp, e);
   }
   twr.commit(tw);
@@ -467,7 +475,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
 #pragma unroll
   for (int i = 0; i < R; ++i) {                               // RK state: requested now, used after the second transform
     const unsigned e = PM::e(i);
-    fn[i] = at32(y0p, e);
+    fn[i] = at32(reinterpret_cast<const cx<T>*>(a.y0r) + mbase, e);
     ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : at32(accp, e);
   }
   __syncthreads();
@@ -480,8 +488,8 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
     const unsigned e = PM::e(i);
     cx<T> y0 = fn[i], acc = ldf[i];
     ldf[i] = lz[i];
-    at32(reinterpret_cast<cx<T>*>(d.w1p) + mbase, e) = pmul(ldf[i], dx[i]);
-    at32(reinterpret_cast<cx<T>*>(d.w2p) + mbase, e) = pmul(ldf[i], dy[i]);
+    nt_store(&at32(reinterpret_cast<cx<T>*>(d.w1p) + mbase, e), pmul(ldf[i], dx[i]));
+    nt_store(&at32(reinterpret_cast<cx<T>*>(d.w2p) + mbase, e), pmul(ldf[i], dy[i]));
     const cx<T> kv = pmul(px[i], dx[i]) + pmul(py[i], dy[i]);
     fn[i] = rk_update(a.rk, kv, y0, acc);
     if (a.rk.stage == 4) at32(y0p, e) = y0; else at32(accp, e) = acc;
@@ -527,10 +535,12 @@ typedef double nt_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nt_load16(const float* p, float (&o)[4]) { const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 __device__ __forceinline__ void nt_load16(const double* p, double (&o)[2]) { const nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p)); o[0] = v.x; o[1] = v.y; }
 
+// (t_s, c_s) of up to 64 stages ride in the kernel arguments (no upload per flow); longer flows pass a device table
+template <typename T> struct TcTab { static constexpr int MAXST = 64; T v[2 * MAXST]; };
 // V = pixels per thread: 16-byte loads when npix allows it, 1 for the any-size path (odd pixel counts)
 template <typename T, int V = 16 / (int)sizeof(T)>
 __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __restrict__ W /*[nst][2][slices][npix]*/,
-                                                    const T* __restrict__ tc /*[nst][2] = (t_s, c_s)*/, T* __restrict__ out /*[5][B][npix]*/,
+                                                    TcTab<T> tcv, const T* __restrict__ tcd /*[nst][2] = (t_s, c_s), or nullptr: tcv*/, T* __restrict__ out /*[5][B][npix]*/,
                                                     long npix, int P, int B, int nst, int alias_quirk) {
   struct alignas(V * sizeof(T)) Vec { T v[V]; };
   const int b = blockIdx.y;
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __r
 #pragma unroll
       for (int j = 0; j < SU; ++j) {
         if (s0 + j >= nst) break;
-        const T t = tc[2 * (s0 + j)], c = tc[2 * (s0 + j) + 1];
+        const T t = tcd ? tcd[2 * (s0 + j)] : tcv.v[2 * (s0 + j)], c = tcd ? tcd[2 * (s0 + j) + 1] : tcv.v[2 * (s0 + j) + 1];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
           T px, py, m11, m12, m22;
