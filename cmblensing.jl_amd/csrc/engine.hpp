@@ -1039,17 +1039,19 @@ struct Dataset {
     c->template x_pass<1>(x, m, sl); c->y_mask(m, m, ops[OP_MPIX].d[0], sl); c->template x_pass<0>(m, x, sl);
   }
   // x (harmonic F) -> M x = Mf * (Mpix * x) ; transpose: Mpix' * (Mf' * x)   (src/dataset.jl:279-285)
-  void apply_M(cx<T>* x, int B, bool transpose) {
+  // qu: the pixel side of M is exchanged in QU Fourier (x comes in QU Fourier for M, goes out in QU Fourier for M'), so that the beam
+  // next to it does the basis change in its own launch instead of a launch of its own
+  void apply_M(cx<T>* x, int B, bool transpose, bool qu = false) {
     const long sl = (long)P * B;
-    if (!has(OP_MPIX)) { apply(OP_MF, x, x, B, transpose); return; }
+    if (!has(OP_MPIX)) { apply(OP_MF, x, x, B, transpose, qu && !transpose, qu && transpose); return; }
     if (!transpose) {
-      c->harm(x, x, P, B, 0, nullptr, false, false, true);                 // -> QU Fourier
+      if (!qu) c->harm(x, x, P, B, 0, nullptr, false, false, true);        // -> QU Fourier
       pixel_mask(x, sl);
       apply(OP_MF, x, x, B, false, true, false);
     } else {
       apply(OP_MF, x, x, B, true, false, true);
       pixel_mask(x, sl);
-      c->harm(x, x, P, B, 0, nullptr, false, true, false);
+      if (!qu) c->harm(x, x, P, B, 0, nullptr, false, true, false);
     }
   }
 
@@ -1063,8 +1065,8 @@ struct Dataset {
     c->F_to_map(out, mp2.template as<T>(), sl);
     L.flow_map(mp2.template as<T>(), m, P, B, false);
     c->rfft2_F(m, out, sl);
-    apply(OP_B, out, out, B, false, true, false);
-    apply_M(out, B, false);
+    apply(OP_B, out, out, B, false, true, true);                          // QU Fourier -> (EB) x beam -> QU Fourier
+    apply_M(out, B, false, true);
   }
 
   // gradientf_logpdf (src/dataset.jl:76-80): L'B'M'Cn^-1 (d - M B L f) - Cf^-1 f.  f_h == nullptr means f = 0;
@@ -1082,8 +1084,8 @@ struct Dataset {
     }
     if (f_h && !dd) apply(OP_CN_INV, r, r, B, false, false, false, nullptr, 0, (T)-1);       // d = 0: the sign of -(M B L f) rides along
     else apply(OP_CN_INV, r, r, B);
-    apply_M(r, B, true);
-    apply(OP_B, r, r, B, true, false, true);                               // -> QU Fourier
+    apply_M(r, B, true, true);
+    apply(OP_B, r, r, B, true, true, true);                                // QU Fourier -> (EB) x beam' -> QU Fourier
     L.flow_adj_F(r, r, P, B, false);
     if (f_h) {
       c->harm(r, r, P, B, 0, nullptr, false, true, false);                 // -> harmonic
@@ -1218,8 +1220,8 @@ struct Dataset {
     };
     if (!gfo) { finish_lp(); return; }
     // d/df~ = -B'M'Cn^-1 z  -> QU Fourier
-    apply_M(w, B, true);
-    apply(OP_B, w, w, B, true, false, true, nullptr, 0, (T)-1);
+    apply_M(w, B, true, true);
+    apply(OP_B, w, w, B, true, true, true, nullptr, 0, (T)-1);
     // pullback through f~ = L f : delta flow t 1->0 from (f~, w, 0)
     L.flow_delta(ftil.template as<T>(), w, dphi1.template as<cx<T>>(), P, B, true, quirk);
     // g_f = df1 - Cf^-1 f   (harmonic) ; then d/dfhat = D' \ g_f  -> QU Fourier
