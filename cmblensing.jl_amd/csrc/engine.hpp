@@ -125,6 +125,9 @@ struct Ctx : CtxBase {
     // powers of two >= 32 run the fused kernels; everything else (and everything, with CMBL_FORCE_GENERIC=1) the any-size path
     generic = !(ispow2(Ny) && ispow2(Nx) && Ny >= 32 && Nx >= 32) || env_int("CMBL_FORCE_GENERIC", 0) != 0;
     Nyh = Ny / 2 + 1; M = Ny / 2; lgM = ilog2(M); lgNx = ilog2(Nx);
+    // the adjoint row pass keeps two row sets in LDS: where even one row of each does not fit next to the twiddle table (double
+    // precision at Nx = 4096) the whole context runs the any-size path, whose transforms ping-pong in LDS one sequence at a time
+    if (!generic && row_rpw<T>(lgNx, 2) == 0) generic = true;
     CMBL_HIP(hipSetDevice(device));
     { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) num_cus = n; }
     // NULL is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns when the caller has not

@@ -90,3 +90,12 @@ def test_anysize_path_equals_fused_path(camb, prec):
     tol = TOL[prec]["flow"] if prec == "f32" else 1e-11            # fp32: each side is within 5e-5 of the float64 oracle
     for name, a, b in zip(("rfft", "L*f", "L\\f", "L'g", "dphi", "df", "f0"), res["0"], res["1"]):
         assert rel(a, b) < tol * (10 if name == "dphi" else 1), (name, rel(a, b))
+
+
+def test_largest_row_length_double_precision(camb):
+    """Nx = 4096 in double precision: the fused adjoint row pass does not fit LDS (two row sets of 68 KB + the table), so the context
+    falls back to the any-size path as a whole -- every operator must still work and agree with the oracle"""
+    TP.test_lenseflow_ops(camb, "f64", 32, 4096, 2, 1, 1, 7)
+    TP.test_lenseflow_gradient(camb, "f64", 32, 4096, 2, 1, 1, "fwd", 7)
+    # (single precision stays on the fused kernels at this size; a 1 x 136 degree strip is not a single-precision parity case: its
+    # lowest lx modes deflect by many pixels and the flow amplifies rounding to 1e-3, tools/gpu_size_probe.py)
