@@ -48,11 +48,14 @@ static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x
   } while (0)
 #define CMBL_LAUNCH(ctxp, kid, kernel, grid, lds, stream, ...) CMBL_LAUNCH_NT(ctxp, kid, NTP, kernel, grid, lds, stream, __VA_ARGS__)
 
-// compiled column-tile shapes (lgM, R, NT):  C = R*NT >> lgM columns per workgroup
+// compiled column-tile shapes (lgM, R, NT):  C = R*NT >> lgM columns per workgroup.  Per lgM the list holds what tileY() can select in
+// either precision (narrowest C >= 4 that fits LDS, 512 threads preferred; C = 2 or 1 where four double-precision columns do not fit)
+// plus one wider / narrower neighbour for CMBL_TUNE_C sweeps; 1024-thread and R = 16 variants of lgM 9 / 10 spilled registers and were
+// never selected.
 #ifndef CMBL_COL_LIST
 #define CMBL_COL_LIST(X) X(4, 1, 256) X(5, 1, 256) X(5, 2, 256) X(6, 1, 256) X(6, 2, 256) X(7, 2, 256) X(7, 4, 256) X(8, 4, 256) X(8, 8, 256) \
-                         X(9, 4, 256) X(9, 8, 256) X(9, 16, 256) X(10, 8, 256) X(10, 16, 256) X(11, 8, 1024) X(11, 4, 1024) X(11, 2, 1024) \
-                         X(8, 2, 512) X(8, 4, 512) X(9, 4, 512) X(9, 8, 512) X(10, 4, 512) X(10, 8, 512) X(9, 2, 1024) X(9, 4, 1024) X(10, 4, 1024)
+                         X(9, 4, 256) X(9, 8, 256) X(10, 8, 256) X(11, 4, 1024) X(11, 2, 1024) \
+                         X(8, 2, 512) X(8, 4, 512) X(9, 4, 512) X(9, 8, 512) X(10, 4, 512) X(10, 8, 512)
 #endif
 #ifndef CMBL_ROW_LIST
 #define CMBL_ROW_LIST(X) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)

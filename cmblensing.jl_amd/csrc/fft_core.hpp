@@ -84,15 +84,14 @@ __device__ __forceinline__ cx<double> vfrom(cx<double> c) { return c; }
 // ---- butterflies -------------------------------------------------------------------------------------------------------------
 // exp(-+ 2 pi i e / 16) as a value of the register type (INV: conjugate)
 template <typename T, bool INV> __device__ __forceinline__ typename vreg<T>::type w16(int e) {
-  constexpr double c[4] = {1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977};   // cos(e pi / 8), e = 0..3
-  // cos((e) pi/8), sin(e pi/8) for e = 0..15 from the first octant
-  const int q = e & 15;
+  // cos / sin of e pi / 8 from the first octant, as literals (a local table of doubles ended up in scratch memory)
+  constexpr double c1 = 0.92387953251128674, c2 = 0.70710678118654752, c3 = 0.38268343236508977;
   double cs, sn;
-  switch (q) {
-    case 0: cs = 1; sn = 0; break;            case 1: cs = c[1]; sn = c[3]; break;    case 2: cs = c[2]; sn = c[2]; break;     case 3: cs = c[3]; sn = c[1]; break;
-    case 4: cs = 0; sn = 1; break;            case 5: cs = -c[3]; sn = c[1]; break;   case 6: cs = -c[2]; sn = c[2]; break;    case 7: cs = -c[1]; sn = c[3]; break;
-    case 8: cs = -1; sn = 0; break;           case 9: cs = -c[1]; sn = -c[3]; break;  case 10: cs = -c[2]; sn = -c[2]; break;  case 11: cs = -c[3]; sn = -c[1]; break;
-    case 12: cs = 0; sn = -1; break;          case 13: cs = c[3]; sn = -c[1]; break;  case 14: cs = c[2]; sn = -c[2]; break;   default: cs = c[1]; sn = -c[3]; break;
+  switch (e & 15) {
+    case 0: cs = 1; sn = 0; break;            case 1: cs = c1; sn = c3; break;     case 2: cs = c2; sn = c2; break;      case 3: cs = c3; sn = c1; break;
+    case 4: cs = 0; sn = 1; break;            case 5: cs = -c3; sn = c1; break;    case 6: cs = -c2; sn = c2; break;     case 7: cs = -c1; sn = c3; break;
+    case 8: cs = -1; sn = 0; break;           case 9: cs = -c1; sn = -c3; break;   case 10: cs = -c2; sn = -c2; break;   case 11: cs = -c3; sn = -c1; break;
+    case 12: cs = 0; sn = -1; break;          case 13: cs = c3; sn = -c1; break;   case 14: cs = c2; sn = -c2; break;    default: cs = c1; sn = -c3; break;
   }
   return vmake((T)cs, (T)(INV ? sn : -sn));
 }

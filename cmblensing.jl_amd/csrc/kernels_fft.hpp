@@ -150,7 +150,7 @@ template <int R, int NT, int LGM> struct ColTile {
 // waits once.
 template <typename T, int NT, int NH> struct TwStage {                       // twiddle table, NH entries
   static constexpr int K = (NH + NT - 1) / NT;
-  cx<T> v[K];
+  cx<T> v[K] = {};            // zero-initialised: a conditionally written register array otherwise lands in scratch memory (seen in fp64)
   __device__ __forceinline__ void issue(const cx<T>* __restrict__ g) {
 #pragma unroll
     for (int i = 0; i < K; ++i) { const int j = threadIdx.x + i * NT; if (NH % NT == 0 || j < NH) v[i] = g[j]; }
@@ -165,7 +165,7 @@ template <typename T, int NT, int NH> struct TwStage {                       // 
 // lanes run over c fastest so each wave touches (64/C) segments of C contiguous complex values.
 template <typename T, int NT, int LGM, int LGC> struct TileStage {           // half-spectrum tile: C columns x (M+1) rows
   static constexpr int M = 1 << LGM, C = 1 << LGC, TOT = C * (M + 1), K = (TOT + NT - 1) / NT;
-  cx<T> v[K];
+  cx<T> v[K] = {};
   __device__ __forceinline__ void issue(const cx<T>* __restrict__ g /*slice base*/, int Nx, int x0) {
     const cx<T>* tg = tile_base(g, x0, mixed_rows(M + 1));
 #pragma unroll
@@ -221,7 +221,7 @@ template <int R, int NT, int LGM> struct PairMap {
 // the LDS copy is not synchronised yet).  Replaces TileStage + c2r_pre: one LDS pass and one barrier less.
 template <typename T, int NT, int LGM, int LGC> struct HalfStage {
   static constexpr int M = 1 << LGM, C = 1 << LGC, NP = (M >> 1) + 1, TOT = C * NP, K = (TOT + NT - 1) / NT, NyhP = mixed_rows(M + 1);
-  cx<T> a[K], b[K], w[K];
+  cx<T> a[K] = {}, b[K] = {}, w[K] = {};
   __device__ __forceinline__ void issue(const cx<T>* __restrict__ g /*slice base*/, const cx<T>* __restrict__ twg, int x0) {
     const cx<T>* tg = tile_base(g, x0, NyhP);
 #pragma unroll
@@ -333,8 +333,8 @@ __device__ __forceinline__ void mpt_write_forward(cx<T>* s, const cx<T>* tw, ZF&
 // Here X = gX, Y = i*ly[k]*gY (the d/dy multiply rides along).
 template <typename T, int NT, int LGN, int LGC> struct PairStage {
   static constexpr int N = 1 << LGN, M = N >> 1, C = 1 << LGC, TOT = C * (M + 1), K = (TOT + NT - 1) / NT;
-  cx<T> X[K], Y[K];
-  T l[K];
+  cx<T> X[K] = {}, Y[K] = {};
+  T l[K] = {};
   __device__ __forceinline__ void issue(const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY, const T* __restrict__ ly, int Nx, int x0) {
     const cx<T>* tX = tile_base(gX, x0, mixed_rows(M + 1));
     const cx<T>* tY = tile_base(gY, x0, mixed_rows(M + 1));
@@ -416,6 +416,12 @@ template <typename T> struct alignas(16) CxVec { cx<T> v[16 / sizeof(cx<T>)]; };
 template <typename T> __device__ __forceinline__ const CxVec<T>& vec32(const cx<T>* base, unsigned idx) {
   return *reinterpret_cast<const CxVec<T>*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(cx<T>));
 }
+// 16-byte load into a register-staged array element.  With one value per vector (double precision) the element is assigned as a
+// value: the aggregate copy kept the whole array in scratch memory, with a full wait after every load.
+template <typename T> __device__ __forceinline__ void vload32(CxVec<T>& dst, const cx<T>* base, unsigned idx) {
+  if constexpr (sizeof(cx<T>) == 16) dst.v[0] = at32(base, idx);
+  else dst = vec32(base, idx);
+}
 template <typename T> __device__ __forceinline__ CxVec<T>& vec32(cx<T>* base, unsigned idx) {
   return *reinterpret_cast<CxVec<T>*>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(cx<T>));
 }
@@ -429,20 +435,20 @@ template <typename T, int LGNX, int RPW, int NA> struct RowsMixedStage {
   using V = typename vreg<T>::type;
   static constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW);
   static constexpr int TOT = RPW * NH / VE, K = (TOT + NT - 1) / NT;
-  CxVec<T> va[NA][K], vb[NA][K], w[K];
+  CxVec<T> va[NA][K] = {}, vb[NA][K] = {}, w[K] = {};
   __device__ __forceinline__ void issue(const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr) {
     const int rot = CMBL_ROW_ROT(ky0);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
       if ((TOT % NT == 0 || u < TOT) && r < nr) {
-        w[i] = vec32(twg, (unsigned)(xt * MIXW + c));
+        vload32(w[i], twg, (unsigned)(xt * MIXW + c));
         const unsigned o = (unsigned)((xt * NyhP + r) * MIXW + c), ob = (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c);
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
           const cx<T>* ga = g[a] + (size_t)ky0 * MIXW;                    // uniform part of the address
-          va[a][i] = vec32(ga, o);
-          vb[a][i] = vec32(ga, ob);
+          vload32(va[a][i], ga, o);
+          vload32(vb[a][i], ga, ob);
         }
       }
     }
@@ -499,11 +505,13 @@ __device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s
 template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void rows_load_F(cx<T>* __restrict__ s, const cx<T>* __restrict__ g, int nr) {
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), NT = row_nt(RPW), TOT = RPW * Nx / VE, K = (TOT + NT - 1) / NT;
+  // every thread loads unconditionally (rows beyond nr re-read the group's last row, entries beyond TOT the first): an array written
+  // under a predicate stays in scratch memory in the double-precision instantiations, with a full wait after each load
   CxVec<T> v[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int u = threadIdx.x + i * NT, r = (u * VE) >> LGNX;
-    if ((TOT % NT == 0 || u < TOT) && r < nr) v[i] = vec32(g, (unsigned)(u * VE));
+    const int u0 = threadIdx.x + i * NT, u = (TOT % NT == 0 || u0 < TOT) ? u0 : 0, r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
+    v[i] = vec32(g, (unsigned)(((r < nr ? r : nr - 1) << LGNX) + x));
   }
 #pragma unroll
   for (int i = 0; i < K; ++i) {
