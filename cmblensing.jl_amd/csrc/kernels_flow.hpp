@@ -535,11 +535,20 @@ typedef double nt_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nt_load16(const float* p, float (&o)[4]) { const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 __device__ __forceinline__ void nt_load16(const double* p, double (&o)[2]) { const nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p)); o[0] = v.x; o[1] = v.y; }
 
+// k_dphi_reduce: stages whose loads are in flight together per thread (SU) and the register budget (waves per SIMD).  With SU = 4 the
+// kernel needed 165 registers = 3 waves per SIMD = 768 resident blocks for a grid of 1024 at 1024^2: a third of the blocks ran in a
+// second round (121 us).  SU = 2 fits 128 registers, the whole grid is resident at once: 89 us (512 MB -> 5.8 TB/s).
+#ifndef CMBL_DPHI_WAVES
+#define CMBL_DPHI_WAVES 4
+#endif
+#ifndef CMBL_DPHI_SU
+#define CMBL_DPHI_SU 2
+#endif
 // (t_s, c_s) of up to 64 stages ride in the kernel arguments (no upload per flow); longer flows pass a device table
 template <typename T> struct TcTab { static constexpr int MAXST = 64; T v[2 * MAXST]; };
 // V = pixels per thread: 16-byte loads when npix allows it, 1 for the any-size path (odd pixel counts)
 template <typename T, int V = 16 / (int)sizeof(T)>
-__global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __restrict__ W /*[nst][2][slices][npix]*/,
+__global__ __launch_bounds__(NTP, CMBL_DPHI_WAVES) void k_dphi_reduce(PhiMaps<T> ph, const T* __restrict__ W /*[nst][2][slices][npix]*/,
                                                     TcTab<T> tcv, const T* __restrict__ tcd /*[nst][2] = (t_s, c_s), or nullptr: tcv*/, T* __restrict__ out /*[5][B][npix]*/,
                                                     long npix, int P, int B, int nst, int alias_quirk) {
   struct alignas(V * sizeof(T)) Vec { T v[V]; };
@@ -552,8 +561,8 @@ __global__ __launch_bounds__(NTP) void k_dphi_reduce(PhiMaps<T> ph, const T* __r
     const Vec hxx = *reinterpret_cast<const Vec*>(ph.hxx + pb + i), hyx = *reinterpret_cast<const Vec*>(ph.hyx + pb + i);
     const Vec hyy = *reinterpret_cast<const Vec*>(ph.hyy + pb + i);
     double U1[V] = {}, U2[V] = {}, A[V] = {}, Bb[V] = {}, Cc[V] = {};
-    // the per-stage products are read exactly once: non-temporal loads, four stages' worth requested before the first is used
-    constexpr int SU = 4;
+    // the per-stage products are read exactly once: non-temporal loads, SU stages' worth requested before the first is used
+    constexpr int SU = CMBL_DPHI_SU;
     for (int s0 = 0; s0 < nst; s0 += SU) {
       Vec w1[SU], w2[SU];
 #pragma unroll
