@@ -186,6 +186,14 @@ def test_lenseflow_gradient(camb, prec, Ny, Nx, P, B, Bphi, mode, n):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_lenseflow_gradient_many_steps(camb, prec):
+    """n = 20 RK steps = 80 stages: beyond the 64 (t_s, c_s) pairs that ride in the kernel arguments of the δϕ quadrature, so the
+    table goes through device memory; n = 16 is the last that does not"""
+    for n in (16, 20):
+        test_lenseflow_gradient(camb, prec, 64, 32, 2, 1, 1, "fwd", n)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("Ny,Nx,P", [(32, 32, 1), (64, 32, 2), (32, 64, 3)])
 def test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P):
     """Independent known answer (tests/_known.py, no oracle involved): L(ϕ)*f = f(x + ∇ϕ(x)) by direct Fourier summation.
