@@ -333,7 +333,12 @@ struct Ctx : CtxBase {
   // column tile: twiddles + C columns of an N-point (pair) or M-point (packed) transform, padded rows
   size_t ldsY(int C, bool pair = true) const { return ((size_t)2 * M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
   // Row launches: one workgroup per group of RPW adjacent ky rows of a slice (RPW = row_rpw<T>(lgNx, row sets), kernels_fft.hpp)
-  size_t ldsX(int rpw, int nbuf) const { return ((size_t)Nx + (size_t)nbuf * rpw * row_ld(Nx)) * sizeof(cx<T>); }
+  // Row launches of about one workgroup per CU (258 row groups at 1024^2 QU) run faster when no CU hosts two of them: two co-resident
+  // row workgroups are VALU-issue bound and the launch ends with its slowest workgroup.  Asking for more than half of the CU's LDS
+  // keeps them apart; the few workgroups beyond the CU count are the short ones (row_group) and run in a second, short round.
+  const size_t lds_one_per_cu = env_int("CMBL_ONE_PER_CU", 1) ? (size_t)82 * 1024 : 0;
+  size_t lds_apart(size_t lds, long nblk) const { return (lds_one_per_cu && nblk <= num_cus + num_cus / 8) ? std::max(lds, lds_one_per_cu) : lds; }
+  size_t ldsX(int rpw, int nbuf) const { return ((size_t)row_tw(Nx) + (size_t)nbuf * rpw * row_ld(Nx)) * sizeof(cx<T>); }
   long row_groups(long slices, int rpw) const { return slices * ((Nyh + rpw - 1) / rpw); }
 
   template <typename Fn> void dispatch_col(const TileY& t, Fn&& fn) const {
@@ -397,7 +402,8 @@ struct Ctx : CtxBase {
     dispatch_row([&](auto lgnx) {
       constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 1);
       if constexpr (RPW > 0) {
-        CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), row_nt(RPW), (k_x_fft<T, MODE, LGNX, RPW>), dim3((unsigned)row_groups(slices, RPW)), ldsX(RPW, 1), st,
+        CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), row_nt(RPW), (k_x_fft<T, MODE, LGNX, RPW>), dim3((unsigned)row_groups(slices, RPW)),
+                       ldsX(RPW, 1), st,
                        in, out, twX.as<cx<T>>(), dlx_over_Nx, Nyh);
       } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
     });
@@ -871,7 +877,7 @@ struct Flow {
           c->dispatch_row([&](auto lgnx) {
             constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
             if constexpr (RPW > 0) {
-              CMBL_LAUNCH_NT(c, K_ADJ_X, row_nt(RPW), (k_adj_x<T, LGNX, RPW>), dim3((unsigned)c->row_groups(gs, RPW)), c->ldsX(RPW, 2), st, x);
+              CMBL_LAUNCH_NT(c, K_ADJ_X, row_nt(RPW), (k_adj_x<T, LGNX, RPW>), dim3((unsigned)c->row_groups(gs, RPW)), c->lds_apart(c->ldsX(RPW, 2), c->row_groups(gs, RPW)), st, x);
             } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
           });
         }

@@ -6,7 +6,7 @@
 // so a forward/pointwise/inverse chain never needs a reordering pass: frequency k lives at slot brev(k).
 // Up to four radix-2 levels are fused per LDS round trip: a thread pulls 2^LG elements into registers, runs LG levels of
 // the in-place network on them (radix-16 for LG=4) and writes them back, so a 1024-point transform is 3 round trips / 3
-// barriers.  Element i of a sequence lives at LDS index pad(i) = i + (i >> 4): the one-in-sixteen padding spreads the
+// barriers.  Element i of a sequence lives at LDS index pad(i) = i + (i >> CMBL_PAD_SHIFT): the padding spreads the
 // power-of-two strides of bit-reversed and butterfly accesses over the 64 banks.  All sizes are template parameters, so
 // every LDS address inside a stage is `pad(base) + immediate` and every twiddle index is a constant shift.
 //
@@ -29,6 +29,11 @@
 
 namespace cmbl {
 
+// One spare slot per 2^CMBL_PAD_SHIFT.  A third of the LDS cycles of the fused kernels are bank conflicts (SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE = 0.32, all on the ds_read_b64 side: 32-lane groups on 64 banks; the writes stay inside their transfer time).
+// A spare slot per 8 removes the read conflicts of the two lower stages of a wave-private 512-point transform (bank model of the
+// stage accesses: 96 -> 64 LDS cycles per transform, 48 ideal) -- and changes no kernel time on the GPU (A/B at 1024^2), so the
+// smaller footprint stays: the conflict cycles hide behind the waits of the dependent chain.
 #ifndef CMBL_PAD_SHIFT
 #define CMBL_PAD_SHIFT 4
 #endif
@@ -176,16 +181,16 @@ __device__ __forceinline__ void dif_mid_dit_stage(cx<T>* __restrict__ s, const W
   using V = typename vreg<T>::type;
   constexpr int r = 1 << LG, lgnb = LGN - LG;
   wk.template each<lgnb>([&](int seq, int rr) {
-    cx<T>* p = s + seq * LD + pad(rr << LG);                          // r <= 16 adjacent slots: pad(b0 + m) == pad(b0) + m
+    cx<T>* p = s + seq * LD + pad(rr << LG);                          // r <= 16 adjacent slots: pad(b0 + m) == pad(b0) + pad(m)
     V v[r], u[r];
 #pragma unroll
-    for (int m = 0; m < r; ++m) v[m] = vload(p + m);
+    for (int m = 0; m < r; ++m) v[m] = vload(p + pad(m));
     dft<T, LG, false>(v);
 #pragma unroll
     for (int k = 0; k < r; ++k) u[k] = mid(seq, rr << LG, brevc<LG>(k), v[dft_loc<LG>(k)]);   // slot = b0 + j, j a constant after unrolling
     dft<T, LG, true>(u);
 #pragma unroll
-    for (int m = 0; m < r; ++m) vstore(p + m, u[dft_loc<LG>(m)]);
+    for (int m = 0; m < r; ++m) vstore(p + pad(m), u[dft_loc<LG>(m)]);
   });
   wk.sync();
 }

@@ -390,11 +390,16 @@ __host__ __device__ constexpr int row_ld(int n) { return pad(n) + ((4 - pad(n) %
 #ifndef CMBL_XLG_SMALL
 #define CMBL_XLG_SMALL 3      // Nx < 1024: radix-8 stages keep 64+ butterflies per stage for the two waves of a row (512²: step 2.58 -> 2.32 ms)
 #endif
+// Twiddle-table entries a row kernel keeps in LDS: the first half of the circle.  With the stage twiddles formed from ONE table read
+// (stage_twiddles: index j * 2^sh < Nx / 2) and the fused top level (index < Nx / 2) nothing beyond it is read; the 4 KB saved at
+// Nx = 1024 are 4 KB less to load per workgroup.
+static_assert(CMBL_TW_REC == 2, "row kernels load half of the twiddle circle: needs the one-read stage twiddles in both precisions");
+__host__ __device__ constexpr int row_tw(int nx) { return nx >> 1; }
 // fused radix-2 levels per stage of a row transform
 __host__ __device__ constexpr int row_xlg(int lgnx) { return lgnx >= 10 ? CMBL_XLG : CMBL_XLG_SMALL; }
 template <typename T> __host__ __device__ constexpr int row_rpw(int lgnx, int na) {
   for (int rpw = (lgnx >= 10 ? 4 : CMBL_RPW_SMALL); rpw >= 1; rpw >>= 1)
-    if (((size_t)(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024) return rpw;
+    if (((size_t)row_tw(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024) return rpw;
   return 0;
 }
 // Block -> (slice, first row).  nblk = row groups of the launch (slices * ceil(Nyh / RPW)).  The full groups of all slices come
@@ -654,13 +659,13 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + Nx;
+  cx<T>* s = tw + row_tw(Nx);
   const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh, gridDim.x);
   const int NyhP = mixed_rows(Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx, fo = ((size_t)rg.sl * Nyh + rg.ky0) * Nx;
   CMBL_XWSTAMP(14);
   CMBL_XSTAMP(0);
-  TwStage<T, NT, Nx> twr;
+  TwStage<T, NT, row_tw(Nx)> twr;
   twr.issue(twX);
   if (MODE == 1) rows_load_F<T, LGNX, RPW>(s, in + fo, rg.nr);
   else {

@@ -311,12 +311,12 @@ template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* smem, unsigned blk, unsigned nblk) {
   constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), NT = row_nt(RPW), PF = NH >= 64 ? NH / 64 : 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + Nx;
+  cx<T>* s = tw + row_tw(Nx);
   cx<T>* s2 = s + RPW * LD;                                   // second row set: sequence RPW + row, owned by the same threads
   const RowGroup rg = row_group<RPW>(blk, a.Nyh, nblk);
   const int NyhP = mixed_rows(a.Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx;
-  TwStage<T, NT, Nx> twr;
+  TwStage<T, NT, row_tw(Nx)> twr;
   twr.issue(a.twX);
   {
     cx<T>* const sa[2] = {s, s2};
@@ -351,7 +351,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
     const cx<T>* p2 = s2 + row * LD + pad(b0);
     V va[r], vb[r], u[r];
 #pragma unroll
-    for (int m = 0; m < r; ++m) { va[m] = vload(p1 + m); vb[m] = vload(p2 + m); }
+    for (int m = 0; m < r; ++m) { va[m] = vload(p1 + pad(m)); vb[m] = vload(p2 + pad(m)); }
     dft<T, LG, false>(va);
     dft<T, LG, false>(vb);
 #pragma unroll
@@ -371,7 +371,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
     if (!last) {
       dft<T, LG, true>(u);
 #pragma unroll
-      for (int m = 0; m < r; ++m) vstore(p1 + m, u[dft_loc<LG>(m)]);
+      for (int m = 0; m < r; ++m) vstore(p1 + pad(m), u[dft_loc<LG>(m)]);
     }
   });
   if (last) return;
@@ -393,11 +393,11 @@ template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char* smem, unsigned blk, unsigned nblk) {
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + Nx;
+  cx<T>* s = tw + row_tw(Nx);
   const RowGroup rg = row_group<RPW>(blk, g.Nyh, nblk);
   const int NyhP = mixed_rows(g.Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx;
-  TwStage<T, NT, Nx> twr;
+  TwStage<T, NT, row_tw(Nx)> twr;
   twr.issue(g.twX);
   {
     cx<T>* const sa[1] = {s};
