@@ -331,7 +331,7 @@ struct Ctx : CtxBase {
     return best;
   }
   // column tile: twiddles + C columns of an N-point (pair) or M-point (packed) transform, padded rows
-  size_t ldsY(int C, bool pair = true) const { return ((size_t)2 * M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
+  size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
   // Row launches: one workgroup per group of RPW adjacent ky rows of a slice (RPW = row_rpw<T>(lgNx, row sets), kernels_fft.hpp)
   // Row launches of about one workgroup per CU (258 row groups at 1024^2 QU) run faster when no CU hosts two of them: two co-resident
   // row workgroups are VALU-issue bound and the launch ends with its slowest workgroup.  Asking for more than half of the CU's LDS

@@ -569,17 +569,17 @@ __device__ __forceinline__ void pair_split(const cx<T>* __restrict__ s, F&& f) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// y pass, forward: map -> mixed.   grid (Nx/C, slices).  LDS: twY[2M] (full circle) + C*tile_ld(M) cplx
+// y pass, forward: map -> mixed.   grid (Nx/C, slices).  LDS: twY[M] (half the circle: all that the one-read stage twiddles and the fused levels touch) + C*tile_ld(M) cplx
 template <typename T, int R, int NT, int LGM>
 __global__ __launch_bounds__(NT) void k_y_r2c(const T* __restrict__ in, cx<T>* __restrict__ out, const cx<T>* __restrict__ twY, int Nx) {
   using G = ColTile<R, NT, LGM>;
   constexpr int M = G::M, LD = G::LDM, C = G::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + 2 * M;
+  cx<T>* s = tw + M;                            // half of the twiddle circle (see row_tw)
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
-  TwStage<T, NT, 2 * M> twr;
+  TwStage<T, NT, M> twr;
   twr.issue(twY);
   using PM = PairMap<R, NT, LGM>;
   const cx<T>* src = reinterpret_cast<const cx<T>*>(in) + (sl * Nx + x0) * (size_t)M;
@@ -599,11 +599,11 @@ __global__ __launch_bounds__(NT) void k_y_c2r(const cx<T>* __restrict__ in, T* _
   constexpr int M = G::M, LD = G::LDM, C = G::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + 2 * M;
+  cx<T>* s = tw + M;                            // half of the twiddle circle (see row_tw)
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   using PM = PairMap<R, NT, LGM>;
-  TwStage<T, NT, 2 * M> twr;
+  TwStage<T, NT, M> twr;
   HalfStage<T, NT, LGM, G::LGC> tl;
   twr.issue(twY);
   tl.issue(in + sl * (size_t)mixed_rows(G::Nyh) * Nx, twY, x0);
@@ -626,11 +626,11 @@ __global__ __launch_bounds__(NT) void k_y_mask(const cx<T>* __restrict__ in, cx<
   constexpr int M = G::M, LD = G::LDM, C = G::C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + 2 * M;
+  cx<T>* s = tw + M;                            // half of the twiddle circle (see row_tw)
   const int x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   using PM = PairMap<R, NT, LGM>;
-  TwStage<T, NT, 2 * M> twr;
+  TwStage<T, NT, M> twr;
   HalfStage<T, NT, LGM, G::LGC> tl;
   twr.issue(twY);
   tl.issue(in + sl * (size_t)mixed_rows(G::Nyh) * Nx, twY, x0);

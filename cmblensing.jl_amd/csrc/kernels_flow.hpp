@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + 2 * M;
+  cx<T>* s = tw + M;                            // half of the twiddle circle (see row_tw)
   const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   constexpr int NyhP = mixed_rows(Nyh);
   const size_t moff = sl * (size_t)NyhP * Nx;
   // everything this workgroup needs from HBM is requested before anything is waited for
-  TwStage<T, NT, 2 * M> twr;
+  TwStage<T, NT, M> twr;
   PairStage<T, NT, LGN, LGC> ps;
   twr.issue(a.twY);
   ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, x0);
@@ -265,14 +265,14 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + 2 * M;
+  cx<T>* s = tw + M;                            // half of the twiddle circle (see row_tw)
   const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const size_t sl = blockIdx.y;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
   constexpr int NyhP = mixed_rows(Nyh);
   const size_t moff = sl * (size_t)NyhP * Nx;
-  TwStage<T, NT, 2 * M> twr;
+  TwStage<T, NT, M> twr;
   HalfStage<T, NT, LGM, LGC> tl;
   twr.issue(a.twY);
   tl.issue(a.H + moff, a.twY, x0);
@@ -433,7 +433,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
   const FlowYArgs<T>& a = d.f;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + 2 * M;
+  cx<T>* s = tw + M;                            // half of the twiddle circle (see row_tw)
   const int Nx = a.Nx, x0 = xcd_tile(blockIdx.x, gridDim.x) * C;
   const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
   const T invNy = T(1) / T(2 * M);
@@ -447,7 +447,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   // same request of 511 other workgroups -- the pair tile, which alone gates the first transform, then arrives with the LAST
   // bytes of the burst (in-kernel stamps: first commit at 13.9k cycles of a 39k-cycle workgroup).  So: pair tile first; p(t) and
   // the delta-f tile fly during the first transform; the RK state during the second.
-  TwStage<T, NT, 2 * M> twr;
+  TwStage<T, NT, M> twr;
   PairStage<T, NT, LGN, LGC> ps;
   HalfStage<T, NT, LGM, LGC> th;
   twr.issue(a.twY);
