@@ -10,11 +10,17 @@ the Fourier-diagonal / mask / reduction work, LenseFlow n = 7 RK4 steps, fp32, i
 
 `--config C` runs BASELINE.json's configuration C (2: 512² QU fp32; 3: 1024² T+QU fp32; 5: 2048² QU fp64 n=10) with the same step and
 adds that configuration's own operations (L*f, L'g, Wiener CG / one MAP_joint step / quadratic_estimate) under `extras`.
+`--only cg` (profiling aid, not a headline): the step is ONE Wiener-filter CG iteration (src/numerical_algorithms.jl:73-134).
 
-roofline: `frac` divides SURVEY.md §8(d)'s ALGORITHMIC bytes of the dominant kernel (its share of the reference's pass structure) by
-the kernel's mean launch time and the 8 TB/s peak; `frac_traffic` divides the MEASURED HBM bytes of the same launch (rocprofv3 PMC
-passes, profiles/r02_traffic_*.json) instead -- the utilisation figure -- and `frac_traffic_vs_6300` uses the 6.3 TB/s a streaming copy
-achieves on this part.  `per_kernel` carries the same three numbers for every flow kernel, `whole_step` for the whole step.
+roofline: every fraction in the line is a bandwidth.
+  * `frac` / `achieved`: the COMPULSORY bytes of the dominant kernel's launch -- every array the launch must read or write once,
+    derived per kernel in `compulsory_bytes()` below and in DESIGN.md §5 -- divided by the launch's mean duration (the kernel's own
+    start/stop timestamps, recorded by the library with hipExtLaunchKernel events on the stream it launches on) and by 8 TB/s.
+  * `traffic`: bytes the L2 exchanged with the fabric for the same launch, from separate rocprofv3 `--pmc FETCH_SIZE` / `--pmc
+    WRITE_SIZE` passes (profiles/r03_traffic_*.json, calibrated on known-size copies: profiles/r03_counter_calibration.json);
+    `traffic_over_compulsory` ≈ 1 means no wasted re-reads.  The counters include Infinity-Cache hits.
+  * `survey_equivalent_*` (under `whole_step` only): SURVEY.md §8(d)'s pass structure of the REFERENCE divided by our step time -- a
+    speed-up figure that may exceed the peak because the fused kernels do not move those bytes; never used for `frac`.
 
 N > 1: one process per GPU, every rank runs its own independent posterior chain state (weak scaling, no
 data-path collective); RCCL (`nccl` backend) only gathers the per-chain scalars, as SURVEY.md §8(e) prescribes.
@@ -30,6 +36,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+STREAM_GBS = 6300.0        # what a streaming copy achieves on the part (same guide)
 
 
 def synthetic_cls():
@@ -44,8 +52,8 @@ def synthetic_cls():
     return out
 
 
-def algorithmic_bytes(N, P, B, Bphi, n, s):
-    """SURVEY.md §8(d) formulas (unit = one map-pass = N²·s bytes)."""
+def survey_bytes(N, P, B, Bphi, n, s):
+    """SURVEY.md §8(d) formulas for the REFERENCE's pass structure (unit = one map-pass = N²·s bytes)."""
     mp = N * N * s
     lf = 4 * n * (15 * P * B + 2 * Bphi) * mp
     delta = 4 * n * (30 * P * B + 30 * B + 7 * Bphi) * mp
@@ -54,33 +62,46 @@ def algorithmic_bytes(N, P, B, Bphi, n, s):
     return dict(map_pass=mp, lenseflow=lf, delta_flow=delta, precompute=pre, grad_lnP=grad)
 
 
-# share of SURVEY §8(d)'s per-stage map-passes carried by each of our kernels, per (pol,batch) slice
-KERNEL_SHARE = {
-    "flow_y_fwd": lambda P, B, Bphi: 10.5 * P * B + 2 * Bphi,      # y-halves of rfft/2 irfft, i·ly multiply, velocity ⊕ RK
-    "x_grad": lambda P, B, Bphi: 4.5 * P * B,                      # x-halves of rfft/irfft(∂x), i·lx multiply
-    "adj_y": lambda P, B, Bphi: 7.5 * P * B + 2 * Bphi,
-    "adj_x": lambda P, B, Bphi: 7.5 * P * B,
-    # δ-flow stage = two launches: columns (f part 10.5 + δf part 7.5 per slice) and rows (δf row pass 7.5 + next stage's d/dx pass
-    # 4.5 per slice).  The δϕ update is a quadrature over the stages and is formed once per δ-flow (dphi_reduce + 5 rffts): the
-    # ≈30·B + 5·Bϕ map-passes per stage that SURVEY §8(d) counts for it are work this design does not do.
-    "delta_cols": lambda P, B, Bphi: 18.0 * P * B + 2 * Bphi,
-    "delta_rows": lambda P, B, Bphi: 12.0 * P * B,
-}
+def compulsory_bytes(kernel, Ny, Nx, P, B, Bphi, n, s):
+    """Bytes one launch of `kernel` must move once (mean over the 4n launches of a flow), for the layouts of DESIGN.md §2:
+    map = Ny·Nx·s (real, [x][y]); mixed = mixed_rows(Ny/2+1)·Nx·2s (y-transformed, rows padded to a multiple of 4); F = (Ny/2+1)·Nx·2s.
+    S = P·B slices.  Stage-dependent terms: the RK accumulator is not read in stage 1 of 4 (¾), stage 4 writes the state instead of
+    the accumulator (same size), the last launch of a flow writes no next-stage input (1 − 1/4n).  p(t) (two maps per ϕ slot) is
+    counted once per ϕ slot: the pol slices of a slot read the same lines within one launch (L2 hits; confirmed by the counters).
+    Returns None for kernels without a model."""
+    nyh = Ny // 2 + 1
+    mp, mx, F = Ny * Nx * s, ((nyh + 3) & ~3) * Nx * 2 * s, nyh * Nx * 2 * s
+    S, nst = P * B, 4 * n
+    nl = 1.0 - 1.0 / nst
+    adj_x = S * (2 * mx + F + 0.75 * F + F + nl * mx)                    # Wx, Wy; Y0, acc; acc|Y0; Hnext
+    table = {
+        "x_grad": S * 2 * mx,                                           # A -> Gx
+        "flow_y_fwd": S * (2 * mx + mp + 0.75 * mp + mp + nl * mx) + Bphi * 2 * mp,      # Gx, A; y0, acc; acc|y0; Anext; p(t)
+        "adj_y": S * 3 * mx + Bphi * 2 * mp,                            # H; Wx, Wy; p(t)
+        "adj_x": adj_x,
+        "delta_cols": S * (3 * mx + mp + 0.75 * mp + mp + 2 * mp + 2 * mx + nl * mx) + Bphi * 2 * mp,   # Gx, A, H; y0, acc; acc|y0; w1, w2; Wx, Wy; Anext; p(t)
+        "delta_rows": adj_x + S * nl * 2 * mx,                          # the δf row pass + ∂x of the next stage's f (not in the last launch)
+        "dphi_reduce": Bphi * 5 * mp + nst * 2 * S * mp + 5 * B * mp,   # five ϕ maps; per-stage products; five reduced maps
+        "y_r2c": None, "y_c2r": None,
+    }
+    return table.get(kernel)
 
 
-def measured_traffic(N, P, B, dtype):
-    """HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs, gfx950 correction
-    applied: profiles/r02_traffic_*.json, tools/make_traffic_json.py): ({kernel class: bytes per launch}, bytes per step) or
-    ({}, None) when no profile matches this workload.  It cannot be measured from inside this process."""
-    path = os.path.join(ROOT, "profiles", f"r02_traffic_{N}{'IQU'[3 - P:] if P > 1 else 'I'}_{dtype}.json")
+def measured_traffic(N, P, B, dtype, n, unit="grad"):
+    """L2<->fabric bytes from the committed rocprofv3 PMC passes (profiles/r03_traffic_*.json, tools/run_traffic.sh): ({kernel class:
+    bytes per launch}, bytes per step, file name) or ({}, None, None) when no profile matches this workload.  Counters cannot be
+    read from inside this process."""
+    pol = {1: "I", 2: "QU", 3: "IQU"}[P]
+    name = f"r03_traffic_{'cg_' if unit == 'cg' else ''}{N}{pol}_{dtype}{'_B%d' % B if B > 1 else ''}.json"
+    path = os.path.join(ROOT, "profiles", name)
     try:
         z = json.load(open(path))
         w = z["workload"]
-        if (w["nside"], w["npol"], w["nbatch"], w["dtype"]) != (N, P, B, dtype):
-            return {}, None
-        return {k: v["traffic_bytes_per_launch"] for k, v in z["by_class"].items()}, z.get("total_bytes_per_step")
+        if (w["nside"], w["npol"], w["nbatch"], w["dtype"], w.get("nrk", n)) != (N, P, B, dtype, n):
+            return {}, None, None
+        return {k: v["traffic_bytes_per_launch"] for k, v in z["by_class"].items()}, z.get("total_bytes_per_step"), "profiles/" + name
     except (OSError, KeyError, ValueError):
-        return {}, None
+        return {}, None, None
 
 
 def cpu_baseline(N, pol, nsteps, npT=np.float32):
@@ -105,6 +126,57 @@ CONFIGS = {2: dict(nside=512, pol="P", dtype="f32", nrk=7), 3: dict(nside=1024, 
            5: dict(nside=2048, pol="P", dtype="f64", nrk=10)}
 
 
+def kernel_table(proj, run, nunits, N, P, B, nrk, sz, traf):
+    """Per-kernel-class timings of `run()` (the library's per-launch events: each kernel's own start/stop timestamps) with the
+    compulsory bytes of the classes that have a model and the measured traffic where a profile exists."""
+    proj.prof_reset(); proj.prof_enable(True)
+    run()
+    proj.prof_enable(False)
+    tab = proj.prof_table()
+    per = {}
+    for k, (ms, nl) in sorted(tab.items(), key=lambda kv: -kv[1][0]):
+        t_us = ms / nl * 1e3
+        e = {"ms_per_unit": ms / nunits, "avg_launch_us": t_us, "launches_per_unit": nl / nunits}
+        cb = compulsory_bytes(k, N, N, P, B, B, nrk, sz)
+        if cb:
+            e["compulsory_bytes_per_launch"] = cb
+            e["achieved_GBps"] = cb / (t_us * 1e-6) / 1e9
+            e["frac"] = e["achieved_GBps"] / PEAK_GBS
+        if k in traf:
+            e["traffic_bytes_per_launch"] = traf[k]
+            e["frac_traffic"] = traf[k] / (t_us * 1e-6) / 1e9 / PEAK_GBS
+            if cb:
+                e["traffic_over_compulsory"] = traf[k] / cb
+        per[k] = e
+    return per
+
+
+def cg_block(C, torch, sim, nit=40):
+    """One Wiener-filter CG iteration (src/numerical_algorithms.jl:73-134 driving src/maximization.jl:17-42), per kernel class."""
+    ds, phi, proj = sim["ds"], sim["phi"], sim["proj"]
+    ds.argmaxf_logpdf(phi, tol=0.0, nsteps=4)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ds.argmaxf_logpdf(phi, tol=0.0, nsteps=nit)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    N, P = proj.Nx, ds.P
+    sz = 4 if proj.T == torch.float32 else 8
+    dtype = "f32" if sz == 4 else "f64"
+    traf, traf_unit, src = measured_traffic(N, P, 1, dtype, ds.L.nsteps, unit="cg")
+    os.environ["CMBL_SLICE_STREAMS"] = "1"
+    per = kernel_table(proj, lambda: ds.argmaxf_logpdf(phi, tol=0.0, nsteps=nit), nit, N, P, 1, ds.L.nsteps, sz, traf)
+    os.environ.pop("CMBL_SLICE_STREAMS")
+    flow = ("x_grad", "flow_y_fwd", "adj_y", "adj_x")
+    out = {"ms_per_iteration": dt / nit * 1e3, "iterations_timed": nit,
+           "launches_per_iteration": sum(v["launches_per_unit"] for v in per.values()),
+           "non_flow_launches_per_iteration": sum(v["launches_per_unit"] for k, v in per.items() if k not in flow),
+           "per_kernel": per,
+           "note": "ms_per_iteration: wall clock of a fixed-length run (tol = 0) / iterations, set-up launches (b = L'B'M'Cn^-1 d, first "
+                   "residual) included; per_kernel from a second run with per-launch events, one launch over all pol slices"}
+    if traf_unit:
+        out.update(traffic_GB_per_iteration=traf_unit / 1e9, frac_traffic=traf_unit / (dt / nit) / 1e9 / PEAK_GBS, traffic_source=src)
+    return out
+
+
 def config_extras(C, torch, cfg, sim, timeit):
     """the operations BASELINE.json names for configuration `cfg`, timed outside the headline region"""
     ds, f, phi = sim["ds"], sim["f"], sim["phi"]
@@ -115,12 +187,14 @@ def config_extras(C, torch, cfg, sim, timeit):
     if cfg == 2:
         t0 = time.perf_counter(); fw, h = ds.argmaxf_logpdf(phi); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         ex.update(wiener_cg_iterations=len(h), wiener_cg_ms=dt * 1e3, wiener_cg_ms_per_iteration=dt * 1e3 / len(h))
+        ex["cg_iteration"] = cg_block(C, torch, sim)
     if cfg == 3:
         p0 = C.Field(sim["proj"], torch.zeros_like(phi.arr), C.FOURIER)
         C.MAP_joint_step(ds, p0, cg_nsteps=100)
         t0 = time.perf_counter(); st = C.MAP_joint_step(ds, p0, cg_nsteps=100); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         ex.update(map_joint_step_ms=dt * 1e3, map_joint_cg_iterations=len(st["cg_hist"]), map_joint_linesearch_evals=st["linesearch_evals"],
                   map_joint_note="one MAP_joint step from ϕ = 0: Wiener CG capped at 100 iterations + ∇logpdf(Mixed) + Brent line search")
+        ex["cg_iteration"] = cg_block(C, torch, sim)
     if cfg == 5:
         C.quadratic_estimate(ds, "EB")
         t0 = time.perf_counter(); C.quadratic_estimate(ds, "EB"); torch.cuda.synchronize()
@@ -139,8 +213,10 @@ def main():
     ap.add_argument("--nrk", type=int, default=7, help="LenseFlow RK4 steps")
     ap.add_argument("--nbatch", type=int, default=1, help="chains per GPU (batch dim 4)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5], help="BASELINE.json configuration (0 = the headline workload)")
+    ap.add_argument("--only", default="", choices=["", "cg"], help="profiling aid: the step is one Wiener-CG iteration instead of ∇lnP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets the N>1 logic be exercised on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -155,9 +231,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = None
-    if world > 1:
+    rccl = None
+    if world > 1 or os.environ.get("CMBL_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         if args.dist_backend == "gloo":
             local = local % max(torch.cuda.device_count(), 1)
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -178,6 +256,18 @@ def main():
                      nsteps=nrk, Nbatch=B, seeds=seeds)
     ds, proj = sim["ds"], sim["proj"]
     fo, po = ds.mix(sim["f"], sim["phi"])
+
+    if args.only == "cg":
+        # one unit = one CG iteration: a fixed-length solve (tol = 0) of steps + warmup iterations in total
+        def run_all():
+            return ds.argmaxf_logpdf(sim["phi"], tol=0.0, nsteps=args.steps + args.warmup)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run_all()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "Wiener-filter CG iterations/s (profiling aid)", "value": (args.steps + args.warmup) / dt, "unit": "iterations/s",
+                          "ms_per_step": dt / (args.steps + args.warmup) * 1e3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"workload": f"{N}² {pol} Wiener CG iteration"}}, ensure_ascii=False))
+        return
 
     def step():
         return ds.gradient_logpdf_mixed(fo, po)
@@ -205,6 +295,12 @@ def main():
         allp = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)
         lps = torch.cat(allp).cpu().numpy()
+        # who took part, as the collective library sees it: rank, device index and PCI bus id of every rank
+        prop = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "device": local, "name": prop.name, "pci_bus_id": getattr(prop, "pci_bus_id", None), "uuid": str(getattr(prop, "uuid", ""))}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": everyone}
     else:
         lps = np.asarray(lp)
     assert np.all(np.isfinite(lps)), lps
@@ -222,54 +318,46 @@ def main():
                    "nside": N, "npol": P, "chains_per_gpu": B, "rk4_steps": nrk, "parallelism": f"{world} independent chains (no data-path collective)"},
         "logpdf": [float(x) for x in lps],
     }
+    if rccl is not None:
+        out["collective"] = rccl
 
     if rank == 0 and not args.no_roofline:
-        # per-launch HIP events on the library's stream over a re-run of (at most 20 of) the same steps.  The timed region above
-        # runs each pol slice as its own launch chain on its own stream (concurrent half-size launches have no individual
-        # bandwidth), so this leg switches that off: one launch over all slices, the same kernels.
+        # per-launch timestamps over a re-run of (at most 20 of) the same steps.  The timed region above runs each pol slice as its
+        # own launch chain on its own stream (concurrent half-size launches have no individual bandwidth), so this leg switches that
+        # off: one launch over all slices, the same kernels.
         os.environ["CMBL_SLICE_STREAMS"] = "1"
         nprof = min(args.steps, 20)
-        proj.prof_reset(); proj.prof_enable(True)
-        for _ in range(nprof):
-            step()
-        proj.prof_enable(False)
+        traf, traf_step, traf_src = measured_traffic(N, P, B, args.dtype, nrk)
+        per = kernel_table(proj, lambda: [step() for _ in range(nprof)], nprof, N, P, B, nrk, sz, traf)
         os.environ.pop("CMBL_SLICE_STREAMS")
-        tab = proj.prof_table()
-        tot = sum(v[0] for v in tab.values())
-        ab = algorithmic_bytes(N, P, B, B, nrk, sz)
-        traf, traf_step = measured_traffic(N, P, B, args.dtype)
-        per = {}
-        for k, (ms, nl) in sorted(tab.items(), key=lambda kv: -kv[1][0]):
-            t_us = ms / nl * 1e3
-            e = {"ms_per_step": ms / nprof, "avg_launch_us": t_us, "launches_per_step": nl / nprof}
-            if k in KERNEL_SHARE:
-                e["algorithmic_bytes_per_launch"] = KERNEL_SHARE[k](P, B, B) * ab["map_pass"]
-                e["frac"] = e["algorithmic_bytes_per_launch"] / (t_us * 1e-6) / 8e12
-            if k in traf:
-                e["traffic_bytes_per_launch"] = traf[k]
-                e["frac_traffic"] = traf[k] / (t_us * 1e-6) / 8e12
-                e["frac_traffic_vs_6300"] = traf[k] / (t_us * 1e-6) / 6.3e12
-            per[k] = e
-        dom = max((k for k in per if k in KERNEL_SHARE), key=lambda k: per[k]["ms_per_step"])
+        tot = sum(v["ms_per_unit"] for v in per.values())
+        dom = max((k for k in per if "frac" in per[k]), key=lambda k: per[k]["ms_per_unit"])
         d = per[dom]
-        whole = {"survey_algorithmic_GB": ab["grad_lnP"] / 1e9,
-                 "survey_equivalent_GB_per_s": ab["grad_lnP"] / 1e9 / (ms_per_step * 1e-3),
-                 "survey_equivalent_frac": ab["grad_lnP"] / 1e9 / (ms_per_step * 1e-3) / 8000.0,
-                 "note": "survey_equivalent_* divides SURVEY §8(d)'s pass structure of the REFERENCE (31.5 GB at 1024² QU) by our step time: "
-                         "a speed-up figure, not a bandwidth; traffic_* are the measured HBM bytes of our launches"}
+        sb = survey_bytes(N, P, B, B, nrk, sz)
+        modelled = sum(v["compulsory_bytes_per_launch"] * v["launches_per_unit"] for v in per.values() if "frac" in v)
+        whole = {"launches_per_step": sum(v["launches_per_unit"] for v in per.values()),
+                 "non_flow_launches_per_step": sum(v["launches_per_unit"] for k, v in per.items() if "frac" not in v),
+                 "compulsory_GB_per_step_flow_kernels": modelled / 1e9,
+                 "flow_kernels_GBps": modelled / 1e9 / (ms_per_step * 1e-3),
+                 "survey_equivalent_GB": sb["grad_lnP"] / 1e9,
+                 "survey_equivalent_GBps": sb["grad_lnP"] / 1e9 / (ms_per_step * 1e-3),
+                 "note": "survey_equivalent_* = SURVEY §8(d)'s pass structure of the REFERENCE divided by our step time: a speed-up figure, "
+                         "not a bandwidth (the fused kernels do not move those bytes).  traffic_* = measured L2<->fabric bytes of all launches of a step."}
         if traf_step:
-            whole.update(traffic_GB_per_step=traf_step / 1e9, traffic_GB_per_s=traf_step / 1e9 / (ms_per_step * 1e-3),
-                         frac_traffic=traf_step / (ms_per_step * 1e-3) / 8e12, frac_traffic_vs_6300=traf_step / (ms_per_step * 1e-3) / 6.3e12)
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["algorithmic_bytes_per_launch"] / (d["avg_launch_us"] * 1e-6) / 1e9,
-                           "peak": 8000.0, "unit": "GB/s", "frac": d["frac"], "traffic": d.get("traffic_bytes_per_launch"),
-                           "frac_traffic": d.get("frac_traffic"), "frac_traffic_vs_6300": d.get("frac_traffic_vs_6300"),
-                           "avg_launch_us": d["avg_launch_us"], "launches_per_step": d["launches_per_step"],
-                           "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "kernel_time_share": d["ms_per_step"] * nprof / tot,
-                           "note": "per-kernel figures from a re-run with CMBL_SLICE_STREAMS=1 (one launch over all pol slices); "
-                                   "value / ms_per_step / whole_step are the timed region with one launch chain per pol slice; "
-                                   "`frac` = SURVEY-algorithmic bytes, `frac_traffic` = measured HBM bytes (profiles/r02_traffic_*.json)",
+            whole.update(traffic_GB_per_step=traf_step / 1e9, traffic_GBps=traf_step / 1e9 / (ms_per_step * 1e-3),
+                         frac_traffic=traf_step / (ms_per_step * 1e-3) / 1e9 / PEAK_GBS,
+                         frac_traffic_vs_streaming=traf_step / (ms_per_step * 1e-3) / 1e9 / STREAM_GBS)
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+                           "traffic": d.get("traffic_bytes_per_launch"), "traffic_over_compulsory": d.get("traffic_over_compulsory"),
+                           "traffic_source": traf_src, "frac_vs_streaming_copy": d["achieved_GBps"] / STREAM_GBS,
+                           "avg_launch_us": d["avg_launch_us"], "launches_per_step": d["launches_per_unit"],
+                           "compulsory_bytes_per_launch": d["compulsory_bytes_per_launch"], "kernel_time_share": d["ms_per_unit"] / tot,
+                           "note": "achieved = compulsory bytes of one launch (bench.py compulsory_bytes, DESIGN.md §5) / mean kernel duration "
+                                   "(the kernel's own start/stop timestamps, hipExtLaunchKernel events; one launch over all pol slices, "
+                                   "CMBL_SLICE_STREAMS=1); value / ms_per_step / whole_step are the timed region with one launch chain per pol "
+                                   "slice.  traffic = measured L2<->fabric bytes per launch (rocprofv3 PMC, Infinity-Cache hits included)",
                            "per_kernel": per, "whole_step": whole}
-    if rank == 0 and args.config:
+    if rank == 0 and not args.no_extras and world == 1:
         def timeit(fn, n=10):
             for _ in range(2):
                 fn()
@@ -278,7 +366,18 @@ def main():
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n * 1e3
-        out["extras"] = config_extras(C, torch, args.config, sim, timeit)
+        if args.config:
+            out["extras"] = config_extras(C, torch, args.config, sim, timeit)
+        elif B == 1 and not args.no_roofline:
+            # the driver-level hot loop: one Wiener-filter CG iteration on this workload and on its T+QU sibling
+            ex = {"cg_iteration": {f"{N}_{pol}": cg_block(C, torch, sim)}}
+            if pol == "P" and args.dtype == "f32":
+                sim3 = C.load_sim(2.0, N, "IP", synthetic_cls(), T=tT, device=local, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=nrk)
+                ex["cg_iteration"][f"{N}_IP"] = cg_block(C, torch, sim3)
+                fo3, po3 = sim3["ds"].mix(sim3["f"], sim3["phi"])
+                ex["grad_lnP_ms_IP"] = timeit(lambda: sim3["ds"].gradient_logpdf_mixed(fo3, po3), n=20)
+                ex["grad_lnP_IP_note"] = f"{N}² T+QU (BASELINE configs[2] workload, the north_star target): ∇logpdf(Mixed) step, mean of 20"
+            out["extras"] = ex
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, pol, nrk, npT)
     if rank == 0:
