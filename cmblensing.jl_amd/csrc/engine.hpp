@@ -13,6 +13,7 @@
 #include "kernels_fft.hpp"
 #include "kernels_pointwise.hpp"
 #include "kernels_flow.hpp"
+#include "kernels_harm.hpp"
 #include "kernels_generic.hpp"
 
 namespace cmbl {
@@ -34,10 +35,10 @@ inline void raise_lds_limit(const void* fn, size_t bytes) {
 }
 // kernel classes for the optional per-launch event timing (cmbl_prof_*)
 enum KernelId { K_LAYOUT = 0, K_Y_R2C, K_Y_C2R, K_X_FFT, K_X_GRAD, K_FLOW_Y, K_ADJ_Y, K_ADJ_X, K_DELTA_Y, K_DELTA_ROWS, K_DPHI_Y, K_DPHI_X,
-                K_GRADHESS, K_HARM, K_LINCOMB, K_MASK, K_REDUCE, K_GEN_DFT, K_GEN_POINT, K_CG, K_COUNT };
+                K_GRADHESS, K_HARM, K_LINCOMB, K_MASK, K_REDUCE, K_GEN_DFT, K_GEN_POINT, K_CG, K_XPW, K_PWFLAT, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x_fft", "x_grad", "flow_y_fwd", "adj_y", "adj_x", "delta_cols", "delta_rows",
                                                   "dphi_reduce", "dphi_combine", "gradhess_mult", "harm_apply", "lincomb", "mask_mul", "reduce",
-                                                  "generic_dft", "generic_pointwise", "cg_update"};
+                                                  "generic_dft", "generic_pointwise", "cg_update", "x_harm", "harm_dot"};
 
 // With profiling on, the launch goes through hipExtLaunchKernelGGL, whose start / stop events carry the kernel's OWN begin and end
 // timestamps (what rocprofv3's kernel trace reports); an event pair recorded around a plain launch also brackets its dispatch (+2 us).
@@ -446,6 +447,66 @@ struct Ctx : CtxBase {
     CMBL_LAUNCH(this, K_MASK, (k_mask_mul<T>), dim3(gx, (unsigned)slices), 0, stream, out, in, m, npix());
   }
 
+  // ---- fused harmonic work (kernels_harm.hpp) -----------------------------------------------------------------------------
+  // partial sums of the fused launches: region r of dot_part holds [B][nblk] doubles of one producer (PART_*), finished by its consumer
+  enum PartRegion { PART_QF = 0, PART_QP, PART_QN, PART_CG_RZ, PART_CG_PAP, PART_COUNT };
+  static constexpr size_t PART_STRIDE = (size_t)64 * 2048;                 // doubles per region: B <= 64, blocks per slot <= 2048
+  DevBuf dot_part;
+  ModeGeom<T> geom() const { return ModeGeom<T>{cos2F.as<T>(), sin2F.as<T>(), lam.as<T>(), plane(), Nx}; }
+  double dot_scale() const { return 1.0 / ((double)Ny * Nx); }
+  DotOut dot_out(int region, int nblk, int B) {
+    CMBL_REQUIRE((size_t)B * nblk <= PART_STRIDE, ERR_SHAPE, "too many partial sums");
+    dot_part.ensure(sizeof(double) * PART_STRIDE * PART_COUNT);
+    return DotOut{dot_part.as<double>() + (size_t)region * PART_STRIDE, nblk, sum_mode};
+  }
+  // row carrier: P pol slices of each of B batch slots; in: mixed (IN_F = false) or F (true); out_mixed nullable.  Returns where the
+  // launch left its partial sums (region `region`)
+  template <int P, bool IN_F, typename PW> DotOut x_pw(const cx<T>* in, cx<T>* out_mixed, const PW& pw, int B, bool herm = false, int region = 0) {
+    CMBL_REQUIRE(!generic, ERR_STATE, "fused row pass called on the any-size path");
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    DotOut o{};
+    dispatch_row([&](auto lgnx) {
+      constexpr int LGNX = decltype(lgnx)::value, RPW = xpw_rpw<T>(LGNX, P);
+      if constexpr (RPW > 0) {
+        const int G = (Nyh + RPW - 1) / RPW;
+        o = dot_out(region, G, B);
+        CMBL_LAUNCH_NT(this, K_XPW, xpw_nt(P, RPW), (k_x_pw<T, LGNX, RPW, P, IN_F, PW>), dim3((unsigned)(B * G)), ldsX(RPW, P), stream, in, out_mixed,
+                       twX.as<cx<T>>(), XPwIo{Nyh, herm ? 1 : 0}, pw, o, B);
+      } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
+    });
+    return o;
+  }
+  int flat_blocks(int B) const { return (int)std::max<long>(1, std::min<long>((plane() + NTP - 1) / NTP, std::max(64, 1024 / B))); }
+  template <typename PW> DotOut pw_flat(const PW& pw, int B, int region = 0) {
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    const int nblk = flat_blocks(B);
+    const DotOut o = dot_out(region, nblk, B);
+    CMBL_LAUNCH(this, K_PWFLAT, (k_pw_flat<T, PW>), dim3((unsigned)nblk, (unsigned)B), 0, stream, pw, o, plane(), Nx, B);
+    return o;
+  }
+  // totals of up to four producers' partials -> out[j][b] (device doubles), one launch
+  void finish_parts(const DotOut* parts, double* const* outs, int nreg, int B) {
+    PartRegions r{};
+    for (int j = 0; j < nreg; ++j) { r.part[j] = parts[j].part; r.nblk[j] = parts[j].nblk; r.out[j] = outs[j]; }
+    CMBL_LAUNCH(this, K_REDUCE, (k_finish_parts<T>), dim3((unsigned)(nreg * B)), 0, stream, r, B, dot_scale(), sum_mode);
+  }
+  // can the five-map delta-phi epilogue run as one row launch (five row sets in LDS)?
+  bool x_dphi_fits() const {
+    bool ok = false;
+    if (!generic) dispatch_row([&](auto lgnx) { ok = row_rpw<T>(decltype(lgnx)::value, 5) > 0; });
+    return ok;
+  }
+  void x_dphi(const cx<T>* in_mixed5, cx<T>* out, int B, const DphiTail<T>& tail) {
+    dispatch_row([&](auto lgnx) {
+      constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 5);
+      if constexpr (RPW > 0) {
+        const int G = (Nyh + RPW - 1) / RPW;
+        CMBL_LAUNCH_NT(this, K_DPHI_X, row_nt(RPW), (k_x_dphi<T, LGNX, RPW>), dim3((unsigned)(B * G)), ldsX(RPW, 5), stream, in_mixed5, out, twX.as<cx<T>>(),
+                       lx_r.as<T>(), ly.as<T>(), Nyh, B, tail);
+      } else fail(ERR_SHAPE, "row tile does not fit LDS");
+    });
+  }
+
   // ---- per-batch reductions (src/proj_lambert.jl:318-353) ----------------------------------------------------------------
   // reduce_dev: two launches, the B results land in `out_dev` (device doubles); nothing synchronises.  `sum_mode` selects the
   // accumulation (set_sum_accuracy_mode!, src/util.jl:288-316).
@@ -561,7 +622,7 @@ struct Flow {
   DevBuf pcache;                          // [2n+1][2][Bphi][Nx][Ny] : p(t_k)
   bool use_pcache = false;
   DevBuf phiF, gh;                        // scratch for precompute
-  DevBuf A, A2, Gx, y0, acc;              // forward flow state          (slices)
+  DevBuf A, A2, A3, Gx, y0, acc;          // forward flow state          (slices); A3: second primary y-transform buffer (see flow_map)
   DevBuf H, Wx, Wy, Y0, Yacc;             // adjoint flow state          (slices)
   DevBuf P0;                              // delta flow: dphi result (F layout)
   DevBuf cvt;                             // boundary conversion scratch
@@ -785,7 +846,7 @@ struct Flow {
     dphi_finish(dphi, P, B, nst, alias_quirk);
   }
   // delta-phi: quadrature over the stored stages, five real transforms, the l-multipliers (shared by both paths)
-  void dphi_finish(cx<T>* dphi, int P, int B, int nst, bool alias_quirk) {
+  void dphi_finish(cx<T>* dphi, int P, int B, int nst, bool alias_quirk, const DphiTail<T>* tail = nullptr) {
     const long pl = c->plane(), np = c->npix();
     TcTab<T> tcv{};
     const T* tcd = nullptr;
@@ -798,21 +859,37 @@ struct Flow {
     else
       CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T, 1>), dim3((unsigned)std::min<long>((np + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
                   tcv, tcd, U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
+    if (c->x_dphi_fits() && env_int("CMBL_NO_FUSED_HARM", 0) == 0) {
+      // the five x transforms and the l-multipliers in one row launch (five row sets in LDS), the caller's tail on top
+      cx<T>* m5 = c->mixed_scratch(5L * B);
+      c->y_r2c(U5.as<T>(), m5, 5L * B);
+      c->x_dphi(m5, dphi, B, tail ? *tail : DphiTail<T>{nullptr, nullptr, nullptr});
+      return;
+    }
     c->rfft2_F(U5.as<T>(), F5.as<cx<T>>(), 5L * B);
     CMBL_LAUNCH(c, K_DPHI_X, (k_dphi_combine<T>), dim3((unsigned)((pl + NTP - 1) / NTP)), 0, c->stream, F5.as<cx<T>>(), dphi, c->lx_r.template as<T>(),
                 c->ly.template as<T>(), c->Nx, pl, B);
+    if (tail && tail->Ginv) {                                               // unfused tail: dphi = Ginv * (dphi + add1 - sub1)
+      PwPhiGrad<T> g{pl, tail->Ginv, dphi, tail->add1, tail->sub1, dphi};
+      c->pw_flat(g, B);
+    }
   }
 
-  // L*f (inverse=false) or L\f (inverse=true) on maps; out may alias in
-  void flow_map(const T* in, T* out, int P, int B, bool inverse) {
+  // L*f (inverse=false) or L\f (inverse=true) on maps; out may alias in.
+  // abuf: the primary y-transform buffer of this flow (default A; the ping-pong partner is always A2).  a_ready: abuf already holds
+  // rfft_y(in) (written by a fused row pass), so the initial y pass is skipped.  emit_last: the last stage also leaves rfft_y(out) --
+  // in abuf again, the number of stages being even -- for a caller that continues in Fourier space.
+  cx<T>* abuf_ensure(DevBuf& b, long slices) { b.ensure(sizeof(cx<T>) * slices * c->mplane()); return b.template as<cx<T>>(); }
+  void flow_map(const T* in, T* out, int P, int B, bool inverse, bool a_ready = false, bool emit_last = false, DevBuf* abuf = nullptr) {
     check_ready(B);
     if (c->generic) return gen_flow_map(in, out, P, B, inverse);
     const long slices = (long)P * B, pl = c->mplane(), np = c->npix();          // A, Gx: mixed layout
-    A.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
+    DevBuf& Ab = abuf ? *abuf : A;
+    Ab.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
     acc.ensure(sizeof(T) * slices * np);
     T* y = out;
-    cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
-    c->y_r2c(in, a_cur, slices);                                             // the first RK step reads the state from `in` (y0r), the rest from `out`
+    cx<T>* a_cur = Ab.template as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
+    if (!a_ready) c->y_r2c(in, a_cur, slices);                             // the first RK step reads the state from `in` (y0r), the rest from `out`
     const int K = groups(P, B);
     const long gs = slices / K;                                            // slices per group
     const auto tile = c->tileY(gs, true);
@@ -828,7 +905,7 @@ struct Flow {
           a.A = a_cur + so * pl; a.Gx = Gx.as<cx<T>>() + so * pl; a.Anext = a_nxt + so * pl; a.y0 = y + so * np; a.acc = acc.as<T>() + so * np;
           a.y0r = (step == 0 ? in : y) + so * np;
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
-          a.Nx = c->Nx; a.P = P;
+          a.Nx = c->Nx; a.P = P; a.emit_last = emit_last ? 1 : 0;
           a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
           a.ph = ph(a.rk.t, phi_off(g, K, B));
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
@@ -842,14 +919,16 @@ struct Flow {
   }
 
   // L'*g (inverse=false, t 1->0) or L'\g (inverse=true, t 0->1); F layout, QU-Fourier basis; out may alias in
-  void flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse) {
+  // h_ready: H already holds ifft_x(in) in the mixed layout (written by a fused row pass next to `in` itself)
+  cx<T>* hbuf_ensure(long slices) { H.ensure(sizeof(cx<T>) * slices * c->mplane()); return H.as<cx<T>>(); }
+  void flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse, bool h_ready = false) {
     check_ready(B);
     if (c->generic) return gen_flow_adj_F(in, out, P, B, inverse);
     const long slices = (long)P * B, pl = c->plane(), mpl = c->mplane();
     H.ensure(sizeof(cx<T>) * slices * mpl); Wx.ensure(sizeof(cx<T>) * slices * mpl); Wy.ensure(sizeof(cx<T>) * slices * mpl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
-    c->template x_pass<1>(out, H.as<cx<T>>(), slices);
+    if (!h_ready) c->template x_pass<1>(out, H.as<cx<T>>(), slices);
     const int K = groups(P, B);
     const long gs = slices / K;
     const auto tile = c->tileY(gs, true);
@@ -887,20 +966,24 @@ struct Flow {
   // forward_primal=true : pullback of L*f  -> integrate t 1->0;  false: pullback of L\f -> t 0->1.
   // Two launches per RK stage (k_delta_cols, k_delta_rows) for the (f, delta f) chain; the stage's partial products go to a
   // per-stage buffer and delta-phi -- a pure quadrature over the stages -- is formed once at the end (k_dphi_reduce, 5 rffts, combine).
-  void flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
+  // a_ready / abuf: as in flow_map (abuf holds rfft_y(f)); h_ready: H holds ifft_x(df); tail: the last line of the posterior gradient
+  // rides on the delta-phi epilogue (dphi_finish)
+  void flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk, bool a_ready = false, DevBuf* abuf = nullptr,
+                  bool h_ready = false, const DphiTail<T>* tail = nullptr) {
     check_ready(B);
-    if (c->generic) return gen_flow_delta(f, df, dphi, P, B, forward_primal, alias_quirk);
+    if (c->generic) { CMBL_REQUIRE(!tail, ERR_STATE, "fused tail on the any-size path"); return gen_flow_delta(f, df, dphi, P, B, forward_primal, alias_quirk); }
     const long slices = (long)P * B, pl = c->plane(), mpl = c->mplane(), np = c->npix();
     const int nst = 4 * n;
-    A.ensure(sizeof(cx<T>) * slices * mpl); A2.ensure(sizeof(cx<T>) * slices * mpl); Gx.ensure(sizeof(cx<T>) * slices * mpl);
+    DevBuf& Ab = abuf ? *abuf : A;
+    Ab.ensure(sizeof(cx<T>) * slices * mpl); A2.ensure(sizeof(cx<T>) * slices * mpl); Gx.ensure(sizeof(cx<T>) * slices * mpl);
     acc.ensure(sizeof(T) * slices * np);
     H.ensure(sizeof(cx<T>) * slices * mpl); Wx.ensure(sizeof(cx<T>) * slices * mpl); Wy.ensure(sizeof(cx<T>) * slices * mpl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);
     Wst.ensure(sizeof(T) * (size_t)nst * 2 * slices * np);              // 4n x 2 maps per slice: 448 MB at 1024^2 QU fp32, n = 7
     U5.ensure(sizeof(T) * 5 * B * np); F5.ensure(sizeof(cx<T>) * 5 * B * pl); tcbuf.ensure(sizeof(T) * 2 * nst);
-    cx<T>* a_cur = A.as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
-    c->y_r2c(f, a_cur, slices);
-    c->template x_pass<1>(df, H.as<cx<T>>(), slices);
+    cx<T>* a_cur = Ab.template as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
+    if (!a_ready) c->y_r2c(f, a_cur, slices);
+    if (!h_ready) c->template x_pass<1>(df, H.as<cx<T>>(), slices);
     const int K = groups(P, B);
     const long gs = slices / K;
     const auto tile = c->tileY(gs, true);
@@ -945,7 +1028,7 @@ struct Flow {
         std::swap(a_cur, a_nxt);
       }
     join(K);
-    dphi_finish(dphi, P, B, nst, alias_quirk);
+    dphi_finish(dphi, P, B, nst, alias_quirk, tail);
   }
 
   // ---- boundary-level entry points ---------------------------------------------------------------
@@ -1065,6 +1148,75 @@ struct Dataset {
     }
   }
 
+  // ---- fused path (kernels_harm.hpp; power-of-two maps) ----------------------------------------------------------------------------
+  bool fused() const { return !c->generic && env_int("CMBL_NO_FUSED_HARM", 0) == 0; }
+  OpRef<T> opref(int which, bool transpose = false) const {
+    const Op& o = op(which);
+    OpRef<T> r{};
+    for (int k = 0; k < 5; ++k) r.d[k] = o.d[k];
+    r.kind = o.kind; r.transpose = transpose ? 1 : 0;
+    return r;
+  }
+  template <typename Fn> void by_pol(Fn&& fn) const {
+    if (P == 1) fn(std::integral_constant<int, 1>{}); else if (P == 2) fn(std::integral_constant<int, 2>{}); else fn(std::integral_constant<int, 3>{});
+  }
+  DevBuf m1;                                 // mixed-layout scratch of the data-space part
+  // From rfft_y(L f) in `a_ftil` (mixed, left intact) to  w = scale * B'M' Cn^-1 (M B L f - d):  w in QU Fourier to `w_F` (F layout) and
+  // ifft_x(w) to L.H (mixed), ready for an adjoint / delta flow with h_ready.  Returns where the
+  // partial sums of (MBLf - d)' Cn^-1 (MBLf - d) were left.  value_only: stop after the quadratic form.  dd == nullptr: d = 0.   (src/dataset.jl:59-66,76-80)
+  DotOut data_space(Flow<T>& L, const cx<T>* a_ftil, const cx<T>* dd, int dB, T scale, cx<T>* w_F, bool value_only, int B) {
+    const long sl = (long)P * B;
+    DotOut qn{};
+    cx<T>* H = value_only ? nullptr : L.hbuf_ensure(sl);
+    by_pol([&](auto pp) {
+      constexpr int PP = decltype(pp)::value;
+      const ModeGeom<T> g = c->geom();
+      if (has(OP_MPIX)) {
+        m1.ensure(sizeof(cx<T>) * sl * c->mplane());
+        cx<T>* m = m1.template as<cx<T>>();
+        PwChain<T, PP> b1{g, {}, 1, 1, nullptr, T(0), nullptr, T(1)};
+        b1.ch.push(opref(OP_B));
+        c->template x_pw<PP, false>(a_ftil, m, b1, B);                                  // beam
+        c->y_mask(m, m, ops[OP_MPIX].d[0], sl);                                         // pixel mask
+        PwResid<T, PP> rs{g, {}, {}, opref(OP_CN_INV), dd, dB, T(1), nullptr};
+        rs.pre.push(opref(OP_MF)); rs.post.push(opref(OP_MF, true));
+        qn = c->template x_pw<PP, false>(m, value_only ? nullptr : m, rs, B, false, Ctx<T>::PART_QN);   // Fourier mask, residual, Cn^-1, quadratic form, Fourier mask'
+        if (value_only) return;
+        c->y_mask(m, m, ops[OP_MPIX].d[0], sl);                                         // pixel mask'
+        PwChain<T, PP> b2{g, {}, 1, 1, nullptr, T(0), w_F, scale};
+        b2.ch.push(opref(OP_B, true));
+        c->template x_pw<PP, false>(m, H, b2, B);                                       // beam', w stored, ifft_x(w) -> H
+      } else {
+        PwResid<T, PP> rs{g, {}, {}, opref(OP_CN_INV), dd, dB, scale, value_only ? nullptr : w_F};
+        rs.pre.push(opref(OP_B)); rs.pre.push(opref(OP_MF));
+        rs.post.push(opref(OP_MF, true)); rs.post.push(opref(OP_B, true));
+        qn = c->template x_pw<PP, false>(a_ftil, H, rs, B, false, Ctx<T>::PART_QN);
+      }
+    });
+    return qn;
+  }
+  // f (harmonic F) -> L f: leaves the lensed maps in `ftil` and rfft_y(L f) in L.A
+  void lens_from_harmonic(Flow<T>& L, const cx<T>* f_h, T* ftil, int B) {
+    const long sl = (long)P * B;
+    mp2.ensure(sizeof(T) * sl * c->npix());
+    cx<T>* a = L.abuf_ensure(L.A, sl);
+    by_pol([&](auto pp) {
+      constexpr int PP = decltype(pp)::value;
+      PwChain<T, PP> r{c->geom(), {}, 0, 1, nullptr, T(0), nullptr, T(1)};
+      c->template x_pw<PP, true>(f_h, a, r, B, true);                                   // EB -> QU, ifft_x, Hermitian rows projected
+    });
+    c->y_c2r(a, mp2.template as<T>(), sl);
+    L.flow_map(mp2.template as<T>(), ftil, P, B, false, true, true, &L.A);
+  }
+  // Y = L'B'M'Cn^-1 (d - M B L f)   (QU Fourier, F layout; the data part of gradientf_logpdf)
+  void model_adjoint(Flow<T>& L, const cx<T>* f_h, const cx<T>* dd, int dB, cx<T>* Y, int B) {
+    const long sl = (long)P * B;
+    ftil.ensure(sizeof(T) * sl * c->npix());
+    lens_from_harmonic(L, f_h, ftil.template as<T>(), B);
+    data_space(L, L.A.template as<cx<T>>(), dd, dB, T(-1), Y, false, B);
+    L.flow_adj_F(Y, Y, P, B, false, true);
+  }
+
   // mu = M B L f : harmonic F in (f may be nullptr == 0) -> harmonic F out (t2); uses mp2 for maps
   // `ftil_out`: where the lensed maps f~ = L f are left (default: the scratch mp2)
   void mean(Flow<T>& L, const cx<T>* f_h, cx<T>* out, int B, T* ftil_out = nullptr) {
@@ -1085,6 +1237,12 @@ struct Dataset {
     const long n = fsize(B);
     t2.ensure(sizeof(cx<T>) * n);
     cx<T>* r = t2.template as<cx<T>>();
+    if (f_h && fused()) {
+      model_adjoint(L, f_h, dd, B, r, B);
+      c->harm(r, r, P, B, 0, nullptr, false, true, false);                 // -> harmonic
+      apply(OP_CF_INV, f_h, out, B, false, false, false, r, (T)1, (T)-1);  // out = r - Cf^-1 f
+      return;
+    }
     if (f_h) {
       mean(L, f_h, r, B);
       if (dd) c->lincomb1((T*)r, (const T*)dd, (const T*)r, 1.0, -1.0, 2 * n / B, B);
@@ -1116,7 +1274,80 @@ struct Dataset {
     if (cg_flag_host) (void)hipHostFree(cg_flag_host);
     for (auto& e : cg_ev) if (e) (void)hipEventDestroy(e);
   }
+  // Fused form of the same iteration (power-of-two maps): per iteration the two flows, 7 launches between them (basis change + ifft_x,
+  // c2r, beam, mask, Fourier mask / Cn^-1 / Fourier mask', mask', beam' + ifft_x) and 3 after them (A p and p'Ap -> alpha; x, r, r'z ->
+  // beta and the stop test; p and the best iterate).  Every scalar is produced by the launch that produced its sum.
+  int wiener_cg_fused(Flow<T>& L, const cx<T>* dd, const cx<T>* fstart, double tol, int maxit, cx<T>* f_out, double* hist, int B) {
+    const long n = fsize(B), nr = 2 * n / B;
+    xs.ensure(sizeof(cx<T>) * n); rs.ensure(sizeof(cx<T>) * n); ps.ensure(sizeof(cx<T>) * n);
+    aps.ensure(sizeof(cx<T>) * n); best.ensure(sizeof(cx<T>) * n); bb.ensure(sizeof(cx<T>) * n); zs.ensure(sizeof(cx<T>) * n);
+    cx<T>*x = xs.template as<cx<T>>(), *r = rs.template as<cx<T>>(), *p = ps.template as<cx<T>>(), *Y = zs.template as<cx<T>>();
+    cx<T>*Ap = aps.template as<cx<T>>(), *bx = best.template as<cx<T>>(), *b = bb.template as<cx<T>>();
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    cg_scal.ensure(sizeof(double) * 7 * 64 + sizeof(int) * 8);
+    cg_hist.ensure(sizeof(double) * (size_t)maxit * B);
+    if (!cg_flag_host) {
+      CMBL_HIP(hipHostMalloc((void**)&cg_flag_host, sizeof(int) * 16, hipHostMallocDefault));
+      for (auto& e : cg_ev) CMBL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    CgScal st;
+    double* sd = cg_scal.template as<double>();
+    st.res = sd; st.best = sd + 128;
+    st.hist = cg_hist.template as<double>();
+    int* si = reinterpret_cast<int*>(sd + 448);
+    st.done = si; st.better = si + 2; st.nan = si + 4; st.nh = si + 5;
+    hipStream_t sm = c->stream;
+    std::vector<double> one(B, 1.0), mone(B, -1.0);
+    // b = -gradientf(f=0, d) = -L'B'M'Cn^-1 d
+    gradientf(L, nullptr, dd, b, B);
+    c->lincomb((T*)b, (T*)b, nullptr, mone.data(), nullptr, nr, B);
+    if (fstart) {
+      CMBL_HIP(hipMemcpyAsync(x, fstart, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, sm));
+      gradientf(L, x, nullptr, Ap, B);                                      // A x
+      c->lincomb((T*)r, (T*)b, (T*)Ap, one.data(), mone.data(), nr, B);     // r = b - A x
+    } else {
+      CMBL_HIP(hipMemsetAsync(x, 0, sizeof(cx<T>) * n, sm));
+      CMBL_HIP(hipMemcpyAsync(r, b, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, sm));
+    }
+    const ModeGeom<T> g = c->geom();
+    const double sc = c->dot_scale();
+    by_pol([&](auto pp) {
+      constexpr int PP = decltype(pp)::value;
+      const DotOut o = c->pw_flat(PwCgStart<T, PP>{g, opref(OP_PRECOND_INV), x, r, p, bx}, B, Ctx<T>::PART_CG_RZ);
+      CMBL_LAUNCH(c, K_CG, (k_cg_init<T>), dim3(1), 0, sm, st, o, sc, B);
+    });
+    auto post_flags = [&](int slot) {
+      CMBL_HIP(hipMemcpyAsync(cg_flag_host + 8 * slot, st.done, sizeof(int) * 6, hipMemcpyDeviceToHost, sm));
+      CMBL_HIP(hipEventRecord(cg_ev[slot], sm));
+    };
+    auto wait_flags = [&](int slot) { CMBL_HIP(hipEventSynchronize(cg_ev[slot])); return cg_flag_host + 8 * slot; };
+    post_flags(0);
+    int par = 0;
+    if (wait_flags(0)[4] == 0) {                                            // a NaN start residual is reported below
+      for (int it = 2; it <= maxit; ++it) {
+        model_adjoint(L, p, nullptr, B, Y, B);                              // Y = -L'B'M'Cn^-1 M B L p
+        by_pol([&](auto pp) {
+          constexpr int PP = decltype(pp)::value;
+          const DotOut oA = c->pw_flat(PwCgAp<T, PP>{g, opref(OP_CF_INV), Y, p, Ap}, B, Ctx<T>::PART_CG_PAP);                // A p = Y - Cf^-1 p
+          const DotOut oR = c->pw_flat(PwCgXr<T, PP>{g, opref(OP_PRECOND_INV), x, r, p, Ap, st, par, oA, sc}, B, Ctx<T>::PART_CG_RZ);   // alpha ; x, r
+          c->pw_flat(PwCgP<T, PP>{g, opref(OP_PRECOND_INV), x, r, p, bx, st, par, tol, oR, sc}, B);                          // beta, stop test ; p, best iterate
+        });
+        par ^= 1;
+        post_flags(it & 1);
+        if (it > 2) { const int* fl = wait_flags((it - 1) & 1); if (fl[it & 1] != 0) break; }   // previous iteration's flags: it left `done` at parity (it - 2) & 1
+      }
+    }
+    CMBL_HIP(hipMemcpyAsync(f_out, bx, sizeof(cx<T>) * n, hipMemcpyDeviceToDevice, sm));
+    int fl[6];
+    CMBL_HIP(hipMemcpyAsync(fl, st.done, sizeof(int) * 6, hipMemcpyDeviceToHost, sm));
+    CMBL_HIP(hipStreamSynchronize(sm));
+    const int nh = fl[5];
+    CMBL_HIP(hipMemcpy(hist, st.hist, sizeof(double) * (size_t)nh * B, hipMemcpyDeviceToHost));
+    CMBL_REQUIRE(fl[4] == 0, ERR_NAN, "NaN residual in conjugate gradient");
+    return nh;
+  }
   int wiener_cg(Flow<T>& L, const cx<T>* dd, const cx<T>* fstart, double tol, int maxit, cx<T>* f_out, double* hist, int B) {
+    if (fused()) return wiener_cg_fused(L, dd, fstart, tol, maxit, f_out, hist, B);
     const long n = fsize(B), nr = 2 * n / B;
     xs.ensure(sizeof(cx<T>) * n); rs.ensure(sizeof(cx<T>) * n); zs.ensure(sizeof(cx<T>) * n); ps.ensure(sizeof(cx<T>) * n);
     aps.ensure(sizeof(cx<T>) * n); best.ensure(sizeof(cx<T>) * n); bb.ensure(sizeof(cx<T>) * n);
@@ -1126,7 +1357,7 @@ struct Dataset {
     cg_scal.ensure(sizeof(double) * 6 * 64 + sizeof(int) * 8);
     cg_hist.ensure(sizeof(double) * (size_t)maxit * B);
     if (!cg_flag_host) {
-      CMBL_HIP(hipHostMalloc((void**)&cg_flag_host, sizeof(int) * 4, hipHostMallocDefault));
+      CMBL_HIP(hipHostMalloc((void**)&cg_flag_host, sizeof(int) * 16, hipHostMallocDefault));
       for (auto& e : cg_ev) CMBL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     CgState st;
@@ -1191,8 +1422,62 @@ struct Dataset {
 
   // logpdf(Mixed(ds); f°, phi°) and optionally its gradient.  fo: map (reference layout == internal), phio: F layout S0.
   // gfo (map) / gphio (F) may be nullptr for value only.
+  // Fused form (power-of-two maps).  Launches outside the four flows: phi prior (1), precompute (4), the y pass of f° (1), unmix + Cf^-1
+  // + its quadratic form + ifft_x (1), c2r (1), the data-space part (5 with a pixel mask, 1 without), D'^-1 between the delta flows (1),
+  // per delta flow the first d/dx pass and the delta-phi epilogue (1 + 3), the final irfft2 (2): 25 with a pixel mask.
+  void logpdf_mixed_fused(Flow<T>& L, const T* fo, const cx<T>* phio_F, double* lp, T* gfo, cx<T>* gphio_F, int B, bool quirk) {
+    const long sl = (long)P * B, n = fsize(B), np = c->npix(), pl = c->plane();
+    phiF.ensure(sizeof(cx<T>) * B * pl); fhat.ensure(sizeof(T) * sl * np); ftil.ensure(sizeof(T) * sl * np);
+    fh.ensure(sizeof(cx<T>) * n); t2.ensure(sizeof(cx<T>) * n); t3.ensure(sizeof(cx<T>) * n);
+    gphi.ensure(sizeof(cx<T>) * B * pl); dphi1.ensure(sizeof(cx<T>) * B * pl);
+    mp2.ensure(sizeof(T) * sl * np);
+    cx<T>*phi = phiF.template as<cx<T>>(), *f_h = fh.template as<cx<T>>(), *w = t3.template as<cx<T>>(), *cfif = t2.template as<cx<T>>();
+    cx<T>* cpip = gphi.template as<cx<T>>();
+    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    qdev.ensure(sizeof(double) * 3 * 64);
+    double* qd = qdev.template as<double>();
+    // phi = G \ phi° ; Cphi^-1 phi ; phi' Cphi^-1 phi
+    DotOut parts[3];
+    parts[1] = c->pw_flat(PwPhiPrior<T>{c->lam.template as<T>(), pl, op(OP_G_INV).d[0], op(OP_CPHI_INV).d[0], phio_F, phi, cpip}, B, Ctx<T>::PART_QP);
+    L.set_phi_F(phi, B);
+    // fhat = L \ f° (its y transform stays in A3) ; f = D \ fhat ; Cf^-1 f ; f' Cf^-1 f ; the y-transformed f goes straight into the forward flow
+    L.flow_map(fo, fhat.template as<T>(), P, B, true, false, true, &L.A3);
+    cx<T>* a = L.abuf_ensure(L.A, sl);
+    by_pol([&](auto pp) {
+      constexpr int PP = decltype(pp)::value;
+      parts[0] = c->template x_pw<PP, false>(L.A3.template as<cx<T>>(), a, PwUnmixPrior<T, PP>{c->geom(), opref(OP_D_INV), opref(OP_CF_INV), f_h, cfif}, B, true, Ctx<T>::PART_QF);
+    });
+    c->y_c2r(a, mp2.template as<T>(), sl);
+    L.flow_map(mp2.template as<T>(), ftil.template as<T>(), P, B, false, true, true, &L.A);       // f~ = L f in ftil, rfft_y(f~) in A
+    // z = M B L f - d ; z' Cn^-1 z ; w = -B'M'Cn^-1 z  (QU Fourier) with ifft_x(w) ready in L.H
+    parts[2] = data_space(L, L.A.template as<cx<T>>(), d_h.template as<cx<T>>(), Bd, T(-1), w, gfo == nullptr, B);
+    double* const outs[3] = {qd, qd + 64, qd + 128};
+    c->finish_parts(parts, outs, 3, B);
+    auto finish_lp = [&]() {
+      double q[3 * 64];
+      CMBL_HIP(hipMemcpyAsync(q, qd, sizeof(double) * 3 * 64, hipMemcpyDeviceToHost, c->stream));
+      CMBL_HIP(hipStreamSynchronize(c->stream));
+      for (int i = 0; i < B; ++i) lp[i] = -0.5 * (q[i] + q[64 + i] + q[128 + i] + logdet_sum);
+    };
+    if (!gfo) { finish_lp(); return; }
+    // pullback through f~ = L f : delta flow t 1->0 from (f~, w, 0)
+    L.flow_delta(ftil.template as<T>(), w, dphi1.template as<cx<T>>(), P, B, true, quirk, true, &L.A, true);
+    // g_f = df1 - Cf^-1 f (harmonic) ; d/dfhat = D' \ g_f -> QU Fourier, with its ifft_x in L.H
+    by_pol([&](auto pp) {
+      constexpr int PP = decltype(pp)::value;
+      PwChain<T, PP> ch{c->geom(), {}, 1, 1, cfif, T(-1), w, T(1)};
+      ch.ch.push(opref(OP_D_INV, true));
+      c->template x_pw<PP, true>(w, L.hbuf_ensure(sl), ch, B);
+    });
+    // pullback through fhat = L \ f° : delta flow t 0->1 from (fhat, w, 0); the epilogue forms d/dphi° = G' \ (dphi1 + dphi2 - Cphi^-1 phi)
+    const DphiTail<T> tail{dphi1.template as<cx<T>>(), cpip, op(OP_G_INV).d[0]};
+    L.flow_delta(fhat.template as<T>(), w, gphio_F, P, B, false, quirk, true, &L.A3, true, &tail);
+    c->F_to_map(w, gfo, sl);                                                // d/df° in f°'s basis (QU map)
+    finish_lp();
+  }
   void logpdf_mixed(Flow<T>& L, const T* fo, const cx<T>* phio_F, double* lp, T* gfo, cx<T>* gphio_F, int B, bool quirk) {
     CMBL_REQUIRE(Bd == B, ERR_SHAPE, "dataset data batch size differs from nbatch");
+    if (fused()) return logpdf_mixed_fused(L, fo, phio_F, lp, gfo, gphio_F, B, quirk);
     const long sl = (long)P * B, n = fsize(B), np = c->npix(), pl = c->plane();
     phiF.ensure(sizeof(cx<T>) * B * pl); fhat.ensure(sizeof(T) * sl * np); ftil.ensure(sizeof(T) * sl * np);
     fh.ensure(sizeof(cx<T>) * n); t1.ensure(sizeof(cx<T>) * n); t3.ensure(sizeof(cx<T>) * n);

@@ -99,6 +99,29 @@ template <int RT, int RPW> struct WorkRows {
   }
 };
 
+// WorkSeqs: like WorkRows with every row set on its own threads -- RT consecutive threads own sequence `threadIdx.x / RT` of NA * RPW
+// sequences (sequence a*RPW + row; rows >= nr absent).  Used by the row carriers that hold all pol slices of a batch slot.
+template <int RT, int RPW> struct WorkSeqs {
+  int nr;
+  static constexpr bool wave_private = RT <= 128;
+  template <int LGNB, typename F> __device__ __forceinline__ void each(F&& f) const {
+    static_assert(RT == 128, "WorkSeqs: two wavefronts per sequence");
+    const int seq = threadIdx.x / RT, t = threadIdx.x % RT;
+    if (seq % RPW >= nr) return;
+    constexpr int I = 1 << LGNB, HI = I >> 1;
+    const int w = t >> 6, lane = t & 63;
+    if constexpr (HI >= 64) {
+#pragma unroll
+      for (int i = 0; i < HI / 64; ++i) f(seq, w * HI + lane + 64 * i);
+    } else if constexpr (HI >= 1) {
+      if (lane < HI) f(seq, w * HI + lane);
+    } else {
+      if (t == 0) f(seq, 0);
+    }
+  }
+  __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+};
+
 // External twiddles of a stage, W^(j k) for k = 1..r-1.  CMBL_TW_REC = 1 (single precision only): ONE table read, W^j, and the powers by
 // multiplication (depth-3 product tree) instead of r-1 table reads -- the transforms are bound by LDS throughput at the CU and the
 // twiddle reads are a quarter of a radix-8 stage's LDS traffic; the products cost 2 packed instructions each on a VALU that has room.

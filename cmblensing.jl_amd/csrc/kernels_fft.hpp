@@ -441,11 +441,12 @@ template <typename T, int LGNX, int RPW, int NA> struct RowsMixedStage {
   static constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW);
   static constexpr int TOT = RPW * NH / VE, K = (TOT + NT - 1) / NT;
   CxVec<T> va[NA][K] = {}, vb[NA][K] = {}, w[K] = {};
-  __device__ __forceinline__ void issue(const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr) {
+  // tid: index of the thread among the NT that share this load (threadIdx.x unless several row sets are loaded side by side)
+  __device__ __forceinline__ void issue(const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr, int tid = threadIdx.x) {
     const int rot = CMBL_ROW_ROT(ky0);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+      const int u = tid + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
       if ((TOT % NT == 0 || u < TOT) && r < nr) {
         vload32(w[i], twg, (unsigned)(xt * MIXW + c));
         const unsigned o = (unsigned)((xt * NyhP + r) * MIXW + c), ob = (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c);
@@ -459,11 +460,11 @@ template <typename T, int LGNX, int RPW, int NA> struct RowsMixedStage {
     }
   }
   // row set a -> the LDS rows at s
-  __device__ __forceinline__ void commit(int a, cx<T>* __restrict__ s, int ky0, int nr) const {
+  __device__ __forceinline__ void commit(int a, cx<T>* __restrict__ s, int ky0, int nr, int tid = threadIdx.x) const {
     const int rot = CMBL_ROW_ROT(ky0);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int u = threadIdx.x + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+      const int u = tid + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
       if ((TOT % NT == 0 || u < TOT) && r < nr) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
@@ -477,20 +478,21 @@ template <typename T, int LGNX, int RPW, int NA> struct RowsMixedStage {
   }
 };
 template <typename T, int LGNX, int RPW, int NA>
-__device__ __forceinline__ void rows_load_mixed_dif(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr) {
+__device__ __forceinline__ void rows_load_mixed_dif(cx<T>* const (&s)[NA], const cx<T>* const (&g)[NA], const cx<T>* __restrict__ twg, int NyhP, int ky0, int nr, int tid = threadIdx.x) {
   RowsMixedStage<T, LGNX, RPW, NA> st;
-  st.issue(g, twg, NyhP, ky0, nr);
+  st.issue(g, twg, NyhP, ky0, nr, tid);
 #pragma unroll
-  for (int a = 0; a < NA; ++a) st.commit(a, s[a], ky0, nr);
+  for (int a = 0; a < NA; ++a) st.commit(a, s[a], ky0, nr, tid);
 }
 // LDS rows -> mixed layout through the last DIT level:  x[a] = u[a] + conj(W_N^a) v[a],  x[a + N/2] = u[a] - conj(W_N^a) v[a]  with
 // u, v the two halves of the row in LDS; values scaled by `scale`.  tw: the LDS twiddle table.
 template <typename T, int LGNX, int RPW>
-__device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, const cx<T>* __restrict__ tw, int NyhP, int ky0, int nr, T scale) {
+__device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, const cx<T>* __restrict__ tw, int NyhP, int ky0, int nr, T scale,
+                                                     int nyq = -1 /* >= 0: drop Im of the ky = 0 and ky = nyq rows (what c2r ignores) */, int tid = threadIdx.x) {
   using V = typename vreg<T>::type;
   constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW), TOT = RPW * NH / VE;
   const int rot = CMBL_ROW_ROT(ky0);
-  for (int u = threadIdx.x; u < TOT; u += NT) {
+  for (int u = tid; u < TOT; u += NT) {
     const int xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
     if (r < nr) {
       CxVec<T> oa, ob;
@@ -499,6 +501,7 @@ __device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s
         const cx<T>* p = s + r * LD + pad(xt * MIXW + c) + e;
         const V uu = vload(p), t = vmulc(vload(p + pad(NH)), vload(tw + xt * MIXW + c + e));
         oa.v[e] = vcx(vscale(vadd(uu, t), scale)); ob.v[e] = vcx(vscale(vsub(uu, t), scale));
+        if (nyq >= 0 && (ky0 + r == 0 || ky0 + r == nyq)) { oa.v[e].y = T(0); ob.v[e].y = T(0); }
       }
       cx<T>* gk = g + (size_t)ky0 * MIXW;                                  // uniform part of the address
       vec32(gk, (unsigned)((xt * NyhP + r) * MIXW + c)) = oa;
@@ -508,19 +511,19 @@ __device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s
 }
 // F layout: contiguous rows (g = first row of the group).  The F side of a transform is its bit-reversed end: no level is fused here.
 template <typename T, int LGNX, int RPW>
-__device__ __forceinline__ void rows_load_F(cx<T>* __restrict__ s, const cx<T>* __restrict__ g, int nr) {
+__device__ __forceinline__ void rows_load_F(cx<T>* __restrict__ s, const cx<T>* __restrict__ g, int nr, int tid = threadIdx.x) {
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), NT = row_nt(RPW), TOT = RPW * Nx / VE, K = (TOT + NT - 1) / NT;
   // every thread loads unconditionally (rows beyond nr re-read the group's last row, entries beyond TOT the first): an array written
   // under a predicate stays in scratch memory in the double-precision instantiations, with a full wait after each load
   CxVec<T> v[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int u0 = threadIdx.x + i * NT, u = (TOT % NT == 0 || u0 < TOT) ? u0 : 0, r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
+    const int u0 = tid + i * NT, u = (TOT % NT == 0 || u0 < TOT) ? u0 : 0, r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
     v[i] = vec32(g, (unsigned)(((r < nr ? r : nr - 1) << LGNX) + x));
   }
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int u = threadIdx.x + i * NT, r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
+    const int u = tid + i * NT, r = (u * VE) >> LGNX, x = (u * VE) & (Nx - 1);
     if ((TOT % NT == 0 || u < TOT) && r < nr) {
 #pragma unroll
       for (int e = 0; e < VE; ++e) s[r * LD + pad(x) + e] = v[i].v[e];

@@ -197,6 +197,7 @@ template <typename T> struct FlowYArgs {
   const cx<T>* twY; const T* ly;
   int Nx, P;
   RKCoef<T> rk;
+  int emit_last;            // the last stage also writes Anext = rfft_y(final state): the caller continues in Fourier space without a y pass
 };
 
 template <typename T, int R, int NT, int LGM>
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
     fn[i] = rk_update(a.rk, kv, y0[i], acc[i]);
     if (a.rk.stage == 4) at32(y0p, e) = y0[i]; else at32(accp, e) = acc[i];
   }
-  if (a.rk.last) return;
+  if (a.rk.last && !a.emit_last) return;
   __syncthreads();
   mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
   half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);

@@ -38,6 +38,8 @@ def test_bench_two_ranks_prints_one_line_consistent_with_one_rank():
     d2 = json.loads(lines[0])
     r1 = subprocess.run([sys.executable, "bench.py"] + common, cwd=ROOT, capture_output=True, text=True, timeout=600)
     d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
-    assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and set(d1) == set(d2) and len(d2["logpdf"]) == 2
+    # the N > 1 line additionally reports who took part in the collective (backend, world size, device of every rank)
+    assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and set(d1) == set(d2) - {"collective"} and len(d2["logpdf"]) == 2
+    assert d2["collective"]["world_size"] == 2 and [r["rank"] for r in d2["collective"]["ranks"]] == [0, 1]
     assert d2["scaling"] == "weak" and d2["metric"] == d1["metric"] and d2["config"]["nside"] == 256
     assert abs(d2["value"] - 2 * 5 / (d2["ms_per_step"] * 5e-3)) < 1e-6 * d2["value"]
