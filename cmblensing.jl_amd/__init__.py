@@ -7,7 +7,7 @@ There is NO CPU fallback: without the built library or without a GPU every compu
 """
 from .lib import load_library, library_path, CmblError, build            # noqa: F401
 from .engine import (ProjLambert, LenseFlow, BaseDataSet, Field, MAP, FOURIER, HARMONIC,   # noqa: F401
-                     FLOW_FWD, FLOW_INV, FLOW_ADJ, FLOW_INVADJ)
+                     FLOW_FWD, FLOW_INV, FLOW_ADJ, FLOW_INVADJ, reference_exact)
 from .sim import (Cls, load_sim, noise_cls, beam_cls, lowpass, cl_to_2d, HarmOp, border_mask)   # noqa: F401
 from .chains import partition_chains, chain_seed, gather_chain_values, allreduce_sum   # noqa: F401
 from .drivers import (quadratic_estimate, MAP_joint, MAP_joint_step, hmc_step, sample_f, gibbs_step, symplectic_integrate,   # noqa: F401

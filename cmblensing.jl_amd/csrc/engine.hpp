@@ -75,7 +75,9 @@ inline int env_int(const char* name, int dflt) { const char* v = std::getenv(nam
 struct CtxBase {
   int Ny = 0, Nx = 0, Nyh = 0, M = 0, lgM = 0, lgNx = 0, dtype = 0, device = 0, num_cus = 256;
   bool generic = false;                   // any-size path (kernels_generic.hpp): Ny or Nx not a power of two (or < 32)
-  int sum_mode = 1;                       // SUM_FLOAT64 (see kernels_pointwise.hpp; the reference's default is SUM_WORKING)
+  // SUM_FLOAT64 by default (see kernels_pointwise.hpp); CMBL_REFERENCE_EXACT=1 starts a context with the reference's own default,
+  // plain sums in the working precision (SUM_WORKING, src/util.jl:288-316)
+  int sum_mode = env_int("CMBL_REFERENCE_EXACT", 0) ? 0 : 1;
   double theta = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;

@@ -423,14 +423,6 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start="p
         theta_resume = {k[6:]: float(v) for k, v in last[fidx[0]].items() if k.startswith("theta_")}
     seeds = [chain_seed(base_seed, c) for c in chain_ids]
     rngs = [np.random.Generator(np.random.PCG64(s if first_step == 0 else [s, first_step])) for s in seeds]
-    if isinstance(phi_start, str):
-        assert phi_start == "prior", phi_start                      # gibbs_initialize_ϕ! (:363-384): simulate(ds.Cϕ)
-        w0 = proj.randn(seeds, R.stream_id(R.STREAM_INIT, 0), 1) if rng == "device" else np.stack([r.standard_normal((1, proj.Nx, proj.Ny)) for r in rngs])
-        phi = Field(proj, proj.diag_apply(np.sqrt(np.asarray(ds.host["Cphi"], float))[None], proj.rfft(proj.tensor(w0)), FOURIER, FOURIER), FOURIER)
-    elif phi_start is None or (np.isscalar(phi_start) and phi_start == 0):
-        phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER)
-    else:
-        phi = phi_start
     hist = dict(logpdf=[], dH=[], accept=[], ncg=[])
     chunk = [[] for _ in range(B)]
 
@@ -479,6 +471,16 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start="p
         else:
             theta.update(theta_start or {})
         TH.set_theta(ds, **theta)
+    # ϕ is initialised AFTER θ like the reference's initializer list (:186-190): the prior draw uses Cϕ(θ) and the host generator
+    # hands out its θ draw first
+    if isinstance(phi_start, str):
+        assert phi_start == "prior", phi_start                      # gibbs_initialize_ϕ! (:363-384): simulate(ds.Cϕ(θ)), after θ (:340-354)
+        w0 = proj.randn(seeds, R.stream_id(R.STREAM_INIT, 0), 1) if rng == "device" else np.stack([r.standard_normal((1, proj.Nx, proj.Ny)) for r in rngs])
+        phi = Field(proj, proj.diag_apply(np.sqrt(np.asarray(ds.host["Cphi"], float))[None], proj.rfft(proj.tensor(w0)), FOURIER, FOURIER), FOURIER)
+    elif phi_start is None or (np.isscalar(phi_start) and phi_start == 0):
+        phi = Field(proj, torch.zeros_like(proj.empty(FOURIER, 1, B)), FOURIER)
+    else:
+        phi = phi_start
     f = None
     for step in range(first_step, nsamps_per_chain) if (filename is not None and resume) else range(first_step, first_step + nsamps_per_chain):
         if rng == "device":

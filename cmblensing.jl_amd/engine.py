@@ -24,6 +24,15 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def reference_exact():
+    """CMBL_REFERENCE_EXACT=1: the two defaults in which the engine deviates from the reference as written become the reference's --
+    the δϕ velocity with the in-place aliasing of src/lenseflow.jl:198-200 (`alias_quirk=True`) and plain sums in the
+    working precision (`sum_accuracy_mode = nothing`, src/util.jl:288-316; read by the library when a context is created).  This
+    is the mode to run when results are compared with output of the Julia package itself (tests/golden/ref_*.npy)."""
+    import os
+    return os.environ.get("CMBL_REFERENCE_EXACT", "0") not in ("", "0")
+
+
 class ProjLambert:
     """Context: geometry + FFT tables + stream.  `T` is torch.float32 or torch.float64."""
 
@@ -354,12 +363,13 @@ class LenseFlow:
         check(self.lib.cmbl_max_lensing_step(self._h, phi.basis, _ptr(phi.arr), _ptr(eta.arr), B, out))
         return np.array(out[:])
 
-    def gradient(self, mode, f_end, delta, alias_quirk=False, basis_df=None):
-        """Pullback of `L*f` (mode=FLOW_FWD) or `L\\f` (FLOW_INV) (src/flowops.jl:40-68).
+    def gradient(self, mode, f_end, delta, alias_quirk=None, basis_df=None):
+        """Pullback of `L*f` (mode=FLOW_FWD) or `L\\f` (FLOW_INV) (src/flowops.jl:40-68).  alias_quirk=None: `reference_exact()`.
         f_end: primal OUTPUT (map Field); delta: cotangent.  Returns (δϕ [FOURIER], δf, f_start)."""
         P, B = self.proj._check(f_end.arr, MAP)
         self.proj._check(delta.arr, delta.basis)
         basis_df = delta.basis if basis_df is None else basis_df
+        alias_quirk = reference_exact() if alias_quirk is None else alias_quirk
         dphi = self.proj.empty(FOURIER, 1, B)
         df = self.proj.empty(basis_df, P, B)
         fstart = self.proj.empty(MAP, P, B)
@@ -399,8 +409,9 @@ class BaseDataSet:
         self.logdet_mix = 0.0          # logdet(D,θ) + logdet(G,θ) of the mixed parametrisation (src/dataset.jl:86); 0 at fiducial θ
         # ϕ-gradients: False = the mathematically consistent δϕ velocity (default), True = the reference exactly as written, with
         # the in-place aliasing of src/lenseflow.jl:198-200 (differs by ~3e-4).  Every driver (MAP_joint, MAP_marg,
-        # hmc_step, sample_joint) takes `alias_quirk=None` = this dataset-level setting.
-        self.alias_quirk = False
+        # hmc_step, sample_joint) takes `alias_quirk=None` = this dataset-level setting.  CMBL_REFERENCE_EXACT=1 flips the default
+        # (and starts every context with plain working-precision sums, the reference's `sum_accuracy_mode`).
+        self.alias_quirk = reference_exact()
         check(self.lib.cmbl_dataset_set_logdet(self._h, self.logdet_sum))
 
     def __del__(self):

@@ -105,8 +105,8 @@ def load_library():
         "cmbl_tr_diag": [vp, ci, vp, ci, ci, pd],
         "cmbl_set_sum_accuracy_mode": [vp, ci],
         "cmbl_timer_report": [vp, ctypes.c_char_p, ctypes.c_size_t],
-        "cmbl_device_malloc": [ctypes.c_size_t, ctypes.POINTER(vp)],
-        "cmbl_device_free": [vp],
+        "cmbl_device_malloc": [vp, ctypes.c_size_t, ctypes.POINTER(vp)],
+        "cmbl_device_free": [vp, vp],
         "cmbl_copy_to_device": [vp, vp, vp, ctypes.c_size_t],
         "cmbl_copy_to_host": [vp, vp, vp, ctypes.c_size_t],
     }

@@ -74,7 +74,7 @@ class CMBLensingMuseProblem:
         keep = ds.d
         ds.set_data(d)
         try:
-            f, phi, hist = MAP_joint(ds, phi_start=(zguess or {}).get("phi"), **self.MAP_joint_kwargs)
+            f, phi, hist = MAP_joint(ds, phi_start=(zguess or {}).get("phi"), fstart=(zguess or {}).get("f"), **self.MAP_joint_kwargs)
         finally:
             ds.set_data(keep)
         return dict(f=f, phi=phi), hist

@@ -73,7 +73,7 @@ def _ops(ds, r, Aphi, bands=None):
         logdet_mix += (D0.pinv() @ D).logdet(proj)
     Nphi = np.asarray(h["Nphi"], float)
     G = np.ones_like(Cphi0) if "G_user" not in h else np.asarray(h["G_user"], float)
-    if Aphi is not None:
+    if Aphi is not None and "G_user" not in h:      # a user-supplied G stays constant: `if G == nothing` (src/dataset.jl:317-320), logdet(G,θ) = 0
         g0 = np.sqrt(1 + 2 * Nphi * _pinv(Cphi0))
         G = _pinv(g0) * np.sqrt(1 + 2 * Nphi * _pinv(Cphi))
         logdet_mix += HarmOp([G]).logdet(proj)

@@ -80,9 +80,10 @@ int cmbl_timer_report(cmbl_ctx* ctx, char* buf, size_t buflen);
 
 /* ---- device memory helpers for callers that do not link HIP themselves (a Julia process without AMDGPU.jl, the plain-C
  *      test): every field pointer of this API is a device pointer; these give a host program the means to own some.
+ *      Buffers live on the context's device (the call selects it: the caller cannot, it does not link HIP).
  *      Copies are ordered on the context's stream and complete on return. */
-int cmbl_device_malloc(size_t bytes, void** out);
-int cmbl_device_free(void* p);
+int cmbl_device_malloc(cmbl_ctx* ctx, size_t bytes, void** out);
+int cmbl_device_free(cmbl_ctx* ctx, void* p);
 int cmbl_copy_to_device(cmbl_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
 int cmbl_copy_to_host(cmbl_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
 

@@ -15,8 +15,8 @@
 typedef const char* (*cmbl_last_error_t)(void);
 typedef int (*cmbl_ctx_create_t)(int, int, double, int, int, void*, cmbl_ctx**);
 typedef int (*cmbl_ctx_destroy_t)(cmbl_ctx*);
-typedef int (*cmbl_device_malloc_t)(size_t, void**);
-typedef int (*cmbl_device_free_t)(void*);
+typedef int (*cmbl_device_malloc_t)(cmbl_ctx*, size_t, void**);
+typedef int (*cmbl_device_free_t)(cmbl_ctx*, void*);
 typedef int (*cmbl_copy_to_device_t)(cmbl_ctx*, void*, const void*, size_t);
 typedef int (*cmbl_copy_to_host_t)(cmbl_ctx*, void*, const void*, size_t);
 typedef int (*cmbl_lenseflow_create_t)(cmbl_ctx*, int, cmbl_flow**);
@@ -58,9 +58,9 @@ int main(int argc, char** argv) {
   cmbl_ctx* ctx = NULL; cmbl_flow* L = NULL;
   CHK(p_cmbl_ctx_create(Ny, Nx, theta, CMBL_F64, 0, NULL, &ctx));
   void *d_phi, *d_f, *d_delta, *d_Lf, *d_dphi, *d_df, *d_f0;
-  CHK(p_cmbl_device_malloc(sz[0] * 8, &d_phi)); CHK(p_cmbl_device_malloc(sz[1] * 8, &d_f)); CHK(p_cmbl_device_malloc(sz[2] * 8, &d_delta));
-  CHK(p_cmbl_device_malloc(sz[3] * 8, &d_Lf)); CHK(p_cmbl_device_malloc(sz[4] * 8, &d_dphi)); CHK(p_cmbl_device_malloc(sz[5] * 8, &d_df));
-  CHK(p_cmbl_device_malloc(sz[1] * 8, &d_f0));
+  CHK(p_cmbl_device_malloc(ctx, sz[0] * 8, &d_phi)); CHK(p_cmbl_device_malloc(ctx, sz[1] * 8, &d_f)); CHK(p_cmbl_device_malloc(ctx, sz[2] * 8, &d_delta));
+  CHK(p_cmbl_device_malloc(ctx, sz[3] * 8, &d_Lf)); CHK(p_cmbl_device_malloc(ctx, sz[4] * 8, &d_dphi)); CHK(p_cmbl_device_malloc(ctx, sz[5] * 8, &d_df));
+  CHK(p_cmbl_device_malloc(ctx, sz[1] * 8, &d_f0));
   CHK(p_cmbl_copy_to_device(ctx, d_phi, h[0], sz[0] * 8)); CHK(p_cmbl_copy_to_device(ctx, d_f, h[1], sz[1] * 8));
   CHK(p_cmbl_copy_to_device(ctx, d_delta, h[2], sz[2] * 8));
 
@@ -89,8 +89,8 @@ int main(int argc, char** argv) {
   { double ref = 0; for (size_t i = 0; i < sz[1]; ++i) ref += h[1][i] * h[1][i]; if (fabs(dot - ref) > 1e-10 * ref) { fprintf(stderr, "dot mismatch\n"); bad = 1; } }
 
   CHK(p_cmbl_lenseflow_destroy(L));
-  p_cmbl_device_free(d_phi); p_cmbl_device_free(d_f); p_cmbl_device_free(d_delta); p_cmbl_device_free(d_Lf);
-  p_cmbl_device_free(d_dphi); p_cmbl_device_free(d_df); p_cmbl_device_free(d_f0);
+  p_cmbl_device_free(ctx, d_phi); p_cmbl_device_free(ctx, d_f); p_cmbl_device_free(ctx, d_delta); p_cmbl_device_free(ctx, d_Lf);
+  p_cmbl_device_free(ctx, d_dphi); p_cmbl_device_free(ctx, d_df); p_cmbl_device_free(ctx, d_f0);
   CHK(p_cmbl_ctx_destroy(ctx));
   puts(bad ? "C_ABI_FAIL" : "C_ABI_PASS");
   return bad;

@@ -43,3 +43,31 @@ def test_bench_two_ranks_prints_one_line_consistent_with_one_rank():
     assert d2["collective"]["world_size"] == 2 and [r["rank"] for r in d2["collective"]["ranks"]] == [0, 1]
     assert d2["scaling"] == "weak" and d2["metric"] == d1["metric"] and d2["config"]["nside"] == 256
     assert abs(d2["value"] - 2 * 5 / (d2["ms_per_step"] * 5e-3)) < 1e-6 * d2["value"]
+
+
+def test_nccl_backend_world_size_one():
+    """The RCCL branch itself (`nccl` backend, device-resident payloads) with the only world size a one-GPU box offers:
+    bench.py's init / barrier / all_reduce(MAX) / all_gather / all_gather_object path and chains.allreduce_sum /
+    gather_chain_values on device tensors all execute; the JSON line reports the collective as RCCL sees it."""
+    common = ["--steps", "3", "--warmup", "1", "--nside", "256", "--no-cpu-baseline", "--no-roofline", "--no-extras"]
+    r = _run(1, ["bench.py", "--gpus", "1", "--dist-backend", "nccl"] + common, 29544, env=dict(CMBL_BENCH_FORCE_DIST="1"))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["collective"]["backend"] == "nccl" and d["collective"]["world_size"] == 1
+    assert d["collective"]["ranks"][0]["rank"] == 0 and d["collective"]["ranks"][0]["device"] == 0
+    code = ("import os, torch, torch.distributed as dist, numpy as np, cmblensing_jl_amd as C\n"
+            "torch.cuda.set_device(0)\n"
+            "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+            "t = torch.arange(6, dtype=torch.float64, device='cuda').reshape(3, 2)\n"
+            "c = torch.view_as_complex(t.clone())\n"
+            "buf = torch.view_as_real(c).contiguous(); dist.all_reduce(buf)\n"          # what allreduce_sum does on the nccl branch for world > 1
+            "assert torch.equal(buf, t)\n"
+            "assert C.allreduce_sum(c, dist) is c\n"
+            "g = C.gather_chain_values([0, 1], np.array([[1., 2.], [3., 4.]]), 2, dist, 'cuda')\n"
+            "assert g.tolist() == [[1., 2.], [3., 4.]]\n"
+            "v = [torch.empty_like(t)]; dist.all_gather(v, t); assert torch.equal(v[0], t)\n"
+            "dist.destroy_process_group(); print('NCCL_WS1_OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29545"))
+    assert r.returncode == 0 and "NCCL_WS1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

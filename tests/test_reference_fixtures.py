@@ -1,0 +1,225 @@
+"""Parity against output of the REFERENCE ITSELF (marius311/CMBLensing.jl run by julia/make_reference_fixtures.jl on the committed
+inputs tests/golden/ref_inputs/*.npy).  The build image has no Julia, so tests/golden/ref_outputs/ may be absent: the comparisons
+then SKIP with "parity unpinned" (the oracle is in that case pinned only by the reference's property tests) -- they
+never pass vacuously.  What always runs: the committed inputs are what the seeds generate today, the NumPy-file recipe the Julia
+script uses is readable by NumPy, and (GPU) the engine's reference-exact mode (CMBL_REFERENCE_EXACT=1: δϕ velocity as written
+upstream, plain working-precision sums) agrees with the oracle run the same way.
+
+Reference-exact comparisons use alias_quirk=True: the reference's in-place aliasing of src/lenseflow.jl:198-200 is what the Julia
+package computes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+from oracle.lenseflow import LenseFlow as OLF
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_reference_inputs as MRI                       # noqa: E402
+
+INP = os.path.join(ROOT, "tests", "golden", "ref_inputs")
+REF = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+UNPINNED = ("parity unpinned: tests/golden/ref_outputs/ holds no output of the Julia reference "
+            "(run julia/make_reference_fixtures.jl on a machine with CMBLensing.jl and commit the files)")
+
+
+def inp(name):
+    return np.load(os.path.join(INP, name + ".npy"))
+
+
+def ref(name):
+    p = os.path.join(REF, name + ".npy")
+    if not os.path.isfile(p):
+        pytest.skip(UNPINNED)
+    return np.load(p)
+
+
+def rel(a, b):
+    return float(np.linalg.norm((np.asarray(a) - np.asarray(b)).ravel()) / np.linalg.norm(np.asarray(b).ravel()))
+
+
+# ---- always run --------------------------------------------------------------------------------------------------------------
+def test_committed_inputs_are_what_the_seeds_generate():
+    now = MRI.all_inputs()
+    assert sorted(now) == sorted(f[:-4] for f in os.listdir(INP) if f.endswith(".npy"))
+    for k, v in now.items():
+        c = inp(k)
+        assert c.shape == v.shape and c.dtype == v.dtype, k
+        assert rel(c, v) < 1e-13, k
+
+
+def test_npy_recipe_of_the_julia_script_is_numpy_readable(tmp_path):
+    """julia/make_reference_fixtures.jl writes .npy by hand (magic, version 1.0, uint16 header length, dict padded with blanks so that
+    the data start on a 64-byte boundary, C order with reversed axes).  Same recipe in Python -> np.load reads it back."""
+    for a in (np.arange(24, dtype=np.float64).reshape(1, 2, 3, 4), (np.arange(6) * (1 + 2j)).astype(np.complex128), np.array([3.5])):
+        shape = ", ".join(str(n) for n in a.shape) + ("," if a.ndim == 1 else "")
+        descr = {np.dtype(np.float64): "<f8", np.dtype(np.complex128): "<c16"}[a.dtype]
+        hdr = "{'descr': '%s', 'fortran_order': False, 'shape': (%s), }" % (descr, shape)
+        hdr += " " * (63 - (10 + len(hdr)) % 64) + "\n"
+        assert (10 + len(hdr)) % 64 == 0
+        p = tmp_path / "x.npy"
+        p.write_bytes(b"\x93NUMPY\x01\x00" + np.uint16(len(hdr)).tobytes() + hdr.encode() + a.tobytes())
+        np.testing.assert_array_equal(np.load(p), a)
+
+
+def test_skip_message_when_reference_outputs_are_absent():
+    """the switch itself: with no ref_outputs the comparisons below skip (they do not pass), with them they run"""
+    if os.path.isdir(REF) and any(f.endswith(".npy") for f in os.listdir(REF)):
+        assert os.path.isfile(os.path.join(REF, "flow_Lf.npy")), "ref_outputs/ is present but incomplete"
+    else:
+        with pytest.raises(pytest.skip.Exception, match="parity unpinned"):
+            ref("flow_Lf")
+
+
+# ---- oracle against the reference (CPU) --------------------------------------------------------------------------------------
+def _oracle_flow():
+    c = MRI.FLOW
+    proj = O.Proj(c["Ny"], c["Nx"], c["theta"], np.float64)
+    return proj, OLF(proj, inp("flow_phi"), c["nsteps"]), inp("flow_f"), O.rfft2(inp("flow_g"))
+
+
+def test_oracle_flows_against_the_reference():
+    ref("flow_Lf")
+    proj, L, f, gl = _oracle_flow()
+    Lf = L.apply(f)
+    assert rel(Lf, ref("flow_Lf")) < 1e-10
+    assert rel(L.inv(f), ref("flow_Linvf")) < 1e-10
+    assert rel(L.adj(gl), ref("flow_Ladjg")) < 1e-10
+    assert rel(L.invadj(gl), ref("flow_Linvadjg")) < 1e-10
+    _, df, dp = L.grad_apply(Lf, gl, alias_quirk=True)
+    assert rel(df, ref("flow_grad_df")) < 1e-10
+    assert rel(dp, ref("flow_grad_dphi")) < 1e-9
+    # ∇ϕ ‖L(ϕ)f‖ = pullback at cotangent f̃/‖f̃‖
+    _, _, dpn = L.grad_apply(Lf, O.rfft2(Lf / np.sqrt(np.sum(Lf ** 2))), alias_quirk=True)
+    assert rel(dpn, ref("flow_gradnorm_dphi")) < 1e-9
+
+
+def _oracle_posterior(pol):
+    c = MRI.POST[pol]
+    s = O.load_sim(c["theta"], c["Nside"], pol, np.float64, beam_fwhm=c["beam_fwhm"], pixel_mask=c["pixel_mask"])
+    ds = s["ds"]
+    ds.d = inp(f"post_{pol}_d")
+    return s, ds, inp(f"post_{pol}_f"), inp(f"post_{pol}_phi")
+
+
+@pytest.mark.parametrize("pol", ["P", "IP"])
+def test_oracle_posterior_against_the_reference(pol):
+    t = f"post_{pol}_"
+    ref(t + "logpdf")
+    s, ds, f, phi = _oracle_posterior(pol)
+    np.testing.assert_allclose(ds.logpdf(f, phi), ref(t + "logpdf"), rtol=1e-10)
+    fo, po = ds.mix(f, phi)
+    assert rel(fo, ref(t + "fo")) < 1e-10 and rel(po, ref(t + "phio")) < 1e-10
+    np.testing.assert_allclose(ds.logpdf_mixed(fo, po), ref(t + "logpdf_mixed"), rtol=1e-10)
+    lp, gf, gp = ds.grad_logpdf_mixed(fo, po, alias_quirk=True)
+    assert rel(gf, ref(t + "grad_fo")) < 1e-9 and rel(gp, ref(t + "grad_phio")) < 1e-8
+    L = ds.L(phi)
+    assert rel(ds.gradientf_logpdf(f, L, ds.d), ref(t + "gradientf")) < 1e-10
+    fw, hist = ds.argmaxf_logpdf(phi, tol=0.0, nsteps=8)
+    np.testing.assert_allclose([h[1][0] for h in hist], ref(t + "cg_res"), rtol=1e-8)
+    assert rel(fw, ref(t + "cg_f")) < 1e-8
+
+
+@pytest.mark.parametrize("pol", ["P"])
+def test_oracle_quadratic_estimate_against_the_reference(pol):
+    t = f"post_{pol}_"
+    ref(t + "qe_Nphi")
+    s, ds, f, phi = _oracle_posterior(pol)
+    key = ["E", "B"]
+    pl = lambda op: {k: op.d[i] for i, k in enumerate(key)}
+    TF = {k: pl(ds.Mf)[k] * pl(ds.B)[k] for k in key}
+    dd = {k: ds.d[:, i:i + 1] for i, k in enumerate(key)}
+    pq, AL, Nphi = O.quadratic_estimate(s["proj"], "EB", dd, dd, pl(ds.Cf), pl(ds.Cftilde), pl(ds.Cn), ds.Cphi, TF)
+    assert rel(Nphi, ref(t + "qe_Nphi")[0, 0]) < 1e-8
+    assert rel(pq, ref(t + "qe_phi")) < 1e-8
+    assert rel(Nphi / 2, ref(t + "Nphi")[0, 0]) < 1e-8                    # what load_sim stores (src/dataset.jl:312)
+
+
+# ---- the HIP engine, reference-exact mode ------------------------------------------------------------------------------------
+@pytest.fixture
+def reference_exact(monkeypatch):
+    monkeypatch.setenv("CMBL_REFERENCE_EXACT", "1")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_gpu_reference_exact_mode_equals_the_oracle_run_the_same_way(prec, reference_exact):
+    """CMBL_REFERENCE_EXACT=1 makes alias_quirk=True and plain working-precision sums the defaults; the oracle with alias_quirk=True
+    is the same computation.  (fp32: the plain float32 sum of ~10⁴ terms of logpdf is what the reference does by default.)"""
+    import torch
+    import cmblensing_jl_amd as C
+    from bench import synthetic_cls
+    assert C.reference_exact()
+    c = MRI.POST["P"]
+    T = torch.float32 if prec == "f32" else torch.float64
+    s = C.load_sim(c["theta"], c["Nside"], "P", synthetic_cls(), T=T, beam_fwhm=c["beam_fwhm"], pixel_mask=c["pixel_mask"])
+    ds = s["ds"]
+    assert ds.alias_quirk is True
+    so, ods, f, phi = _oracle_posterior("P")
+    p = ds.proj
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    ds.set_data(F(ods.d, C.HARMONIC))
+    fo, po = ods.mix(f, phi)
+    lp_o, gf_o, gp_o = ods.grad_logpdf_mixed(fo, po, alias_quirk=True)
+    lp_q0, _, gp_q0 = ods.grad_logpdf_mixed(fo, po, alias_quirk=False)
+    lp, gf, gp = ds.gradient_logpdf_mixed(F(fo, C.MAP), F(po, C.FOURIER))          # defaults only
+    tol = dict(f32=(2e-4, 2e-3, 5e-3), f64=(1e-10, 1e-8, 1e-8))[prec]
+    np.testing.assert_allclose(lp, lp_o, rtol=tol[0])
+    assert rel(gf.arr.cpu().numpy(), gf_o) < tol[1]
+    e1, e0 = rel(gp.arr.cpu().numpy(), gp_o), rel(gp.arr.cpu().numpy(), gp_q0)
+    assert e1 < tol[2] and (prec == "f32" or e0 > 100 * e1), (e1, e0)              # it IS the aliased form, not the consistent one
+    # flows: the pullback default follows the switch too
+    proj, L, ff, gl = _oracle_flow()
+    pp = C.ProjLambert(MRI.FLOW["Ny"], MRI.FLOW["Nx"], MRI.FLOW["theta"], T)
+    G = lambda a, b: C.Field(pp, pp.tensor(a), b)
+    Lg = C.LenseFlow(pp, 7)(G(inp("flow_phi"), C.MAP))
+    Lf = Lg * G(ff, C.MAP)
+    dp, df, _ = Lg.gradient(C.FLOW_FWD, Lf, G(gl, C.FOURIER))
+    _, df_o, dp_o = L.grad_apply(L.apply(ff), gl, alias_quirk=True)
+    assert rel(dp.arr.cpu().numpy(), dp_o) < (5e-4 if prec == "f32" else 1e-9)
+    assert rel(df.arr.cpu().numpy(), df_o) < (1e-4 if prec == "f32" else 1e-10)
+
+
+@pytest.mark.gpu
+def test_gpu_flows_against_the_reference(reference_exact):
+    ref("flow_Lf")
+    import torch
+    import cmblensing_jl_amd as C
+    c = MRI.FLOW
+    p = C.ProjLambert(c["Ny"], c["Nx"], c["theta"], torch.float64)
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    L = C.LenseFlow(p, c["nsteps"])(F(inp("flow_phi"), C.MAP))
+    f, gl = F(inp("flow_f"), C.MAP), F(O.rfft2(inp("flow_g")), C.FOURIER)
+    Lf = L * f
+    g = lambda x: x.arr.cpu().numpy()
+    assert rel(g(Lf), ref("flow_Lf")) < 1e-10 and rel(g(L.ldiv(f)), ref("flow_Linvf")) < 1e-10
+    assert rel(g(L.adjoint * gl), ref("flow_Ladjg")) < 1e-10 and rel(g(L.adjoint.ldiv(gl)), ref("flow_Linvadjg")) < 1e-10
+    dp, df, _ = L.gradient(C.FLOW_FWD, Lf, gl)
+    assert rel(g(df), ref("flow_grad_df")) < 1e-10 and rel(g(dp), ref("flow_grad_dphi")) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pol", ["P", "IP"])
+def test_gpu_posterior_against_the_reference(pol, reference_exact):
+    t = f"post_{pol}_"
+    ref(t + "logpdf_mixed")
+    import torch
+    import cmblensing_jl_amd as C
+    from bench import synthetic_cls
+    c = MRI.POST[pol]
+    s = C.load_sim(c["theta"], c["Nside"], pol, synthetic_cls(), T=torch.float64, beam_fwhm=c["beam_fwhm"], pixel_mask=c["pixel_mask"])
+    ds, p = s["ds"], s["ds"].proj
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    ds.set_data(F(inp(t + "d"), C.HARMONIC))
+    g = lambda x: x.arr.cpu().numpy()
+    fo, po = ds.mix(F(inp(t + "f"), C.HARMONIC), F(inp(t + "phi"), C.FOURIER))
+    assert rel(g(fo), ref(t + "fo")) < 1e-10
+    lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
+    np.testing.assert_allclose(lp, ref(t + "logpdf_mixed"), rtol=1e-10)
+    assert rel(g(gf), ref(t + "grad_fo")) < 1e-9 and rel(g(gp), ref(t + "grad_phio")) < 1e-8
+    fw, hist = ds.argmaxf_logpdf(F(inp(t + "phi"), C.FOURIER), tol=0.0, nsteps=8)
+    np.testing.assert_allclose([h[1][0] for h in hist], ref(t + "cg_res"), rtol=1e-7)
+    assert rel(g(fw), ref(t + "cg_f")) < 1e-8
