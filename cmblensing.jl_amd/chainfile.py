@@ -3,9 +3,15 @@
 Mirrors the reference's on-disk structure (src/sampling.jl:230-256,311-320; src/chains.jl:48-100): one file holding `rundat`
 (the run's settings) and numbered chunks `chunks_1, chunks_2, ...`; a chunk is, per chain, the list of samples since the
 previous write; a sample is a dict of scalars (every step) plus maps (first step, every `nsavemaps`-th step, and -- so that a
-resumed run continues exactly -- the last step of every chunk).  The reference stores this in JLD2 (an HDF5 dialect that needs
-Julia to read back); here the container is a plain zip archive whose members are `.npy` arrays,
-`chunks_<k>/chain<c>/<i>/<key>.npy`, appended in place chunk by chunk.
+resumed run continues exactly -- the last step of every chunk).  The reference stores this in JLD2 (an HDF5 dialect); the container written here is a plain zip archive whose members are `.npy`
+arrays, `chunks_<k>/chain<c>/<i>/<key>.npy`, appended in place chunk by chunk.
+
+Compatibility with the reference's files: `load_chains`, `read_rundat`, `chunk_indices`, `read_chunk` and `last_state` also open a
+`.jld2` chain written by the Julia package (decoded by jld2.py: `rundat` + `chunks_k` = Vector{Vector{Any}} of Dict{Symbol,Any}
+states), so chains sampled with CMBLensing.jl can be analysed -- and resumed from -- here.  Field values (structs with `arr` and
+`metadata`) come back as their arrays in this package's axis order, NamedTuple θ as `theta_<name>` scalars, and the reference's
+keys are renamed to the ones used here (ϕ -> phi, ΔH -> dH, ...; unknown keys keep their Julia names).  This package does NOT write
+JLD2: a chain written here cannot be opened by the Julia `load_chains` (stated in DESIGN.md §1).
 """
 import io
 import json
@@ -15,6 +21,51 @@ import zipfile
 import numpy as np
 
 EXT = ".zip"
+JLD2_EXT = ".jld2"
+# reference state keys (src/sampling.jl:388-464) -> the names this package's chain files use
+JLD2_KEYS = {"ϕ": "phi", "ϕ°": "phi_mixed", "f°": "f_mixed", "f̃": "ftilde", "ΔH": "dH", "lnP": "logpdf", "i": "step"}
+
+
+def _is_jld2(filename):
+    return os.path.splitext(filename)[1] == JLD2_EXT
+
+
+_jld2_open = {}
+
+
+def _jld2(filename):
+    """one decoded file per (path, mtime, size): a chain file is read several times by load_chains / last_state"""
+    from .jld2 import JLD2File
+    st = os.stat(filename)
+    key = (os.path.abspath(filename), st.st_mtime_ns, st.st_size)
+    if key not in _jld2_open:
+        _jld2_open.clear()
+        _jld2_open[key] = JLD2File(filename)
+    return _jld2_open[key]
+
+
+def _jld2_value(v):
+    """a decoded Julia value as a chain-sample entry: Field struct -> its array, scalars -> Python numbers"""
+    if isinstance(v, dict):
+        body = {k: x for k, x in v.items() if k != "__julia_type__"}
+        if "arr" in body and "metadata" in body:                          # BaseField{B,M,T,A} (src/base_fields.jl:14-21)
+            return np.asarray(body["arr"])
+        return {k: _jld2_value(x) for k, x in body.items()}
+    if isinstance(v, list):
+        return [_jld2_value(x) for x in v]
+    return v
+
+
+def _jld2_sample(state):
+    """Dict{Symbol,Any} state of the reference -> sample dict with this package's key names; a NamedTuple θ is flattened"""
+    out = {}
+    for k, v in state.items():
+        v = _jld2_value(v)
+        if k == "θ" and isinstance(v, dict):
+            out.update({"theta_" + kk: vv for kk, vv in v.items()})
+        else:
+            out[JLD2_KEYS.get(k, k)] = v
+    return out
 
 
 def _put(z, name, arr):
@@ -49,17 +100,29 @@ def write_chunk(filename, index, chains, rundat=None, clobber=False):
 
 
 def chunk_indices(filename):
+    if _is_jld2(filename):
+        return sorted(int(k[7:]) for k in _jld2(filename).keys() if k.startswith("chunks_"))      # src/chains.jl:63-64
     with zipfile.ZipFile(filename, "r") as z:
         return sorted({int(n.split("/")[0][7:]) for n in z.namelist() if n.startswith("chunks_")})
 
 
 def read_rundat(filename):
+    if _is_jld2(filename):
+        from .jld2 import to_python
+        return {k: _jld2_value(v) for k, v in to_python(_jld2(filename)["rundat"]).items()}
     with zipfile.ZipFile(filename, "r") as z:
         return json.loads(z.read("rundat.json"))
 
 
 def read_chunk(filename, index, dropmaps=False):
     """-> list over chains of lists of sample dicts"""
+    if _is_jld2(filename):
+        from .jld2 import to_python
+        chains = to_python(_jld2(filename)[f"chunks_{index}"])            # Vector (chains) of Vector{Any} (samples) of Dict{Symbol,Any}
+        samples = [[_jld2_sample(s) for s in ch] for ch in chains]
+        if dropmaps:
+            samples = [[{k: v for k, v in s.items() if np.ndim(v) == 0 and not isinstance(v, (dict, list))} for s in ch] for ch in samples]
+        return samples
     out = {}
     with zipfile.ZipFile(filename, "r") as z:
         pre = f"chunks_{index}/"
