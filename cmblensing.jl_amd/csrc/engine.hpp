@@ -289,6 +289,28 @@ struct Ctx : CtxBase {
     a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
     gen_dft(genY, a, slices);
   }
+  // Separable pieces of the any-size path (mixed layout [slice][ky][x], like the fused kernels use between their column and row passes):
+  // the y transform alone (one real map, or TWO real maps per complex transform), the x transform alone with an optional i*lx multiply
+  // in its store, and the pair c2r that returns (d/dx f, d/dy f) from (Gx, A) with the i*ly multiply in its fetch.
+  void gen_y_r2c(const T* map, cx<T>* A, long slices, const T* map2 = nullptr, cx<T>* A2 = nullptr) {
+    GenDft<T> a{};
+    a.in = map; a.out = A; a.in2 = map2; a.out2 = A2; a.in_real = 1; a.nin = Ny; a.nout = Nyh; a.nseq = Nx; a.scale = 1; a.scale2 = 1;
+    a.in_seq = Ny; a.in_elem = 1; a.in_slice = npix(); a.out_seq = 1; a.out_elem = Nx; a.out_slice = plane();
+    gen_dft(genY, a, slices);
+  }
+  void gen_y_c2r_pair(const cx<T>* G1, const cx<T>* G2, const T* lmul2, T* o1, T* o2, T s1, T s2, long slices) {
+    GenDft<T> a{};
+    a.in = G1; a.in2 = G2; a.lmul_in = lmul2; a.out = o1; a.out2 = o2; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx;
+    a.scale = s1; a.scale2 = s2;
+    a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
+    gen_dft(genY, a, slices);
+  }
+  void gen_x(const cx<T>* in, cx<T>* out, bool inverse, const T* lmul_out, long slices) {
+    GenDft<T> b{};
+    b.in = in; b.out = out; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1; b.inverse = inverse ? 1 : 0; b.lmul_out = lmul_out;
+    b.in_seq = Nx; b.in_elem = 1; b.in_slice = plane(); b.out_seq = Nx; b.out_elem = 1; b.out_slice = plane();
+    gen_dft(genX, b, slices);
+  }
   template <typename V> void transpose(const V* in, V* out, int R, int C, long slices) {
     CMBL_LAUNCH(this, K_LAYOUT, (k_transpose<V>), dim3((C + 31) / 32, (R + 31) / 32, (unsigned)slices), 0, stream, in, out, R, C);
   }
@@ -774,6 +796,21 @@ struct Flow {
   DevBuf gF, gFxy, gmxy, gms, gYs, gLdf, gWxy;
   dim3 pgrid(long n, long slices) const { return dim3((unsigned)std::min<long>((n + NTP - 1) / NTP, 4096), (unsigned)slices); }
   dim3 fgrid(long slices) const { return dim3((unsigned)((c->plane() + NTP - 1) / NTP), (unsigned)slices); }
+  // (gmx, gmy) = grad of the stage input f_s from its y transform A = rfft_y(f_s) (mixed layout), using the separability the fused
+  // kernels use: d/dy needs the y transform alone (the i*ly multiply commutes with the x transforms, which then cancel), d/dx one
+  // forward / i*lx / inverse x pass; ONE complex inverse y transform returns both real maps (pair c2r).  Equal to the reference's
+  // rfft2 -> (i lx, i ly) -> 2 x irfft2 (src/lenseflow.jl:155-157) incl. FFTW's c2r rule at ky = 0 / Nyquist, in 3 launches and
+  // 3 slice-passes instead of 5 launches and 7.5.  CMBL_GEN_SEPARABLE=0: the reference's own pass structure (kept for A/B).
+  DevBuf gA, gGx, gT, gW2;
+  bool gen_sep() const { return env_int("CMBL_GEN_SEPARABLE", 1) != 0; }
+  void gen_grad_sep(const cx<T>* A_, long slices) {
+    const long pl = c->plane(), np = c->npix();
+    gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); gmxy.ensure(sizeof(T) * 2 * slices * np);
+    c->gen_x(A_, gT.as<cx<T>>(), false, c->lx_r.template as<T>(), slices);                      // i lx fft_x(A)
+    c->gen_x(gT.as<cx<T>>(), gGx.as<cx<T>>(), true, nullptr, slices);                          // Nx * d/dx in mixed space
+    c->gen_y_c2r_pair(gGx.as<cx<T>>(), A_, c->ly.template as<T>(), gmxy.as<T>(), gmxy.as<T>() + slices * np,
+                      (T)(1.0 / ((double)c->Ny * c->Nx)), (T)(1.0 / (double)c->Ny), slices);
+  }
   // (gmx, gmy) = grad of the map `ys`  (rfft2, i l multiplies, irfft2 of both components)
   void gen_grad(const T* ys, long slices) {
     const long pl = c->plane(), np = c->npix();
@@ -784,25 +821,34 @@ struct Flow {
     c->F_to_map(gFxy.as<cx<T>>(), gmxy.as<T>(), 2 * slices);
   }
   // d(Fourier state)/dt from the maps (Wx, Wy) = the halves of Wxy: rfft2 of both + the RK update with k = i lx Fx + i ly Fy
+  // (separable form: the two real maps go through ONE complex y transform, then one x launch over both)
   void gen_adj_update(const T* Wxy, cx<T>* Y0, cx<T>* Yacc_, cx<T>* Ys, const RKCoef<T>& rk, long slices) {
-    const long pl = c->plane();
+    const long pl = c->plane(), np = c->npix();
     gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl);
-    c->rfft2_F(Wxy, gFxy.as<cx<T>>(), 2 * slices);
+    if (gen_sep()) {
+      gW2.ensure(sizeof(cx<T>) * 2 * slices * pl);
+      c->gen_y_r2c(Wxy, gW2.as<cx<T>>(), slices, Wxy + slices * np, gW2.as<cx<T>>() + slices * pl);
+      c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
+    } else c->rfft2_F(Wxy, gFxy.as<cx<T>>(), 2 * slices);
     CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
                 c->ly.template as<T>(), c->Nx, Y0, Yacc_, Ys, rk, pl);
   }
   void gen_flow_map(const T* in, T* out, int P, int B, bool inverse) {
-    const long slices = (long)P * B, np = c->npix();
+    const long slices = (long)P * B, np = c->npix(), pl = c->plane();
     acc.ensure(sizeof(T) * slices * np); gms.ensure(sizeof(T) * slices * np);
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
     CMBL_HIP(hipMemcpyAsync(gms.p, out, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
     const double t0 = inverse ? 1.0 : 0.0, h = (inverse ? -1.0 : 1.0) / n;
+    const bool sep = gen_sep();
+    if (sep) { gA.ensure(sizeof(cx<T>) * slices * pl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
-        const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
-        gen_grad(gms.as<T>(), slices);
+        const bool last = step == n - 1 && stage == 4;
+        const RKCoef<T> rk = coef(step, stage, t0, h, last);
+        if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);
         CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_vel_rk<T>), pgrid(np, slices), 0, c->stream, gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t), out, acc.as<T>(),
                     gms.as<T>(), rk, np, P);
+        if (sep && !last) c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices);
       }
   }
   void gen_flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse) {
@@ -831,6 +877,8 @@ struct Flow {
     CMBL_HIP(hipMemcpyAsync(gms.p, f, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
     CMBL_HIP(hipMemcpyAsync(gYs.p, df, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
+    const bool sep = gen_sep();
+    if (sep) { gA.ensure(sizeof(cx<T>) * slices * pl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
     tc_host.resize(2 * (size_t)nst);
     int it = 0;
     for (int step = 0; step < n; ++step)
@@ -839,10 +887,11 @@ struct Flow {
         tc_host[2 * it] = rk.t;
         tc_host[2 * it + 1] = (T)((stage == 1 || stage == 4 ? 1.0 : 2.0) * h / 6);
         c->F_to_map(gYs.as<cx<T>>(), gLdf.as<T>(), slices);                   // L(df)
-        gen_grad(gms.as<T>(), slices);                                       // grad f -> gmxy
+        if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);   // grad f -> gmxy
         T* w1p = Wst.as<T>() + (size_t)(2 * it) * slices * np;
         CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_delta<T>), pgrid(np, slices), 0, c->stream, gLdf.as<T>(), gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t),
                     gWxy.as<T>(), gWxy.as<T>() + slices * np, w1p, w1p + (size_t)slices * np, f, acc.as<T>(), gms.as<T>(), rk, np, P);
+        if (sep && !rk.last) c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices);
         gen_adj_update(gWxy.as<T>(), df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
       }
     dphi_finish(dphi, P, B, nst, alias_quirk);

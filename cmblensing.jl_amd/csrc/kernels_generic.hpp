@@ -36,6 +36,11 @@ __global__ __launch_bounds__(NTP) void k_transpose(const V* __restrict__ in, V* 
   }
 }
 
+template <typename T>
+__device__ __forceinline__ void gen_p(const PhiMaps<T>& ph, size_t gi, T t, T& px, T& py) {
+  if (ph.pcx) { px = ph.pcx[gi]; py = ph.pcy[gi]; }
+  else { T m11, m12, m22; flow_pm(t, ph.gx[gi], ph.gy[gi], ph.hxx[gi], ph.hyx[gi], ph.hyy[gi], px, py, m11, m12, m22); }
+}
 // One launch = `nseq` sequences per slice (blockIdx.y), S per workgroup.  Element n of sequence q of slice s is at
 // in[s*in_slice + q*in_seq + n*in_elem] (real T or cx<T>), likewise for the output.
 template <typename T> struct GenDft {
@@ -47,28 +52,63 @@ template <typename T> struct GenDft {
   long in_seq, in_elem, in_slice, out_seq, out_elem, out_slice;
   int in_real, out_real, inverse, herm;
   T scale;
+  // Separable-derivative / pair options (all off by default):
+  //   lmul_in  : half-spectrum input element m is multiplied by i*lmul_in[m] as it is fetched (d/dy from the y transform alone)
+  //   lmul_out : output element k is multiplied by i*lmul_out[k] (d/dx: forward x pass with the i*lx multiply in its store)
+  //   in2 / out2 (pair): TWO real sequences per complex transform.  herm (c2r): z = ext(in) + i ext(in2) -> out = Re, out2 = Im with
+  //              scales (scale, scale2); lmul_in applies to the SECOND member only.  in_real (r2c): z = in + i in2 ->
+  //              out[k] = (Z[k] + conj Z[N-k]) / 2, out2[k] = (Z[k] - conj Z[N-k]) / 2i, k < nout.
+  const T* lmul_in; const T* lmul_out;
+  const void* in2; void* out2;
+  T scale2;
 };
 
 
 // input element n of a sequence: real / complex / Hermitian-extended half spectrum, conjugated for the e^{+i} transform
+// Hermitian extension of a half spectrum with FFTW's c2r rule; `lm` != nullptr: the stored entries are multiplied by i*lm[m] first
+template <typename T>
+__device__ __forceinline__ cx<T> gen_herm(const cx<T>* p, size_t base, long elem, int n, int nin, int N, const T* lm) {
+  const int m = n < nin ? n : N - n;
+  cx<T> v = p[base + (size_t)m * elem];
+  if (lm) v = mul_il(v, lm[m]);
+  if (n == 0 || 2 * n == N) v.y = T(0);                               // FFTW c2r: these imaginary parts are never read
+  return n < nin ? v : conj(v);
+}
 template <typename T>
 __device__ __forceinline__ cx<T> gen_fetch(const GenDft<T>& a, size_t sl, int seq, int n) {
   const size_t base = sl * a.in_slice + (size_t)seq * a.in_seq;
   cx<T> v;
-  if (a.in_real) v = mk<T>(reinterpret_cast<const T*>(a.in)[base + (size_t)n * a.in_elem], T(0));
-  else if (!a.herm) v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
-  else if (n < a.nin) {
-    v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
-    if (n == 0 || 2 * n == a.N) v.y = T(0);                           // FFTW c2r: these imaginary parts are never read
-  } else v = conj(reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)(a.N - n) * a.in_elem]);
+  if (a.in_real) {
+    v = mk<T>(reinterpret_cast<const T*>(a.in)[base + (size_t)n * a.in_elem], T(0));
+    if (a.in2) v.y = reinterpret_cast<const T*>(a.in2)[base + (size_t)n * a.in_elem];
+  } else if (!a.herm) v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
+  else if (!a.in2) v = gen_herm(reinterpret_cast<const cx<T>*>(a.in), base, a.in_elem, n, a.nin, a.N, a.lmul_in);
+  else {
+    const cx<T> u = gen_herm(reinterpret_cast<const cx<T>*>(a.in), base, a.in_elem, n, a.nin, a.N, (const T*)nullptr);
+    const cx<T> w = gen_herm(reinterpret_cast<const cx<T>*>(a.in2), base, a.in_elem, n, a.nin, a.N, a.lmul_in);
+    v = mk<T>(u.x - w.y, u.y + w.x);                                  // u + i w
+  }
   return a.inverse ? conj(v) : v;                                     // e^{+i} transform = conj(forward(conj x))
 }
+// y = Z[k]; yr = Z[(N - k) % N] (only read for a real pair)
 template <typename T>
-__device__ __forceinline__ void gen_put(const GenDft<T>& a, size_t sl, int seq, int k, cx<T> y) {
+__device__ __forceinline__ void gen_put(const GenDft<T>& a, size_t sl, int seq, int k, cx<T> y, cx<T> yr = cx<T>{}) {
   if (a.inverse) y = conj(y);
   const size_t o = sl * a.out_slice + (size_t)seq * a.out_seq + (size_t)k * a.out_elem;
-  if (a.out_real) reinterpret_cast<T*>(a.out)[o] = a.scale * y.x;
-  else reinterpret_cast<cx<T>*>(a.out)[o] = mk<T>(a.scale * y.x, a.scale * y.y);
+  if (a.out_real) {
+    reinterpret_cast<T*>(a.out)[o] = a.scale * y.x;
+    if (a.out2) reinterpret_cast<T*>(a.out2)[o] = a.scale2 * y.y;
+    return;
+  }
+  if (a.in_real && a.in2) {                                           // split the transform of in + i in2
+    const cx<T> c = conj(yr);
+    const cx<T> x1 = mk<T>(T(0.5) * (y.x + c.x), T(0.5) * (y.y + c.y)), d = mk<T>(T(0.5) * (y.x - c.x), T(0.5) * (y.y - c.y));
+    reinterpret_cast<cx<T>*>(a.out)[o] = mk<T>(a.scale * x1.x, a.scale * x1.y);
+    reinterpret_cast<cx<T>*>(a.out2)[o] = mk<T>(a.scale2 * d.y, -a.scale2 * d.x);            // d / i
+    return;
+  }
+  if (a.lmul_out) y = mul_il(y, a.lmul_out[k]);
+  reinterpret_cast<cx<T>*>(a.out)[o] = mk<T>(a.scale * y.x, a.scale * y.y);
 }
 
 template <typename T, int LGL>
@@ -102,7 +142,8 @@ __global__ __launch_bounds__(NTP) void k_gen_dft(GenDft<T> a) {
     if (out_by_seq) { sq = q % S; k = q / S; } else { sq = q / a.nout; k = q - sq * a.nout; }
     const int seq = seq0 + sq;
     if (seq >= a.nseq) continue;
-    gen_put(a, sl, seq, k, s[sq * LD + pad(k)] * a.chirp[k]);
+    const int kr = k ? a.N - k : 0;
+    gen_put(a, sl, seq, k, s[sq * LD + pad(k)] * a.chirp[k], s[sq * LD + pad(kr)] * a.chirp[kr]);
   }
 }
 
@@ -223,16 +264,11 @@ __global__ __launch_bounds__(BIG ? NTP : 1024) void k_gen_dft_mr(GenDft<T> a, Ge
     int sq, k;
     if (out_by_seq) { sq = q % S; k = q / S; } else { sq = q / a.nout; k = q - sq * a.nout; }
     const int seq = seq0 + sq;
-    if (seq < a.nseq) gen_put(a, sl, seq, k, X[sq * N + k]);
+    if (seq < a.nseq) gen_put(a, sl, seq, k, X[sq * N + k], X[sq * N + (k ? N - k : 0)]);
   }
 }
 
 // ---- pointwise pieces of a flow stage ----------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void gen_p(const PhiMaps<T>& ph, size_t gi, T t, T& px, T& py) {
-  if (ph.pcx) { px = ph.pcx[gi]; py = ph.pcy[gi]; }
-  else { T m11, m12, m22; flow_pm(t, ph.gx[gi], ph.gy[gi], ph.hxx[gi], ph.hyx[gi], ph.hyy[gi], px, py, m11, m12, m22); }
-}
 
 // (Fx, Fy) = (i lx F, i ly F)        F layout, grid (blocks, slices)     (src/lenseflow.jl:155, src/specialops.jl:184-188)
 template <typename T>
