@@ -408,13 +408,10 @@ class JLD2File:
             val = vals[0].item() if isinstance(vals, np.ndarray) else vals[0]
         elif isinstance(vals, np.ndarray):
             val = vals.reshape(dims)                                    # HDF5 dims are Julia's reversed: C order (.., Nx, Ny)
-            jt = dt.julia_type or ""
-            if dt.cls == 6:
-                pass
         else:
             val = _nest(vals, dims)
-        # complex numbers are compounds {re, im}: arrays of them arrive as lists of dicts -- fuse
-        val = _fuse_complex(val, dims if kind == "simple" else None)
+        # complex numbers are compounds {re, im}: short arrays of them arrive as lists of Python complex -- fuse
+        val = _fuse_complex(val)
         self._memo[off] = val
         return val
 
@@ -491,7 +488,7 @@ def _julia_struct(jt, d):
     keys = list(d)
     if keys == ["re", "im"] and all(isinstance(v, (int, float)) for v in d.values()):
         return complex(d["re"], d["im"])
-    if short == "Symbol" or (keys == ["name"] and False):
+    if short == "Symbol" and len(d) == 1:
         return next(iter(d.values()))
     if jt:
         d["__julia_type__"] = jt
@@ -506,7 +503,7 @@ def _nest(vals, dims):
     return [_nest(vals[i * inner:(i + 1) * inner], dims[1:]) for i in range(dims[0])]
 
 
-def _fuse_complex(val, dims):
+def _fuse_complex(val):
     if isinstance(val, list) and val and all(isinstance(v, complex) for v in _flat(val)):
         return np.asarray(val, dtype=np.complex128)
     return val
