@@ -354,6 +354,23 @@ struct Ctx : CtxBase {
     return best;
   }
   // column tile: twiddles + C columns of an N-point (pair) or M-point (packed) transform, padded rows
+  // The delta-flow column kernel holds the most state per thread: at 2048 rows in double precision its four-column tile (8 pairs per
+  // thread) needs 256 registers + 80 spilled, the two-column tile (4 pairs) fits -- measured (grad L)' 10.95 -> 10.45 ms at 2048^2 fp64,
+  // while the forward and adjoint column kernels are faster on four columns (L'g 5.13 vs 5.45 ms).
+  TileY tileY_delta(long slices) const {
+    if (sizeof(T) == 8 && lgM == 10 && tuneC == 0) {
+      TileY t = tileY(slices, true, 0);
+      static const int list[][3] = {
+#define CMBL_X(lgm, r, nt) {lgm, r, nt},
+          CMBL_COL_LIST(CMBL_X)
+#undef CMBL_X
+      };
+      for (const auto& e : list)
+        if (e[0] == lgM && e[2] == 512 && (((long)e[1] * e[2]) >> lgM) == 2 && ldsY(2, true) <= 160 * 1024) return TileY{2, e[2], e[1]};
+      return t;
+    }
+    return tileY(slices, true);
+  }
   size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
   // Row launches: one workgroup per group of RPW adjacent ky rows of a slice (RPW = row_rpw<T>(lgNx, row sets), kernels_fft.hpp)
   // Row launches of about one workgroup per CU (258 row groups at 1024^2 QU) run faster when no CU hosts two of them: two co-resident
@@ -1037,7 +1054,7 @@ struct Flow {
     if (!h_ready) c->template x_pass<1>(df, H.as<cx<T>>(), slices);
     const int K = groups(P, B);
     const long gs = slices / K;
-    const auto tile = c->tileY(gs, true);
+    const auto tile = c->tileY_delta(gs);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
     c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);                // later d/dx passes ride along with the previous stage's row launch
     tc_host.resize(2 * (size_t)nst);
