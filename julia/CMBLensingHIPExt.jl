@@ -8,7 +8,7 @@
 #
 # What plugs in where
 #   1. storage level, the twin of ext/CMBLensingCUDAExt.jl:42-93 for `ROCArray`: `gpu`, `is_gpu_backed`, `Cℓ_to_2D`, `pinv` / `inv`
-#      of Diagonals, `fill!`, `sum`, `dot` of arrays, CPU-RNG `randn!` into device memory, `unsafe_free!`.  With these alone the
+#      of Diagonals, `fill!`, `sum`, CPU-RNG `randn!` into device memory, `unsafe_free!`.  With these alone the
 #      reference runs on the GPU through AMDGPU.jl broadcasts + rocFFT plans (AbstractFFTs dispatches on the array type,
 #      src/util_fft.jl:32-35); everything below replaces the hot path on top.
 #   2. `HIPLenseFlow <: FlowOpWithAdjoint` takes the `ds.L` operator slot (src/dataset.jl:55, `load_sim(L = HIPLenseFlow)`):
@@ -69,9 +69,10 @@ LinearAlgebra.inv(D::Diagonal{T,<:ROCBaseField}) where {T} =
 Base.fill!(f::ROCBaseField, x) = (fill!(f.arr, x); f)                                             # :57
 Base.sum(f::ROCBaseField; dims=:) =
     (dims == :) ? CMBLensing.sum_dropdims(f.arr) : (1 in dims) ? error("Sum over invalid dims of a flat field.") : f      # :58
-Random.randn!(rng::MersenneTwister, A::ROCArray) = (A .= adapt(ROCArray, randn!(rng, adapt(Array, A))))   # :72-73 host RNG + upload
+Random.randn!(rng::MersenneTwister, A::ROCArray) = (A .= adapt(ROCArray, randn!(rng, adapt(Array, A))))   # :72-73 host RNG + upload (upstream's own "minor type-piracy", kept: `simulate` with the CPU generator needs it)
 CMBLensing.unsafe_free!(x::ROCArray) = AMDGPU.unsafe_free!(x)                                     # :88
-LinearAlgebra.dot(x::ROCArray, y::ROCArray) = sum(conj.(x) .* y)                                  # :91-93
+# (:91-93, `dot(x::CuArray, y::CuArray) = sum(conj.(x) .* y)`, works around a CUDA.jl / Zygote issue and has no twin here: AMDGPU.jl's own
+# `dot` is left alone -- redefining it for two ROCArrays would be type piracy on a package this module does not own)
 
 # ---- context: replaces the memoized ProjLambert + FFT plans (src/proj_lambert.jl:48-75, src/util_fft.jl:32-39) ----------------
 mutable struct HIPContext

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Interleaved A/B of two library builds (the in-tree one and an experiment under cmblensing.jl_amd/_dev/, selected with CMBL_LIB) on
+# the bench workloads: edit the `lib` list / configurations as needed.  Used for profiles/r03_ab_colblock_rejected.txt.
 for rep in 1 2; do
 for lib in cmblensing.jl_amd/libcmblens_hip.so cmblensing.jl_amd/_dev/lib_cb.so; do
   for cfg in "--config 3" "--config 5 --steps 20" "--nbatch 8 --steps 20" "" "--nbatch 2"; do
