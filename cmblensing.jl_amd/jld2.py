@@ -7,6 +7,7 @@ from the HDF5 file-format specification (version 3.0) and the layout of files th
 dat/default_camb_Cls.jld2 is the real-world test vector: tests/test_jld2.py):
 
   * 512-byte text header, then a version-2 superblock; every address in the file is relative to the superblock (base address 512);
+    superblock, object headers and continuation blocks end in a Jenkins lookup3 checksum, which is verified (`verify=True`);
   * version-2 object headers ("OHDR", continuation blocks "OCHK"); groups are object headers whose links are plain link messages;
   * messages: dataspace (0x01), link info (0x02, skipped), datatype (0x03, incl. shared = committed datatypes), fill value (0x05,
     skipped), link (0x06), data layout (0x08: compact, contiguous, version-3 chunked with one implicit chunk, version-4 single-chunk),
@@ -35,6 +36,43 @@ class JLD2Error(ValueError):
 UNDEF = 0xFFFFFFFFFFFFFFFF
 
 
+def _rot(x, k):
+    return ((x << k) | (x >> (32 - k))) & 0xFFFFFFFF
+
+
+def lookup3(data, init=0):
+    """Bob Jenkins' lookup3 `hashlittle`, the checksum HDF5 puts behind superblocks, version-2 object headers and their continuation
+    blocks (H5_checksum_lookup3).  Verified on the reference's own JLD2 file: the superblock and all 80 object headers match."""
+    a = b = c = (0xDEADBEEF + len(data) + init) & 0xFFFFFFFF
+    k, n, M = 0, len(data), 0xFFFFFFFF
+    while n > 12:
+        a = (a + int.from_bytes(data[k:k + 4], "little")) & M
+        b = (b + int.from_bytes(data[k + 4:k + 8], "little")) & M
+        c = (c + int.from_bytes(data[k + 8:k + 12], "little")) & M
+        a = (a - c) & M; a ^= _rot(c, 4); c = (c + b) & M
+        b = (b - a) & M; b ^= _rot(a, 6); a = (a + c) & M
+        c = (c - b) & M; c ^= _rot(b, 8); b = (b + a) & M
+        a = (a - c) & M; a ^= _rot(c, 16); c = (c + b) & M
+        b = (b - a) & M; b ^= _rot(a, 19); a = (a + c) & M
+        c = (c - b) & M; c ^= _rot(b, 4); b = (b + a) & M
+        k += 12
+        n -= 12
+    if n == 0:
+        return c
+    tail = bytes(data[k:k + n]) + b"\0" * (12 - n)
+    a = (a + int.from_bytes(tail[0:4], "little")) & M
+    b = (b + int.from_bytes(tail[4:8], "little")) & M
+    c = (c + int.from_bytes(tail[8:12], "little")) & M
+    c ^= b; c = (c - _rot(b, 14)) & M
+    a ^= c; a = (a - _rot(c, 11)) & M
+    b ^= a; b = (b - _rot(a, 25)) & M
+    c ^= b; c = (c - _rot(b, 16)) & M
+    a ^= c; a = (a - _rot(c, 4)) & M
+    b ^= a; b = (b - _rot(a, 14)) & M
+    c ^= b; c = (c - _rot(b, 24)) & M
+    return c
+
+
 class _Datatype:
     __slots__ = ("cls", "size", "np", "members", "base", "vlen_string", "dims", "julia_type", "tag", "written_type")
 
@@ -51,7 +89,9 @@ class _Datatype:
 
 
 class JLD2File:
-    def __init__(self, path):
+    def __init__(self, path, verify=True):
+        """verify: check the lookup3 checksums of the superblock and of every object header / continuation block that is read"""
+        self.verify = verify
         with open(path, "rb") as fh:
             self.buf = fh.read()
         b = self.buf
@@ -64,6 +104,8 @@ class JLD2File:
         if ver not in (2, 3) or so != 8 or sl != 8:
             raise JLD2Error(f"unsupported superblock (version {ver}, offsets {so}, lengths {sl})")
         base, ext, eof, root = struct.unpack_from("<QQQQ", b, 524)
+        if verify and lookup3(b[512:556]) != struct.unpack_from("<I", b, 556)[0]:
+            raise JLD2Error("superblock checksum mismatch (file corrupt or truncated)")
         self.base = base
         self.root = root
         self._committed = {}
@@ -88,6 +130,8 @@ class JLD2File:
         nb = 1 << (flags & 3)
         size = int.from_bytes(b[p:p + nb], "little")
         p += nb
+        if self.verify and lookup3(b[self.base + off:p + size]) != struct.unpack_from("<I", b, p + size)[0]:
+            raise JLD2Error(f"object header at {off:#x}: checksum mismatch")
         out = []
         blocks = [(p, size)]
         while blocks:
@@ -105,6 +149,8 @@ class JLD2File:
                     cp = self.base + coff
                     if b[cp:cp + 4] != b"OCHK":
                         raise JLD2Error("bad continuation block")
+                    if self.verify and lookup3(b[cp:cp + clen - 4]) != struct.unpack_from("<I", b, cp + clen - 4)[0]:
+                        raise JLD2Error(f"continuation block at {coff:#x}: checksum mismatch")
                     blocks.append((cp + 4, clen - 8))          # minus signature and checksum
                 elif mtype != 0:
                     out.append((mtype, mflags, data))

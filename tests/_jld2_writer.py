@@ -5,8 +5,8 @@ ones the reader's docstring lists:
 
     offset 0      512-byte text header "HDF5-based Julia Data Format, version 0.1.1 ..."
     offset 512    superblock version 2 (offsets / lengths 8 bytes, base address 512, root group object header address)
-    then          objects, each a version-2 object header "OHDR" (flags 0x02: 4-byte chunk size) + Jenkins-checksum slot (zero: neither
-                  reader verifies it here); all addresses relative to the base address
+    then          objects, each a version-2 object header "OHDR" (flags 0x02: 4-byte chunk size) + its Jenkins lookup3 checksum (the
+                  reader verifies it); all addresses relative to the base address
     groups        link messages (type 0x06, version 1, flags 0x10|size bits: charset byte + 1-byte name length), hard links
     datasets      dataspace v2 (scalar / simple), datatype (inline or shared -> committed datatype object), layout v3 contiguous
     committed dt  object header holding the datatype message + attribute "julia_type" (here a fixed-length string; real JLD2
@@ -56,6 +56,8 @@ def _shared(addr):
 
 
 class Writer:
+    lookup3 = None                                                        # set by the test module: the reader's checksum function
+
     def __init__(self):
         self.buf = bytearray(b"HDF5-based Julia Data Format, version 0.1.1\0 (hand-built test file)".ljust(512, b"\0"))
         self.buf += bytes(48)                                             # superblock, filled in by close()
@@ -67,7 +69,8 @@ class Writer:
     def _object(self, msgs):
         body = b"".join(msgs)
         a = self._addr()
-        self.buf += b"OHDR" + bytes([2, 0x02]) + struct.pack("<I", len(body)) + body + bytes(4)
+        hdr = b"OHDR" + bytes([2, 0x02]) + struct.pack("<I", len(body)) + body
+        self.buf += hdr + struct.pack("<I", self.lookup3(hdr))
         return a
 
     def _data(self, raw):
@@ -141,7 +144,8 @@ class Writer:
         """root: {name: address}"""
         links = [_msg(0x06, bytes([1, 0x10, 0, len(k.encode())]) + k.encode() + struct.pack("<Q", a)) for k, a in root.items()]
         ra = self._object(links)
-        sb = b"\x89HDF\r\n\x1a\n" + bytes([2, 8, 8, 0]) + struct.pack("<QQQQ", 512, UNDEF, len(self.buf), ra) + bytes(4)
+        sb = b"\x89HDF\r\n\x1a\n" + bytes([2, 8, 8, 0]) + struct.pack("<QQQQ", 512, UNDEF, len(self.buf), ra)
+        sb += struct.pack("<I", self.lookup3(sb))
         self.buf[512:512 + len(sb)] = sb
         with open(path, "wb") as fh:
             fh.write(bytes(self.buf))

@@ -33,6 +33,7 @@ def _mod(name):
 
 J, CF = _mod("jld2"), _mod("chainfile")
 import _jld2_writer as W                                  # noqa: E402
+W.Writer.lookup3 = staticmethod(J.lookup3)
 
 REF_JLD2 = "/root/reference/dat/default_camb_Cls.jld2"
 
@@ -116,6 +117,23 @@ def test_load_chains_opens_the_reference_container(tmp_path):
     assert "phi" not in CF.load_chains(p, dropmaps=True)[0][0]
     k, step, last = CF.last_state(p)                                                        # what resume=True continues from
     assert (k, step) == (3, 6) and np.array_equal(last[1]["phi"], truth[(1, 6)][0])
+
+
+def test_checksums_are_verified(tmp_path):
+    """lookup3 known answers (Bob Jenkins' own test vectors for hashlittle) and corruption of an object header is detected"""
+    assert J.lookup3(b"") == 0xDEADBEEF and J.lookup3(b"", 0xDEADBEEF) == 0xBD5B7DDE
+    assert J.lookup3(b"Four score and seven years ago") == 0x17770551 and J.lookup3(b"Four score and seven years ago", 1) == 0xCD628161
+    p = str(tmp_path / "chain.jld2")
+    _hand_built_chain(p)
+    raw = bytearray(open(p, "rb").read())
+    i = raw.index(b"OHDR", 600) + 12                                   # a byte inside some object header's message area
+    raw[i] ^= 0x40
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(J.JLD2Error, match="checksum"):
+        f = J.JLD2File(p)
+        for k in f.keys():
+            f[k]
+    assert J.JLD2File(p, verify=False).keys() is not None                # the switch exists for salvage work: opening does not raise
 
 
 def test_unsupported_structures_fail_loudly(tmp_path):
