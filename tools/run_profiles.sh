@@ -24,6 +24,11 @@ for f in $out/traffic_*.json; do cp $f profiles/r03_$(basename $f); done
 cp $out/counter_calibration.json profiles/r03_counter_calibration.json 2>/dev/null
 B="python bench.py --no-cpu-baseline"
 python bench.py > $out/bench_line.json 2> $out/bench.err
+# kernel statistics of the headline workload over 50 warm steps, one launch over all pol slices: the per-kernel means bench.py's roofline
+# leg measures with the kernels' own timestamps (kernel_stats_1024QU_f32.csv, from the 8-step counter run, includes the cold first steps)
+CMBL_SLICE_STREAMS=1 rocprofv3 --kernel-trace --stats -f csv -d $out/trace_bench -o b -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline --no-extras > $out/trace_bench.log 2>&1
+s=$(find $out/trace_bench -name '*kernel_stats.csv' | head -1); [ -n "$s" ] && cp $s $out/kernel_stats_1024QU_f32_50steps.csv
+rm -rf $out/trace_bench
 if [ -z "$quick" ]; then
   for c in 2 3 5; do $B --config $c --steps 50 > $out/bench_config$c.json 2>> $out/bench.err; done
   $B --nbatch 8 --steps 30 > $out/bench_nbatch8.json 2>> $out/bench.err
