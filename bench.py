@@ -104,6 +104,25 @@ def measured_traffic(N, P, B, dtype, n, unit="grad"):
         return {}, None, None
 
 
+PROF_KERNEL = {"delta_cols": "k_delta_cols<", "delta_rows": "k_delta_rows<", "flow_y_fwd": "k_flow_y_fwd<", "adj_y": "k_adj_y<", "adj_x": "k_adj_x<",
+               "dphi_reduce": "k_dphi_reduce<"}
+
+
+def profiler_mean_us(kernel, N, P, B, dtype):
+    """Mean duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this workload (profiles/), or None.  The
+    profiler's kernel times run ~7 % above the un-profiled ones; reported next to the live figure, never instead of it."""
+    import csv
+    pol = {1: "I", 2: "QU", 3: "IQU"}[P]
+    tag = f"{N}{pol}_{dtype}{'_B%d' % B if B > 1 else ''}"
+    for name in (f"r03_kernel_stats_{tag}_50steps.csv", f"r03_kernel_stats_{tag}.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if kernel in PROF_KERNEL and os.path.isfile(path):
+            for r in csv.DictReader(open(path)):
+                if PROF_KERNEL[kernel] in r["Name"]:
+                    return float(r["AverageNs"]) / 1e3, "profiles/" + name
+    return None, None
+
+
 def cpu_baseline(N, pol, nsteps, npT=np.float32):
     """The NumPy oracle (kind 'port': the Julia reference cannot run here) timed on the host cores: one ∇lnP
     evaluation of the same workload (bounded sample)."""
@@ -357,6 +376,11 @@ def main():
                                    "CMBL_SLICE_STREAMS=1); value / ms_per_step / whole_step are the timed region with one launch chain per pol "
                                    "slice.  traffic = measured L2<->fabric bytes per launch (rocprofv3 PMC, Infinity-Cache hits included)",
                            "per_kernel": per, "whole_step": whole}
+        pus, psrc = profiler_mean_us(dom, N, P, B, args.dtype)
+        if pus:
+            out["roofline"]["rocprofv3"] = {"avg_launch_us": pus, "frac": d["compulsory_bytes_per_launch"] / (pus * 1e-6) / 1e9 / PEAK_GBS, "source": psrc,
+                                            "note": "the same kernel's mean in the committed rocprofv3 kernel-trace summary of this workload; the profiler's "
+                                                    "kernel times are ~7 % above the un-profiled ones (DESIGN.md §5)"}
     if rank == 0 and not args.no_extras and world == 1:
         def timeit(fn, n=10):
             for _ in range(2):
