@@ -305,6 +305,19 @@ struct Ctx : CtxBase {
     a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
     gen_dft(genY, a, slices);
   }
+  // out = ifft_x(i lx fft_x(in)) unnormalised, in ONE launch when the axis has a mixed-radix plan (else two: chirp-z transforms)
+  bool gen_x_deriv(const cx<T>* in, cx<T>* out, cx<T>* tmp, const T* lx, long slices) {
+    if (genX.plan.nf == 0 || env_int("CMBL_GEN_XDERIV_FUSED", 1) == 0) {
+      gen_x(in, tmp, false, lx, slices);
+      gen_x(tmp, out, true, nullptr, slices);
+      return false;
+    }
+    GenDft<T> b{};
+    b.in = in; b.out = out; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1; b.lmul_mid = lx;
+    b.in_seq = Nx; b.in_elem = 1; b.in_slice = plane(); b.out_seq = Nx; b.out_elem = 1; b.out_slice = plane();
+    gen_dft(genX, b, slices);
+    return true;
+  }
   void gen_x(const cx<T>* in, cx<T>* out, bool inverse, const T* lmul_out, long slices) {
     GenDft<T> b{};
     b.in = in; b.out = out; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1; b.inverse = inverse ? 1 : 0; b.lmul_out = lmul_out;
@@ -823,8 +836,7 @@ struct Flow {
   void gen_grad_sep(const cx<T>* A_, long slices) {
     const long pl = c->plane(), np = c->npix();
     gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); gmxy.ensure(sizeof(T) * 2 * slices * np);
-    c->gen_x(A_, gT.as<cx<T>>(), false, c->lx_r.template as<T>(), slices);                      // i lx fft_x(A)
-    c->gen_x(gT.as<cx<T>>(), gGx.as<cx<T>>(), true, nullptr, slices);                          // Nx * d/dx in mixed space
+    c->gen_x_deriv(A_, gGx.as<cx<T>>(), gT.as<cx<T>>(), c->lx_r.template as<T>(), slices);     // Nx * d/dx in mixed space: ifft_x(i lx fft_x(A))
     c->gen_y_c2r_pair(gGx.as<cx<T>>(), A_, c->ly.template as<T>(), gmxy.as<T>(), gmxy.as<T>() + slices * np,
                       (T)(1.0 / ((double)c->Ny * c->Nx)), (T)(1.0 / (double)c->Ny), slices);
   }

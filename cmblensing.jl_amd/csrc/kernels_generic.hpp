@@ -61,6 +61,9 @@ template <typename T> struct GenDft {
   const T* lmul_in; const T* lmul_out;
   const void* in2; void* out2;
   T scale2;
+  // lmul_mid (mixed-radix kernel only): forward transform, multiply element k by i*lmul_mid[k], INVERSE transform, all in LDS -- the
+  // d/dx pass of a stage in one launch (unnormalised: the caller's scale carries 1/N)
+  const T* lmul_mid;
 };
 
 
@@ -239,6 +242,15 @@ __global__ __launch_bounds__(BIG ? NTP : 1024) void k_gen_dft_mr(GenDft<T> a, Ge
     X[sq * N + n] = seq < a.nseq ? gen_fetch(a, sl, seq, n) : mk<T>(T(0), T(0));
   }
   __syncthreads();
+  const int npass = a.lmul_mid ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  if (pass == 1) {                                                    // X = conj(i l X): the inverse transform is conj(forward(conj .))
+    for (int q = threadIdx.x; q < S * N; q += nt) {
+      const int sq = q / N, k = q - sq * N;
+      X[q] = conj(mul_il(X[q], a.lmul_mid[k]));
+    }
+    __syncthreads();
+  }
   int Ns = 1;
   for (int f = 0; f < plan.nf; ++f) {
     const int R = plan.radix[f];
@@ -260,11 +272,12 @@ __global__ __launch_bounds__(BIG ? NTP : 1024) void k_gen_dft_mr(GenDft<T> a, Ge
     Ns *= R;
     cx<T>* t = X; X = Y; Y = t;
   }
+  }
   for (int q = threadIdx.x; q < S * a.nout; q += nt) {
     int sq, k;
     if (out_by_seq) { sq = q % S; k = q / S; } else { sq = q / a.nout; k = q - sq * a.nout; }
     const int seq = seq0 + sq;
-    if (seq < a.nseq) gen_put(a, sl, seq, k, X[sq * N + k], X[sq * N + (k ? N - k : 0)]);
+    if (seq < a.nseq) gen_put(a, sl, seq, k, a.lmul_mid ? conj(X[sq * N + k]) : X[sq * N + k], X[sq * N + (k ? N - k : 0)]);
   }
 }
 
