@@ -292,8 +292,9 @@ struct Ctx : CtxBase {
   // Separable pieces of the any-size path (mixed layout [slice][ky][x], like the fused kernels use between their column and row passes):
   // the y transform alone (one real map, or TWO real maps per complex transform), the x transform alone with an optional i*lx multiply
   // in its store, and the pair c2r that returns (d/dx f, d/dy f) from (Gx, A) with the i*ly multiply in its fetch.
-  void gen_y_r2c(const T* map, cx<T>* A, long slices, const T* map2 = nullptr, cx<T>* A2 = nullptr) {
+  void gen_y_r2c(const T* map, cx<T>* A, long slices, const T* map2 = nullptr, cx<T>* A2 = nullptr, const GenPro<T>* pro = nullptr) {
     GenDft<T> a{};
+    if (pro) a.pro = *pro;
     a.in = map; a.out = A; a.in2 = map2; a.out2 = A2; a.in_real = 1; a.nin = Ny; a.nout = Nyh; a.nseq = Nx; a.scale = 1; a.scale2 = 1;
     a.in_seq = Ny; a.in_elem = 1; a.in_slice = npix(); a.out_seq = 1; a.out_elem = Nx; a.out_slice = plane();
     gen_dft(genY, a, slices);
@@ -851,12 +852,15 @@ struct Flow {
   }
   // d(Fourier state)/dt from the maps (Wx, Wy) = the halves of Wxy: rfft2 of both + the RK update with k = i lx Fx + i ly Fy
   // (separable form: the two real maps go through ONE complex y transform, then one x launch over both)
-  void gen_adj_update(const T* Wxy, cx<T>* Y0, cx<T>* Yacc_, cx<T>* Ys, const RKCoef<T>& rk, long slices) {
+  bool gen_pro() const { return env_int("CMBL_GEN_PROLOGUE", 1) != 0; }
+  void gen_adj_update(const T* Wxy, cx<T>* Y0, cx<T>* Yacc_, cx<T>* Ys, const RKCoef<T>& rk, long slices, const GenPro<T>* pro = nullptr) {
     const long pl = c->plane(), np = c->npix();
     gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl);
     if (gen_sep()) {
       gW2.ensure(sizeof(cx<T>) * 2 * slices * pl);
-      c->gen_y_r2c(Wxy, gW2.as<cx<T>>(), slices, Wxy + slices * np, gW2.as<cx<T>>() + slices * pl);
+      // pro (mode 3): the pair is formed in the fetch from L(df) and p; `in` / `in2` only mark the launch as a real pair
+      if (pro) c->gen_y_r2c(pro->Ldf, gW2.as<cx<T>>(), slices, pro->Ldf, gW2.as<cx<T>>() + slices * pl, pro);
+      else c->gen_y_r2c(Wxy, gW2.as<cx<T>>(), slices, Wxy + slices * np, gW2.as<cx<T>>() + slices * pl);
       c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
     } else c->rfft2_F(Wxy, gFxy.as<cx<T>>(), 2 * slices);
     CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
@@ -875,6 +879,12 @@ struct Flow {
         const bool last = step == n - 1 && stage == 4;
         const RKCoef<T> rk = coef(step, stage, t0, h, last);
         if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);
+        if (sep && !last && gen_pro()) {                                     // velocity + RK bookkeeping in the fetch of the next stage's y transform
+          GenPro<T> e{};
+          e.mode = 1; e.ph = ph(rk.t); e.rk = rk; e.gx = gmxy.as<T>(); e.gy = gmxy.as<T>() + slices * np; e.y0 = out; e.acc = acc.as<T>(); e.npix = np; e.P = P;
+          c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices, nullptr, nullptr, &e);
+          continue;
+        }
         CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_vel_rk<T>), pgrid(np, slices), 0, c->stream, gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t), out, acc.as<T>(),
                     gms.as<T>(), rk, np, P);
         if (sep && !last) c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices);
@@ -918,6 +928,18 @@ struct Flow {
         c->F_to_map(gYs.as<cx<T>>(), gLdf.as<T>(), slices);                   // L(df)
         if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);   // grad f -> gmxy
         T* w1p = Wst.as<T>() + (size_t)(2 * it) * slices * np;
+        if (sep && !rk.last && gen_pro()) {
+          // the stage's pointwise work rides in the fetches of the two y transforms that consume it: f part + products -> rfft_y(f_{s+1});
+          // (p_x L(df), p_y L(df)) -> the pair r2c of the delta-f velocity
+          GenPro<T> e{};
+          e.ph = ph(rk.t); e.rk = rk; e.gx = gmxy.as<T>(); e.gy = gmxy.as<T>() + slices * np; e.Ldf = gLdf.as<T>(); e.y0 = f; e.acc = acc.as<T>();
+          e.w1p = w1p; e.w2p = w1p + (size_t)slices * np; e.npix = np; e.P = P;
+          e.mode = 2;
+          c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices, nullptr, nullptr, &e);
+          e.mode = 3;
+          gen_adj_update(nullptr, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices, &e);
+          continue;
+        }
         CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_delta<T>), pgrid(np, slices), 0, c->stream, gLdf.as<T>(), gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t),
                     gWxy.as<T>(), gWxy.as<T>() + slices * np, w1p, w1p + (size_t)slices * np, f, acc.as<T>(), gms.as<T>(), rk, np, P);
         if (sep && !rk.last) c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices);

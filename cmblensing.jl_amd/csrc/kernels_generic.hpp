@@ -41,6 +41,19 @@ __device__ __forceinline__ void gen_p(const PhiMaps<T>& ph, size_t gi, T t, T& p
   if (ph.pcx) { px = ph.pcx[gi]; py = ph.pcy[gi]; }
   else { T m11, m12, m22; flow_pm(t, ph.gx[gi], ph.gy[gi], ph.hxx[gi], ph.hyx[gi], ph.hyy[gi], px, py, m11, m12, m22); }
 }
+// Pointwise work of a flow stage done in the FETCH of the real-input y transform that consumes its result (each map element is
+// fetched exactly once), instead of in a launch of its own that writes a map the transform then reads back:
+//   mode 1: the value fetched is the next stage input f_{s+1} = RK4 update with k = p . grad f (== k_gen_vel_rk), y0 / acc updated on the way;
+//   mode 2: the same for the f part of a delta-flow stage, plus the per-stage products w = L(df) grad f (== the f half of k_gen_delta);
+//   mode 3: the pair (p_x L(df), p_y L(df)) (== the delta-f half of k_gen_delta), for the pair r2c.
+template <typename T> struct GenPro {
+  int mode;                          // 0 = plain fetch
+  PhiMaps<T> ph; RKCoef<T> rk;
+  const T *gx, *gy, *Ldf;
+  T *y0, *acc, *w1p, *w2p;
+  long npix; int P;
+};
+
 // One launch = `nseq` sequences per slice (blockIdx.y), S per workgroup.  Element n of sequence q of slice s is at
 // in[s*in_slice + q*in_seq + n*in_elem] (real T or cx<T>), likewise for the output.
 template <typename T> struct GenDft {
@@ -64,6 +77,7 @@ template <typename T> struct GenDft {
   // lmul_mid (mixed-radix kernel only): forward transform, multiply element k by i*lmul_mid[k], INVERSE transform, all in LDS -- the
   // d/dx pass of a stage in one launch (unnormalised: the caller's scale carries 1/N)
   const T* lmul_mid;
+  GenPro<T> pro;
 };
 
 
@@ -81,7 +95,21 @@ template <typename T>
 __device__ __forceinline__ cx<T> gen_fetch(const GenDft<T>& a, size_t sl, int seq, int n) {
   const size_t base = sl * a.in_slice + (size_t)seq * a.in_seq;
   cx<T> v;
-  if (a.in_real) {
+  if (a.in_real && a.pro.mode) {
+    const GenPro<T>& e = a.pro;
+    const size_t o = base + (size_t)n * a.in_elem, i = o - sl * (size_t)e.npix, pb = (size_t)(e.ph.Bphi == 1 ? 0 : sl / e.P) * e.npix;
+    T px, py; gen_p(e.ph, pb + i, e.rk.t, px, py);
+    if (e.mode == 3) { const T l = e.Ldf[o]; v = mk<T>(px * l, py * l); }
+    else {
+      const T ax = e.gx[o], ay = e.gy[o];
+      if (e.mode == 2) { const T l = e.Ldf[o]; e.w1p[o] = l * ax; e.w2p[o] = l * ay; }
+      const T k = px * ax + py * ay;
+      T y = e.y0[o], ac = e.rk.stage == 1 ? T(0) : e.acc[o];
+      const T nxt = rk_update(e.rk, k, y, ac);
+      if (e.rk.stage == 4) e.y0[o] = y; else e.acc[o] = ac;
+      v = mk<T>(nxt, T(0));
+    }
+  } else if (a.in_real) {
     v = mk<T>(reinterpret_cast<const T*>(a.in)[base + (size_t)n * a.in_elem], T(0));
     if (a.in2) v.y = reinterpret_cast<const T*>(a.in2)[base + (size_t)n * a.in_elem];
   } else if (!a.herm) v = reinterpret_cast<const cx<T>*>(a.in)[base + (size_t)n * a.in_elem];
