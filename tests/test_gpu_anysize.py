@@ -99,3 +99,32 @@ def test_largest_row_length_double_precision(camb):
     TP.test_lenseflow_gradient(camb, "f64", 32, 4096, 2, 1, 1, "fwd", 7)
     # (single precision stays on the fused kernels at this size; a 1 x 136 degree strip is not a single-precision parity case: its
     # lowest lx modes deflect by many pixels and the flow amplifies rounding to 1e-3, tools/gpu_size_probe.py)
+
+
+@pytest.mark.parametrize("Ny,Nx", [(96, 160), (51, 38)])
+def test_stage_fusions_equal_the_plain_pass_structure(camb, monkeypatch, Ny, Nx):
+    """The any-size stages in their three forms -- the reference's pass structure (CMBL_GEN_SEPARABLE=0), the separable form with the
+    d/dx pass as two launches and the pointwise work in its own kernels (CMBL_GEN_XDERIV_FUSED=0, CMBL_GEN_PROLOGUE=0), and the default
+    (one-launch d/dx pass, pointwise work in the fetch of the consuming transform) -- are the same computation: flows and gradient flow
+    agree to rounding in double precision.  (51 x 38 runs chirp-z transforms, which have no one-launch d/dx pass.)"""
+    C = _pkg()
+    P, n = 2, 7
+    proj, simf, simp = sims(camb, Ny, Nx, P, 1)
+    f, g, phi = simf(1), simf(11), simp(2)
+    p = C.ProjLambert(Ny, Nx, 2.0, torch.float64)
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+
+    def run():
+        L = C.LenseFlow(p, n)(F(phi, C.MAP))
+        Lf = L * F(f, C.MAP)
+        dp, df, f0 = L.gradient(C.FLOW_FWD, Lf, F(O.rfft2(g), C.FOURIER))
+        return [x.arr.cpu().numpy() for x in (Lf, L.adjoint * F(O.rfft2(g), C.FOURIER), dp, df, f0)]
+    ref = run()
+    for env in (dict(CMBL_GEN_SEPARABLE="0"), dict(CMBL_GEN_XDERIV_FUSED="0", CMBL_GEN_PROLOGUE="0"), dict(CMBL_GEN_PROLOGUE="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        for a, b in zip(got, ref):
+            assert rel(a, b) < 1e-12, env
