@@ -178,8 +178,8 @@ struct Ctx : CtxBase {
     for (int k = 0; k < Ny; ++k) { double a = -2.0 * M_PI * k / Ny; ty[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
     for (int k = 0; k < Nx; ++k) { double a = -2.0 * M_PI * k / Nx; tx[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
     upload(twY, ty); upload(twX, tx); upload(lx_r, lxr); upload(ly, lyv); upload(lam, lamv); upload(cos2F, c2F); upload(sin2F, s2F);
-    red_part.ensure(sizeof(double) * RED_BLOCKS * 64 * 2);
-    red_out.ensure(sizeof(double) * 64);
+    red_part.ensure(sizeof(double) * RED_BLOCKS * MAXBATCH * 2);
+    red_out.ensure(sizeof(double) * MAXBATCH);
     if (generic) { build_axis(genY, Ny); build_axis(genX, Nx); }
   }
 
@@ -505,7 +505,7 @@ struct Ctx : CtxBase {
   // ---- fused harmonic work (kernels_harm.hpp) -----------------------------------------------------------------------------
   // partial sums of the fused launches: region r of dot_part holds [B][nblk] doubles of one producer (PART_*), finished by its consumer
   enum PartRegion { PART_QF = 0, PART_QP, PART_QN, PART_CG_RZ, PART_CG_PAP, PART_COUNT };
-  static constexpr size_t PART_STRIDE = (size_t)64 * 2048;                 // doubles per region: B <= 64, blocks per slot <= 2048
+  static constexpr size_t PART_STRIDE = (size_t)MAXBATCH * 2048;           // doubles per region: B <= MAXBATCH, blocks per slot <= 2048
   DevBuf dot_part;
   ModeGeom<T> geom() const { return ModeGeom<T>{cos2F.as<T>(), sin2F.as<T>(), lam.as<T>(), plane(), Nx}; }
   double dot_scale() const { return 1.0 / ((double)Ny * Nx); }
@@ -518,7 +518,7 @@ struct Ctx : CtxBase {
   // launch left its partial sums (region `region`)
   template <int P, bool IN_F, typename PW> DotOut x_pw(const cx<T>* in, cx<T>* out_mixed, const PW& pw, int B, bool herm = false, int region = 0) {
     CMBL_REQUIRE(!generic, ERR_STATE, "fused row pass called on the any-size path");
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    CMBL_REQUIRE(B <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
     DotOut o{};
     dispatch_row([&](auto lgnx) {
       constexpr int LGNX = decltype(lgnx)::value, RPW = xpw_rpw<T>(LGNX, P);
@@ -533,7 +533,7 @@ struct Ctx : CtxBase {
   }
   int flat_blocks(int B) const { return (int)std::max<long>(1, std::min<long>((plane() + NTP - 1) / NTP, std::max(64, 1024 / B))); }
   template <typename PW> DotOut pw_flat(const PW& pw, int B, int region = 0) {
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    CMBL_REQUIRE(B <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
     const int nblk = flat_blocks(B);
     const DotOut o = dot_out(region, nblk, B);
     CMBL_LAUNCH(this, K_PWFLAT, (k_pw_flat<T, PW>), dim3((unsigned)nblk, (unsigned)B), 0, stream, pw, o, plane(), Nx, B);
@@ -566,7 +566,7 @@ struct Ctx : CtxBase {
   // reduce_dev: two launches, the B results land in `out_dev` (device doubles); nothing synchronises.  `sum_mode` selects the
   // accumulation (set_sum_accuracy_mode!, src/util.jl:288-316).
   template <typename F> void reduce_dev(const F& f, long n, int B, double scale, double* out_dev) {
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    CMBL_REQUIRE(B <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
     switch (sum_mode) {
 #define CMBL_X(M)                                                                                                                     \
       case M:                                                                                                                         \
@@ -792,7 +792,7 @@ struct Flow {
   }
   // get_max_lensing_step (src/lenseflow.jl:242-256); does not touch the flow's own phi cache
   void max_lensing_step(int basis, const void* phi, const void* eta, int nb, double* out_host) {
-    CMBL_REQUIRE(nb <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
+    CMBL_REQUIRE(nb <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
     const long np = c->npix();
     DevBuf &mp = mls_p, &me = mls_e, &pf = mls_f;                           // pooled: called once per line-search evaluation
     mp.ensure(sizeof(T) * 5 * nb * np); me.ensure(sizeof(T) * 5 * nb * np); pf.ensure(sizeof(cx<T>) * nb * c->plane());
@@ -1385,8 +1385,8 @@ struct Dataset {
     aps.ensure(sizeof(cx<T>) * n); best.ensure(sizeof(cx<T>) * n); bb.ensure(sizeof(cx<T>) * n); zs.ensure(sizeof(cx<T>) * n);
     cx<T>*x = xs.template as<cx<T>>(), *r = rs.template as<cx<T>>(), *p = ps.template as<cx<T>>(), *Y = zs.template as<cx<T>>();
     cx<T>*Ap = aps.template as<cx<T>>(), *bx = best.template as<cx<T>>(), *b = bb.template as<cx<T>>();
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
-    cg_scal.ensure(sizeof(double) * 7 * 64 + sizeof(int) * 8);
+    CMBL_REQUIRE(B <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
+    cg_scal.ensure(sizeof(double) * 7 * MAXBATCH + sizeof(int) * 8);
     cg_hist.ensure(sizeof(double) * (size_t)maxit * B);
     if (!cg_flag_host) {
       CMBL_HIP(hipHostMalloc((void**)&cg_flag_host, sizeof(int) * 16, hipHostMallocDefault));
@@ -1394,9 +1394,9 @@ struct Dataset {
     }
     CgScal st;
     double* sd = cg_scal.template as<double>();
-    st.res = sd; st.best = sd + 128;
+    st.res = sd; st.best = sd + 2 * MAXBATCH;
     st.hist = cg_hist.template as<double>();
-    int* si = reinterpret_cast<int*>(sd + 448);
+    int* si = reinterpret_cast<int*>(sd + 7 * MAXBATCH);
     st.done = si; st.better = si + 2; st.nan = si + 4; st.nh = si + 5;
     hipStream_t sm = c->stream;
     std::vector<double> one(B, 1.0), mone(B, -1.0);
@@ -1455,8 +1455,8 @@ struct Dataset {
     aps.ensure(sizeof(cx<T>) * n); best.ensure(sizeof(cx<T>) * n); bb.ensure(sizeof(cx<T>) * n);
     cx<T>*x = xs.template as<cx<T>>(), *r = rs.template as<cx<T>>(), *z = zs.template as<cx<T>>(), *p = ps.template as<cx<T>>();
     cx<T>*Ap = aps.template as<cx<T>>(), *bx = best.template as<cx<T>>(), *b = bb.template as<cx<T>>();
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
-    cg_scal.ensure(sizeof(double) * 6 * 64 + sizeof(int) * 8);
+    CMBL_REQUIRE(B <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
+    cg_scal.ensure(sizeof(double) * 6 * MAXBATCH + sizeof(int) * 8);
     cg_hist.ensure(sizeof(double) * (size_t)maxit * B);
     if (!cg_flag_host) {
       CMBL_HIP(hipHostMalloc((void**)&cg_flag_host, sizeof(int) * 16, hipHostMallocDefault));
@@ -1464,9 +1464,9 @@ struct Dataset {
     }
     CgState st;
     double* sd = cg_scal.template as<double>();
-    st.res = sd; st.pAp = sd + 64; st.res2 = sd + 128; st.alpha = sd + 192; st.beta = sd + 256; st.best = sd + 320;
+    st.res = sd; st.pAp = sd + MAXBATCH; st.res2 = sd + 2 * MAXBATCH; st.alpha = sd + 3 * MAXBATCH; st.beta = sd + 4 * MAXBATCH; st.best = sd + 5 * MAXBATCH;
     st.hist = cg_hist.template as<double>();
-    int* si = reinterpret_cast<int*>(sd + 384);
+    int* si = reinterpret_cast<int*>(sd + 6 * MAXBATCH);
     st.done = si; st.nan = si + 1; st.nh = si + 2; st.better = si + 3;
     hipStream_t sm = c->stream;
     const unsigned gx = (unsigned)std::min<long>((nr + NTP - 1) / NTP, 2048);
@@ -1535,8 +1535,8 @@ struct Dataset {
     mp2.ensure(sizeof(T) * sl * np);
     cx<T>*phi = phiF.template as<cx<T>>(), *f_h = fh.template as<cx<T>>(), *w = t3.template as<cx<T>>(), *cfif = t2.template as<cx<T>>();
     cx<T>* cpip = gphi.template as<cx<T>>();
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
-    qdev.ensure(sizeof(double) * 3 * 64);
+    CMBL_REQUIRE(B <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
+    qdev.ensure(sizeof(double) * 3 * MAXBATCH);
     double* qd = qdev.template as<double>();
     // phi = G \ phi° ; Cphi^-1 phi ; phi' Cphi^-1 phi
     DotOut parts[3];
@@ -1553,13 +1553,13 @@ struct Dataset {
     L.flow_map(mp2.template as<T>(), ftil.template as<T>(), P, B, false, true, true, &L.A);       // f~ = L f in ftil, rfft_y(f~) in A
     // z = M B L f - d ; z' Cn^-1 z ; w = -B'M'Cn^-1 z  (QU Fourier) with ifft_x(w) ready in L.H
     parts[2] = data_space(L, L.A.template as<cx<T>>(), d_h.template as<cx<T>>(), Bd, T(-1), w, gfo == nullptr, B);
-    double* const outs[3] = {qd, qd + 64, qd + 128};
+    double* const outs[3] = {qd, qd + MAXBATCH, qd + 2 * MAXBATCH};
     c->finish_parts(parts, outs, 3, B);
     auto finish_lp = [&]() {
-      double q[3 * 64];
-      CMBL_HIP(hipMemcpyAsync(q, qd, sizeof(double) * 3 * 64, hipMemcpyDeviceToHost, c->stream));
+      double q[3 * MAXBATCH];
+      CMBL_HIP(hipMemcpyAsync(q, qd, sizeof(double) * 3 * MAXBATCH, hipMemcpyDeviceToHost, c->stream));
       CMBL_HIP(hipStreamSynchronize(c->stream));
-      for (int i = 0; i < B; ++i) lp[i] = -0.5 * (q[i] + q[64 + i] + q[128 + i] + logdet_sum);
+      for (int i = 0; i < B; ++i) lp[i] = -0.5 * (q[i] + q[MAXBATCH + i] + q[2 * MAXBATCH + i] + logdet_sum);
     };
     if (!gfo) { finish_lp(); return; }
     // pullback through f~ = L f : delta flow t 1->0 from (f~, w, 0)
@@ -1597,22 +1597,22 @@ struct Dataset {
     c->lincomb1((T*)z, (const T*)z, (const T*)d_h.p, 1.0, -1.0, 2 * n / B, B);
     // quadratic forms: the three sets of B sums stay on the device and are read back ONCE, after everything else of this call has been
     // enqueued -- a read-back per term drained the stream three times in the middle of a gradient evaluation
-    CMBL_REQUIRE(B <= 64, ERR_ARG, "nbatch > 64 not supported in reductions");
-    qdev.ensure(sizeof(double) * 3 * 64);
+    CMBL_REQUIRE(B <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
+    qdev.ensure(sizeof(double) * 3 * MAXBATCH);
     double* qd = qdev.template as<double>();
-    apply(OP_CN_INV, z, w, B);                c->dot_F_dev(z, w, P, B, qd + 128);       // w = Cn^-1 z  (kept)
+    apply(OP_CN_INV, z, w, B);                c->dot_F_dev(z, w, P, B, qd + 2 * MAXBATCH);       // w = Cn^-1 z  (kept)
     cx<T>* cfif = t2.template as<cx<T>>(); t2.ensure(sizeof(cx<T>) * n); cfif = t2.template as<cx<T>>();
     apply(OP_CF_INV, f_h, cfif, B);           c->dot_F_dev(f_h, cfif, P, B, qd);
     cx<T>* cpip = gphi.template as<cx<T>>();
     apply(OP_CPHI_INV, phi, cpip, B, false, false, false, nullptr, 0, 1, 1);
-    c->dot_F_dev(phi, cpip, 1, B, qd + 64);
+    c->dot_F_dev(phi, cpip, 1, B, qd + MAXBATCH);
     // A NaN logpdf is a VALUE, not an error: MAP_joint's line search penalises it (src/maximization.jl:194-199) and hmc_step
     // rejects the proposal (log(rand()) < NaN is false, src/sampling.jl:414), so it must reach the caller.
     auto finish_lp = [&]() {
-      double q[3 * 64];
-      CMBL_HIP(hipMemcpyAsync(q, qd, sizeof(double) * 3 * 64, hipMemcpyDeviceToHost, c->stream));
+      double q[3 * MAXBATCH];
+      CMBL_HIP(hipMemcpyAsync(q, qd, sizeof(double) * 3 * MAXBATCH, hipMemcpyDeviceToHost, c->stream));
       CMBL_HIP(hipStreamSynchronize(c->stream));
-      for (int i = 0; i < B; ++i) lp[i] = -0.5 * (q[i] + q[64 + i] + q[128 + i] + logdet_sum);
+      for (int i = 0; i < B; ++i) lp[i] = -0.5 * (q[i] + q[MAXBATCH + i] + q[2 * MAXBATCH + i] + logdet_sum);
     };
     if (!gfo) { finish_lp(); return; }
     // d/df~ = -B'M'Cn^-1 z  -> QU Fourier

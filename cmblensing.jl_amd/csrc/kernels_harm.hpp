@@ -255,7 +255,7 @@ template <typename T> struct PwPhiGrad {
 // The state (res, best, done, better) is double-buffered by iteration parity: block (0, 0) of PwCgP writes the next parity while the
 // other blocks still read the current one.  `done` latches; from then on the launches change nothing.
 struct CgScal {
-  double *res, *best;                          // [2][64] (parity)
+  double *res, *best;                          // [2][MAXBATCH] (parity)
   double* hist;                                // [maxit][B]
   int *done, *better;                          // [2] (parity)
   int *nan, *nh;
@@ -288,7 +288,7 @@ template <typename T, int P> struct PwCgXr {
   DotOut pAp; double scale;                    // PwCgAp's partials
   __device__ __forceinline__ Local prologue(int b, int B, double* scratch) const {
     const double v = sum_partials<T, NTP>(pAp.part + (size_t)b * pAp.nblk, pAp.nblk, scale, pAp.mode, scratch);
-    return Local{(T)(s.res[par * 64 + b] / v), s.done[par]};
+    return Local{(T)(s.res[par * MAXBATCH + b] / v), s.done[par]};
   }
   __device__ __forceinline__ void operator()(const Local& l, int b, long i, int ky, SumAccRt<T>* acc, int mode) const {
     if (l.done) return;
@@ -316,7 +316,7 @@ template <typename T, int P> struct PwCgP {
     const int nx = par ^ 1;
     const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     if (s.done[par]) {                         // latched: carry the state over, change nothing
-      if (writer) { s.done[nx] = 1; s.better[nx] = 0; for (int bb = 0; bb < B; ++bb) { s.res[nx * 64 + bb] = s.res[par * 64 + bb]; s.best[nx * 64 + bb] = s.best[par * 64 + bb]; } }
+      if (writer) { s.done[nx] = 1; s.better[nx] = 0; for (int bb = 0; bb < B; ++bb) { s.res[nx * MAXBATCH + bb] = s.res[par * MAXBATCH + bb]; s.best[nx * MAXBATCH + bb] = s.best[par * MAXBATCH + bb]; } }
       return Local{T(0), 1, 0};
     }
     int better = 1, done = 1, nanf = 0;
@@ -324,15 +324,15 @@ template <typename T, int P> struct PwCgP {
     for (int bb = 0; bb < B; ++bb) {           // every block needs `better`, which looks at all batch slots (:111)
       const double r2 = sum_partials<T, NTP>(rz.part + (size_t)bb * rz.nblk, rz.nblk, scale, rz.mode, scratch);
       nanf |= isnan(r2);
-      better &= (r2 < s.best[par * 64 + bb]); done &= (r2 < tol);
+      better &= (r2 < s.best[par * MAXBATCH + bb]); done &= (r2 < tol);
       if (bb == b) mine = r2;
-      if (writer) { s.res[nx * 64 + bb] = r2; s.hist[(long)(*s.nh) * B + bb] = r2; }
+      if (writer) { s.res[nx * MAXBATCH + bb] = r2; s.hist[(long)(*s.nh) * B + bb] = r2; }
     }
     if (writer) {
-      for (int bb = 0; bb < B; ++bb) s.best[nx * 64 + bb] = better ? s.res[nx * 64 + bb] : s.best[par * 64 + bb];
+      for (int bb = 0; bb < B; ++bb) s.best[nx * MAXBATCH + bb] = better ? s.res[nx * MAXBATCH + bb] : s.best[par * MAXBATCH + bb];
       *s.nh += 1; s.better[nx] = better; *s.nan |= nanf; s.done[nx] = done || nanf;
     }
-    return Local{(T)(mine / s.res[par * 64 + b]), 0, better};
+    return Local{(T)(mine / s.res[par * MAXBATCH + b]), 0, better};
   }
   __device__ __forceinline__ void operator()(const Local& l, int b, long i, int, SumAccRt<T>*, int) const {
     if (l.skip) return;

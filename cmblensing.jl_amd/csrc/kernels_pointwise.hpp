@@ -6,6 +6,7 @@
 namespace cmbl {
 
 constexpr int MAXB = 16;                       // per-batch scalars are passed by value in chunks of MAXB
+constexpr int MAXBATCH = 256;                  // most batch slots (chains per GPU) a reduction / CG / posterior call takes: sizes the per-slot scalar buffers
 template <typename T> struct BScal { T v[MAXB]; };
 
 // ---------------------------------------------------------------------------------------------

@@ -18,6 +18,8 @@
  *   - Ny, Nx: any integers in [2, 4096], like the reference's FFTW plans (src/util_fft.jl:32-35).  Powers of two >= 32 on both
  *     sides run the fused kernels; other sizes the any-size path (mixed-radix / chirp-z transforms, csrc/kernels_generic.hpp),
  *     same results, ~5x slower per pixel.  Sides above 4096 return CMBL_ERR_SHAPE.
+ *   - nbatch (chains / simulations as batch slots of one call): up to 256 per call for the entry points that return per-slot scalars
+ *     (reductions, cmbl_wiener_cg, cmbl_logpdf_mixed, cmbl_grad_logpdf_mixed); more return CMBL_ERR_ARG.  The flows have no such limit.
  *   - a handle is used by one host thread at a time; different contexts are independent.
  *   - calls are asynchronous on the context's stream unless they return host values (`*_host` outputs), i.e. every
  *     field-to-field entry point is already the `_async` form; cmbl_ctx_synchronize() waits for the stream.

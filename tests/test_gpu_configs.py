@@ -221,3 +221,31 @@ def test_config5_2048_QU_f64_n10_and_qe():
     m = (ods.Cphi > 0) & (so["proj"].lmag < 2500)
     np.testing.assert_allclose(got["AL"][m], AL[m], rtol=1e-7)
     assert rel(got["phiqe"].arr.cpu().numpy()[..., m], pq_o[..., m]) < 1e-7
+
+
+def test_more_than_64_batch_slots():
+    """80 chains as batch slots in one call (the per-slot scalar buffers of reductions, CG and posterior hold MAXBATCH = 256): slots 0, 1
+    equal the same two slots of a 2-chain dataset (the generator fills slot-major, so their draws coincide); 257 slots are refused."""
+    import torch
+    import cmblensing_jl_amd as C
+    from bench import synthetic_cls
+    kw = dict(T=torch.float64, beam_fwhm=2.0, pixel_mask=dict(pad_deg=0.2, apod_deg=0.2), Nphi="flat")
+    big = C.load_sim(3.0, (32, 64), "P", synthetic_cls(), Nbatch=80, **kw)
+    two = C.load_sim(3.0, (32, 64), "P", synthetic_cls(), Nbatch=2, **kw)
+    out = []
+    for s in (big, two):
+        ds = s["ds"]
+        fo, po = ds.mix(s["f"], s["phi"])
+        lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
+        fw, hist = ds.argmaxf_logpdf(s["phi"], tol=0.0, nsteps=6)
+        out.append((np.asarray(lp), gf.arr.cpu().numpy(), gp.arr.cpu().numpy(), fw.arr.cpu().numpy(), np.array([h[1] for h in hist]), ds.proj.dot(fo.arr, fo.arr, C.MAP)))
+    b, t = out
+    assert len(b[0]) == 80 and np.all(np.isfinite(b[0]))
+    np.testing.assert_allclose(b[0][:2], t[0], rtol=1e-11)
+    for k in (1, 2, 3):
+        np.testing.assert_allclose(b[k][:2], t[k], rtol=0, atol=1e-10 * np.abs(t[k]).max())
+    np.testing.assert_allclose(b[4][:, :2], t[4], rtol=1e-9)
+    np.testing.assert_allclose(b[5][:2], t[5], rtol=1e-12)
+    p = big["proj"]
+    with pytest.raises(C.CmblError):
+        p.dot(torch.zeros(257, 1, 64, 32, dtype=torch.float64, device="cuda"), torch.zeros(257, 1, 64, 32, dtype=torch.float64, device="cuda"), C.MAP)
