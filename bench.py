@@ -123,22 +123,51 @@ def profiler_mean_us(kernel, N, P, B, dtype):
     return None, None
 
 
-def cpu_baseline(N, pol, nsteps, npT=np.float32):
-    """The NumPy oracle (kind 'port': the Julia reference cannot run here) timed on the host cores: one ∇lnP
-    evaluation of the same workload (bounded sample)."""
+def cpu_baseline(N, pol, nsteps, npT=np.float32, dev=None):
+    """The NumPy oracle (kind 'port': the Julia reference cannot run here) on the host cores: one ∇lnP evaluation of the same
+    workload (bounded sample), timed in the workload's precision.  With `dev` (the device's own inputs and outputs of the timed step,
+    as host arrays) the FLOAT64 oracle is also evaluated on exactly those fp32/fp64-rounded inputs and the HIP results are compared with
+    it: `parity_at_config` -- the parity statement at the headline size, where the GPU tests' oracle comparisons used to stop at 512².
+    Returns (cpu_baseline, parity_at_config | None)."""
     import oracle as O
-    t0 = time.time()
-    so = O.load_sim(2.0, N, pol, npT, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=nsteps)
-    ds = so["ds"]
-    fo, po = ds.mix(so["f"], so["phi"])
-    t_setup = time.time() - t0
-    t0 = time.time()
-    ds._L = None
-    lp, gf, gp = ds.grad_logpdf_mixed(fo, po)
-    dt = time.time() - t0
-    return dict(value=1.0 / dt, unit="steps/s", cores=int(os.environ.get("CMBL_ORACLE_FFT_WORKERS", os.cpu_count() or 1)),
+    rel = lambda a, b: float(np.linalg.norm((np.asarray(a) - b).ravel()) / np.linalg.norm(np.asarray(b).ravel()))
+    pm = dict(pad_deg=1.0, apod_deg=1.0)
+
+    def one(T, inputs=None):
+        t0 = time.time()
+        so = O.load_sim(2.0, N, pol, T, pixel_mask=pm, nsteps=nsteps)
+        ds = so["ds"]
+        if inputs is None:
+            fo, po = ds.mix(so["f"], so["phi"])
+            quirk = False
+        else:
+            ds.d = inputs["d"].astype(np.complex128)
+            fo, po, quirk = inputs["fo"].astype(np.float64), inputs["po"].astype(np.complex128), inputs["alias_quirk"]
+        t_setup = time.time() - t0
+        t0 = time.time()
+        ds._L = None
+        res = ds.grad_logpdf_mixed(fo, po, alias_quirk=quirk)
+        return res, time.time() - t0, t_setup
+
+    parity = None
+    if dev is not None and npT == np.float64:
+        (lp, gf, gp), dt, t_setup = one(np.float64, dev)               # one evaluation serves both legs
+    else:
+        _, dt, t_setup = one(npT)
+        if dev is not None:
+            (lp, gf, gp), dt64, _ = one(np.float64, dev)
+    if dev is not None:
+        parity = {"logpdf_rel": float(np.max(np.abs((np.asarray(dev["lp"]) - lp) / lp))), "gf_rel_l2": rel(dev["gf"], gf), "gphi_rel_l2": rel(dev["gp"], gp),
+                  "logpdf_hip": [float(x) for x in np.atleast_1d(dev["lp"])], "logpdf_oracle": [float(x) for x in np.atleast_1d(lp)],
+                  "alias_quirk": bool(dev["alias_quirk"]), "sum_mode": dev["sum_mode"],
+                  "oracle": "float64 NumPy/SciPy oracle (oracle/dataset.py grad_logpdf_mixed) on the device's own rounded f°, ϕ°, d; operators "
+                            "rebuilt from the same spectra / seeds in float64",
+                  "tolerance": {"f32": "logpdf 2e-5, ∇f° 6e-5, ∇ϕ° 2e-4 (tests/test_gpu_headline_parity.py)", "f64": "1e-10 / 1e-9 / 1e-9"}[
+                      "f32" if dev["fo"].dtype == np.float32 else "f64"]}
+    base = dict(value=1.0 / dt, unit="steps/s", cores=int(os.environ.get("CMBL_ORACLE_FFT_WORKERS", os.cpu_count() or 1)),
                 kind="port", sample=f"1 ∇logpdf(Mixed) evaluation, {N}² {pol} {np.dtype(npT).name}, n={nsteps}, NumPy/SciPy-pocketfft oracle "
                 f"({dt:.2f} s; setup {t_setup:.1f} s not counted)")
+    return base, parity
 
 
 CONFIGS = {2: dict(nside=512, pol="P", dtype="f32", nrk=7), 3: dict(nside=1024, pol="IP", dtype="f32", nrk=7),
@@ -221,6 +250,50 @@ def config_extras(C, torch, cfg, sim, timeit):
     return ex
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch_command(args, argv, env):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): the command that starts the N ranks, one
+    process per GPU, on this node -- or None when this process is already a rank (or N = 1).  The reference needs no external
+    launcher either: `sample_joint` / `MAP_marg` `pmap` over the workers the session holds, one GPU each
+    (src/sampling.jl:266,292, src/util_parallel.jl:73-102)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env:
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def assign_devices(world, ndev, backend):
+    """rank -> device index: one GPU per rank, each GPU used once (src/util_parallel.jl:73-102 assigns a unique GPU per worker and
+    errors otherwise).  Only the `gloo` backend -- a test aid for boxes with fewer GPUs than ranks -- may share devices."""
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if backend != "gloo" and ndev < world:
+        raise SystemExit(f"--gpus {world} but only {ndev} GPU(s) visible: one rank per GPU (use --dist-backend gloo to share devices in tests)")
+    return [r % ndev for r in range(world)]
+
+
+def clock_ramp(step, sync, block=5, tol=0.01, max_blocks=60):
+    """Untimed spin before the warm-up steps: blocks of `block` steps until two consecutive blocks agree to `tol` (the chip's clocks
+    ramp over the first ~0.1-0.3 s of work: a cold K = 20 run read 8 % low in round 3).  Returns (steps spun, last block ms/step)."""
+    prev, n = None, 0
+    for _ in range(max_blocks):
+        sync(); t0 = time.perf_counter()
+        for _ in range(block):
+            step()
+        sync(); cur = (time.perf_counter() - t0) / block
+        n += block
+        if prev is not None and abs(cur - prev) <= tol * prev:
+            break
+        prev = cur
+    return n, cur * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,10 +311,18 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets the N>1 logic be exercised on a box with fewer GPUs than ranks")
+    ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp spin before the warm-up steps")
     args = ap.parse_args()
     if args.config:
         for k, v in CONFIGS[args.config].items():
             setattr(args, k, v)
+    cmd = self_launch_command(args, sys.argv[1:], os.environ)
+    if cmd is not None:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU), like the reference's own
+        # `pmap` over workers (src/sampling.jl:266,292), and rank 0's JSON line passes through on stdout
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import cmblensing_jl_amd as C
@@ -251,20 +332,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = None
     rccl = None
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local = assign_devices(world, ndev, args.dist_backend)[local]
     if world > 1 or os.environ.get("CMBL_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         if args.dist_backend == "gloo":
-            local = local % max(torch.cuda.device_count(), 1)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     cdev = "cpu" if args.dist_backend == "gloo" else "cuda"          # where the (tiny) collective payloads live
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     N, pol, B, nrk = args.nside, args.pol, args.nbatch, args.nrk
     P = {"I": 1, "P": 2, "IP": 3}[pol]
@@ -297,6 +378,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ramp_steps, ramp_ms = (0, None) if args.no_ramp else clock_ramp(step, torch.cuda.synchronize)
     for _ in range(args.warmup):
         lp, gf, gp = step()
     barrier()
@@ -334,7 +416,12 @@ def main():
         "config": {"workload": f"{N}² flat-sky {pol} (npol={P}), θpix=2′, ∇logpdf(Mixed(ds)) step = precompute + L\\f° + L·f + 2 δ-flows "
                                f"+ diag/mask/reductions; 1° apodised border mask, LowPass(3000), 3 μK′ noise"
                                + (f" [BASELINE.json configs[{args.config - 1}]]" if args.config else ""),
-                   "nside": N, "npol": P, "chains_per_gpu": B, "rk4_steps": nrk, "parallelism": f"{world} independent chains (no data-path collective)"},
+                   "nside": N, "npol": P, "chains_per_gpu": B, "rk4_steps": nrk, "parallelism": f"{world} independent chains (no data-path collective)",
+                   # the arithmetic that was timed: CMBL_REFERENCE_EXACT=1 switches both to the reference's
+                   "alias_quirk": bool(ds.alias_quirk), "sum_accuracy_mode": "working" if C.reference_exact() else "float64",
+                   "reference_exact": bool(C.reference_exact())},
+        "clock_ramp": {"untimed_steps": ramp_steps, "last_block_ms_per_step": ramp_ms,
+                       "note": "untimed spin before the W warm-up steps, until two consecutive 5-step blocks agree to 1 %"},
         "logpdf": [float(x) for x in lps],
     }
     if rccl is not None:
@@ -403,7 +490,15 @@ def main():
                 ex["grad_lnP_IP_note"] = f"{N}² T+QU (BASELINE configs[2] workload, the north_star target): ∇logpdf(Mixed) step, mean of 20"
             out["extras"] = ex
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, pol, nrk, npT)
+        dev = None
+        if B == 1:
+            lp, gf, gp = step()
+            host = lambda t: t.detach().cpu().numpy()
+            dev = dict(fo=host(fo.arr), po=host(po.arr), d=host(sim["d"].arr), lp=np.asarray(lp), gf=host(gf.arr), gp=host(gp.arr),
+                       alias_quirk=bool(ds.alias_quirk), sum_mode="working" if C.reference_exact() else "float64")
+        out["cpu_baseline"], par = cpu_baseline(N, pol, nrk, npT, dev)
+        if par is not None:
+            out["parity_at_config"] = par
     if rank == 0:
         print(json.dumps(out, ensure_ascii=False))
     if dist is not None:

@@ -1,0 +1,59 @@
+"""`python bench.py --gpus N` launches its own N ranks (no torchrun around it): the re-exec logic on the CPU, and end to end -- the
+ranks start, find no GPU here and say so (the product path has no CPU fallback).  The reference needs no external launcher either
+(src/sampling.jl:266,292: `pmap` over workers, one GPU each: src/util_parallel.jl:73-102)."""
+import argparse
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+
+def test_self_launch_command():
+    a = argparse.Namespace(gpus=1)
+    assert bench.self_launch_command(a, ["--gpus", "1"], {}) is None                         # N = 1: this process is the job
+    a = argparse.Namespace(gpus=4)
+    assert bench.self_launch_command(a, ["--gpus", "4"], {"WORLD_SIZE": "4", "RANK": "0"}) is None     # already a rank
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    cmd = bench.self_launch_command(a, argv, {})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                                                               # the user's flags reach every rank unchanged
+
+
+def test_one_gpu_per_rank():
+    assert bench.assign_devices(8, 8, "nccl") == list(range(8))
+    assert bench.assign_devices(2, 8, "nccl") == [0, 1]
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench.assign_devices(2, 1, "nccl")                                                   # fewer GPUs than ranks: loud, not shared
+    assert bench.assign_devices(4, 1, "gloo") == [0, 0, 0, 0]                                # the test aid may share
+    with pytest.raises(SystemExit, match="needs a GPU"):
+        bench.assign_devices(1, 0, "nccl")
+
+
+def test_clock_ramp_stops_when_blocks_agree():
+    import time
+    dur = iter([0.004, 0.004, 0.003, 0.002] + [0.001] * 100)
+    cur = [None]
+    n_steps = [0]
+    def step():
+        if n_steps[0] % 5 == 0:
+            cur[0] = next(dur)
+        n_steps[0] += 1
+        time.sleep(cur[0])
+    n, ms = bench.clock_ramp(step, lambda: None, tol=0.2)
+    assert n == n_steps[0] and 10 <= n <= 40 and n % 5 == 0
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="CPU-only check: with a GPU the ranks would run the benchmark")
+def test_plain_python_bench_gpus_2_starts_two_ranks():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0", "--nside", "64"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-3000:]                     # both ranks ran main() and failed loudly

@@ -12,6 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def torch_device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
 def _run(nproc, script_args, port, env=None, timeout=1200):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args
@@ -29,10 +34,15 @@ def test_map_marg_and_chains_2_ranks():
 
 
 def test_bench_two_ranks_prints_one_line_consistent_with_one_rank():
-    """bench.py --gpus 2 under torch.distributed.run: ONE JSON line from rank 0, n_gpus = 2, value = 2 chains' worth of steps over the
-    max-over-ranks time; the --gpus 1 line has the same keys (SCALE and BENCH records agree in form)."""
+    """PLAIN `python bench.py --gpus 2` (no torchrun around it -- the form the driver uses; bench.py starts its own two ranks): ONE JSON
+    line from rank 0, n_gpus = 2, value = 2 chains' worth of steps over the max-over-ranks time; the --gpus 1 line has the same keys
+    (SCALE and BENCH records agree in form).  The same command under torch.distributed.run gives the same line."""
     common = ["--steps", "5", "--warmup", "1", "--nside", "256", "--no-cpu-baseline", "--no-roofline"]
-    r2 = _run(2, ["bench.py", "--gpus", "2", "--dist-backend", "gloo"] + common, 29543)
+    r2 = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dist-backend", "gloo"] + common, cwd=ROOT, capture_output=True, text=True,
+                        timeout=1200, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    r2t = _run(2, ["bench.py", "--gpus", "2", "--dist-backend", "gloo"] + common, 29543)
+    lt = [l for l in r2t.stdout.splitlines() if l.startswith("{")]
+    assert r2t.returncode == 0 and len(lt) == 1 and json.loads(lt[0])["n_gpus"] == 2, r2t.stdout[-2000:] + r2t.stderr[-2000:]
     lines = [l for l in r2.stdout.splitlines() if l.startswith("{")]
     assert r2.returncode == 0 and len(lines) == 1, r2.stdout[-2000:] + r2.stderr[-2000:]
     d2 = json.loads(lines[0])
@@ -41,6 +51,10 @@ def test_bench_two_ranks_prints_one_line_consistent_with_one_rank():
     # the N > 1 line additionally reports who took part in the collective (backend, world size, device of every rank)
     assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and set(d1) == set(d2) - {"collective"} and len(d2["logpdf"]) == 2
     assert d2["collective"]["world_size"] == 2 and [r["rank"] for r in d2["collective"]["ranks"]] == [0, 1]
+    # without the gloo test aid two ranks on a one-GPU box are refused loudly (one rank per GPU, src/util_parallel.jl:73-102)
+    if torch_device_count() == 1:
+        bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert bad.returncode != 0 and "only 1 GPU" in bad.stderr, bad.stderr[-2000:]
     assert d2["scaling"] == "weak" and d2["metric"] == d1["metric"] and d2["config"]["nside"] == 256
     assert abs(d2["value"] - 2 * 5 / (d2["ms_per_step"] * 5e-3)) < 1e-6 * d2["value"]
 

@@ -12,15 +12,10 @@ mkdir -p "$out"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ngpu=$(python -c "import torch; print(torch.cuda.device_count())")
 echo "visible GPUs: $ngpu" | tee "$out/scale_summary.txt"
-port=29600
 for n in 1 2 4 8; do
   [ "$n" -gt "$ngpu" ] && { echo "N=$n skipped (only $ngpu GPUs)" | tee -a "$out/scale_summary.txt"; continue; }
-  if [ "$n" -eq 1 ]; then
-    python bench.py --gpus 1 --steps "$steps" --warmup "$warm" --no-cpu-baseline > "$out/scale_N1.json" 2> "$out/scale_N1.err"
-  else
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port $((port + n)) \
-      bench.py --gpus "$n" --steps "$steps" --warmup "$warm" > "$out/scale_N$n.json" 2> "$out/scale_N$n.err"
-  fi
+  # plain calls: bench.py starts its own N ranks (one per GPU) when no launcher is around it
+  python bench.py --gpus "$n" --steps "$steps" --warmup "$warm" --no-cpu-baseline > "$out/scale_N$n.json" 2> "$out/scale_N$n.err"
   python - "$out/scale_N$n.json" <<'PY' | tee -a "$out/scale_summary.txt"
 import json, sys
 line = [l for l in open(sys.argv[1]) if l.startswith("{")]
