@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from _tol import _record, scalars_close
 from oracle.lenseflow import LenseFlow as OLF
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -14,8 +15,9 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def check_sample(z, key, arr, rtol):
     flat = np.asarray(arr).ravel()
     idx, val, l2 = z[f"{key}.idx"], z[f"{key}.val"], z[f"{key}.l2"]
-    err = np.linalg.norm(flat[idx] - val) / np.linalg.norm(val)
-    assert err < rtol, (key, err)
+    err = float(np.linalg.norm(flat[idx] - val) / np.linalg.norm(val))
+    _record("golden " + key, err, rtol)
+    assert err < rtol, f"{key}: relative L2 error on the golden sample {err:.3e} >= tolerance {rtol:.1e}"
     assert abs(np.sqrt(np.sum(np.abs(flat) ** 2)) - l2) < 10 * rtol * l2, key
 
 
@@ -95,9 +97,9 @@ def test_gpu_reproduces_golden_posterior(prec, pol, Nside):
     check_sample(z, "d", s["d"].arr.cpu().numpy(), tol)
     fo, po = ds.mix(s["f"], s["phi"])
     lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
-    np.testing.assert_allclose(lp, z["logpdf_mixed"], rtol=5e-5 if prec == "f32" else 1e-9)
+    scalars_close("golden logpdf_mixed", lp, z["logpdf_mixed"], rtol=5e-5 if prec == "f32" else 1e-9)
     check_sample(z, "grad_fo", gf.arr.cpu().numpy(), 2e-3 if prec == "f32" else 1e-8)
     check_sample(z, "grad_phio", gp.arr.cpu().numpy(), 5e-3 if prec == "f32" else 1e-8)
     fw, hist = ds.argmaxf_logpdf(s["phi"], tol=0.0, nsteps=8)
-    np.testing.assert_allclose([h[1][0] for h in hist], z["cg_res"], rtol=5e-3 if prec == "f32" else 1e-7)
+    scalars_close("golden cg_res", [h[1][0] for h in hist], z["cg_res"], rtol=5e-3 if prec == "f32" else 1e-7)
     check_sample(z, "cg_f", fw.arr.cpu().numpy(), 2e-3 if prec == "f32" else 1e-8)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 import oracle as O
 import test_gpu_parity as TP
-from test_gpu_parity import rel, DT, TOL, sims, _pkg
+from test_gpu_parity import rel, DT, TOL, sims, _pkg, close, scalars_close
 
 
 @pytest.fixture(scope="module")
@@ -89,7 +89,7 @@ def test_anysize_path_equals_fused_path(camb, prec):
                                                 gdp.arr, gdf.arr, gf0.arr)]
     tol = TOL[prec]["flow"] if prec == "f32" else 1e-11            # fp32: each side is within 5e-5 of the float64 oracle
     for name, a, b in zip(("rfft", "L*f", "L\\f", "L'g", "dphi", "df", "f0"), res["0"], res["1"]):
-        assert rel(a, b) < tol * (10 if name == "dphi" else 1), (name, rel(a, b))
+        close(name, a, b, tol * (10 if name == "dphi" else 1))
 
 
 def test_largest_row_length_double_precision(camb):
@@ -127,4 +127,4 @@ def test_stage_fusions_equal_the_plain_pass_structure(camb, monkeypatch, Ny, Nx)
         for k in env:
             monkeypatch.delenv(k)
         for a, b in zip(got, ref):
-            assert rel(a, b) < 1e-12, env
+            close(env, a, b, 1e-12)

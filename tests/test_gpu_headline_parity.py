@@ -1,0 +1,68 @@
+"""HIP path against the oracle AT the headline and north-star sizes (oracle comparisons used to stop at 512²).
+
+    ∇logpdf(Mixed)            1024² QU fp32   (bench.py's headline step; BASELINE `metric`)        vs float64 oracle on the rounded inputs
+    ∇logpdf(Mixed)            1024² T+QU fp32 (BASELINE configs[2], the north_star target)          "
+    L*f and its pullback      2048² QU fp64, n = 10 (BASELINE configs[4])                           vs float64 oracle, 1e-10 class
+
+Large-size-only bugs (32-bit offsets, the 448 MB product scratch, tile caches, slice streams) are invisible to <= 512² parity.  The
+oracle takes 10-60 s per case on the GPU box's host cores.  Follows src/dataset.jl:84-117 (logpdf of Mixed), src/flowops.jl:40-53
+(the pullback of L*f)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as O
+from oracle.lenseflow import LenseFlow as OLenseFlow
+from _tol import close, scalars_close
+from bench import synthetic_cls
+
+# fp32 tolerances = 3 x the largest error measured on MI355X at these sizes (profiles/r04_parity_measured.txt)
+TOL_LP, TOL_GF, TOL_GP = 2e-5, 6e-5, 2e-4
+
+
+@pytest.mark.parametrize("pol", ["P", "IP"])
+def test_grad_logpdf_mixed_1024_fp32_vs_oracle(pol):
+    import cmblensing_jl_amd as C
+    pm = dict(pad_deg=1.0, apod_deg=1.0)
+    sd = C.load_sim(2.0, 1024, pol, synthetic_cls(), T=torch.float32, pixel_mask=pm, nsteps=7)          # exactly bench.py's workload
+    ds = sd["ds"]
+    fo, po = ds.mix(sd["f"], sd["phi"])
+    lp2 = ds.logpdf_mixed(fo, po)
+    so = O.load_sim(2.0, 1024, pol, np.float64, pixel_mask=pm, nsteps=7)
+    ods = so["ds"]
+    ods.d = sd["d"].arr.cpu().numpy().astype(np.complex128)                                            # the device's own rounded inputs
+    for quirk in (False, True):                                                                        # both settings of DESIGN.md Q1
+        lp, gf, gp = ds.gradient_logpdf_mixed(fo, po, alias_quirk=quirk)
+        olp, ogf, ogp = ods.grad_logpdf_mixed(fo.arr.cpu().numpy().astype(np.float64), po.arr.cpu().numpy().astype(np.complex128), alias_quirk=quirk)
+        scalars_close(f"logpdf(Mixed) 1024² {pol}", lp, olp, rtol=TOL_LP)
+        scalars_close(f"logpdf(Mixed) 1024² {pol}, logpdf-only call", lp2, olp, rtol=TOL_LP)
+        close(f"∇f° 1024² {pol} quirk={quirk}", gf.arr.cpu().numpy(), ogf, TOL_GF)
+        close(f"∇ϕ° 1024² {pol} quirk={quirk}", gp.arr.cpu().numpy(), ogp, TOL_GP)
+
+
+def test_lenseflow_and_pullback_2048_fp64_n10_vs_oracle():
+    import cmblensing_jl_amd as C
+    N, n = 2048, 10
+    oproj = O.Proj(N, N, 2.0, np.float64)
+    cl = O.load_camb()["unlensed_total"]
+    Cphi = O.cl_to_2d(cl["pp"], oproj)
+    Cf = np.stack([O.cl_to_2d(cl["EE"], oproj), O.cl_to_2d(cl["BB"], oproj) + 0.05 * O.cl_to_2d(cl["EE"], oproj)])
+    f = O.from_harm(oproj, np.sqrt(Cf) * O.rfft2(O.white_noise(1, (1, 2, N, N), np.float64)))
+    g = O.from_harm(oproj, np.sqrt(Cf) * O.rfft2(O.white_noise(4, (1, 2, N, N), np.float64)))
+    phi = O.irfft2(np.sqrt(Cphi) * O.rfft2(O.white_noise(2, (1, 1, N, N), np.float64)), N)
+    OL = OLenseFlow(oproj, phi, n)
+    p = C.ProjLambert(N, N, 2.0, torch.float64)
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    L = C.LenseFlow(p, n)(F(phi, C.MAP))
+    want = OL.apply(f)
+    got = L * F(f, C.MAP)
+    close("L*f 2048² QU fp64 n=10", got.arr.cpu().numpy(), want, 1e-11)
+    gl = O.rfft2(g)
+    close("L'g 2048² QU fp64 n=10", (L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy(), OL.adj(gl), 1e-11)
+    f0, df, dp = OL.grad_apply(want, gl)
+    gdp, gdf, gf0 = L.gradient(C.FLOW_FWD, F(want, C.MAP), F(gl, C.FOURIER), alias_quirk=False)
+    close("pullback f 2048²", gf0.arr.cpu().numpy(), f0, 1e-11)
+    close("pullback δf 2048²", gdf.arr.cpu().numpy(), df, 1e-11)
+    close("pullback δϕ 2048²", gdp.arr.cpu().numpy(), dp, 1e-10)

@@ -19,9 +19,7 @@ def _pkg():
     return C
 
 
-def rel(a, b):
-    a, b = np.asarray(a), np.asarray(b)
-    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+from _tol import close, rel, scalars_close            # assertions that log what they measured (tests/_tol.py)
 
 
 DT = {"f32": (torch.float32, np.float32), "f64": (torch.float64, np.float64)}
@@ -66,21 +64,21 @@ def test_geometry_and_basis_transforms(prec, Ny, Nx):
         m = rng.standard_normal((B, P, Nx, Ny)).astype(nT)
         fl = p.rfft(p.tensor(m))
         ref = O.rfft2(m.astype(np.float64))
-        assert rel(fl.cpu().numpy(), ref) < TOL[prec]["fft"], ("rfft", P, B)
+        close(("rfft", P, B), fl.cpu().numpy(), ref, TOL[prec]["fft"])
         back = p.irfft(fl)
-        assert rel(back.cpu().numpy(), m) < TOL[prec]["fft"], ("irfft∘rfft", P, B)
+        close(("irfft∘rfft", P, B), back.cpu().numpy(), m, TOL[prec]["fft"])
         # irfft of NON-Hermitian input must follow FFTW/pocketfft semantics (Im of ky=0,Nyq after the x pass dropped)
         junk = (rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape))
         out = p.irfft(p.tensor(junk))
-        assert rel(out.cpu().numpy(), O.irfft2(junk, Ny)) < TOL[prec]["fft"], ("irfft non-hermitian", P, B)
+        close(("irfft non-hermitian", P, B), out.cpu().numpy(), O.irfft2(junk, Ny), TOL[prec]["fft"])
         # the whole basis lattice (src/proj_lambert.jl:245-300)
         oproj = O.Proj(Ny, Nx, 3.0, np.float64)
         h = p.convert(p.tensor(m), C.MAP, C.HARMONIC)
-        assert rel(h.cpu().numpy(), O.to_harm(oproj, m.astype(np.float64))) < 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32")
+        close("h.cpu().numpy()", h.cpu().numpy(), O.to_harm(oproj, m.astype(np.float64)), 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32"))
         q = p.convert(h, C.HARMONIC, C.FOURIER)
-        assert rel(q.cpu().numpy(), ref) < 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32")
+        close("q.cpu().numpy()", q.cpu().numpy(), ref, 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32"))
         mm = p.convert(h, C.HARMONIC, C.MAP)
-        assert rel(mm.cpu().numpy(), m) < 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32")
+        close("mm.cpu().numpy()", mm.cpu().numpy(), m, 3 * TOL[prec]["fft"] + 1e-6 * (prec == "f32"))
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -106,10 +104,10 @@ def test_reductions_and_diag_ops(prec):
         fh = O.to_harm(op, a.astype(float))
         want = O.from_harm(op, d.astype(float) * fh)
         got = p.diag_apply(d, p.tensor(a), C.HARMONIC, C.MAP, C.MAP)
-        assert rel(got.cpu().numpy(), want) < (5e-6 if prec == "f32" else 1e-12)
+        close("got.cpu().numpy()", got.cpu().numpy(), want, (5e-6 if prec == "f32" else 1e-12))
         want = O.from_harm(op, O.diag_div(d.astype(float), fh))
         got = p.diag_apply(d, p.tensor(a), C.HARMONIC, C.MAP, C.MAP, kind=3)
-        assert rel(got.cpu().numpy(), want) < (5e-6 if prec == "f32" else 1e-12)
+        close("got.cpu().numpy()", got.cpu().numpy(), want, (5e-6 if prec == "f32" else 1e-12))
         ld = p.logdet(d)
         np.testing.assert_allclose(ld, O.logdet_fourier(op, d.astype(float)[None])[0], rtol=1e-6 if prec == "f32" else 1e-12)
     # BlockDiagIEB (src/specialops.jl:80-83)
@@ -118,7 +116,7 @@ def test_reductions_and_diag_ops(prec):
     H = O.HarmOp(3, te=tuple(te[:4].astype(float)), bb=te[4].astype(float))
     want = H(O.to_harm(op, a.astype(float)))
     got = p.diag_apply(te, p.tensor(a), C.HARMONIC, C.MAP, C.HARMONIC)
-    assert rel(got.cpu().numpy(), want) < (5e-6 if prec == "f32" else 1e-12)
+    close("got.cpu().numpy()", got.cpu().numpy(), want, (5e-6 if prec == "f32" else 1e-12))
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -138,22 +136,22 @@ def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi, n):
     F = lambda a, b: C.Field(p, p.tensor(a), b)
     tol = TOL[prec]["flow"]
     out = (L * F(f, C.MAP)).arr.cpu().numpy()
-    assert rel(out, OL.apply(f)) < tol, "L*f"
+    close("L*f", out, OL.apply(f), tol)
     out = L.ldiv(F(f, C.MAP)).arr.cpu().numpy()
-    assert rel(out, OL.inv(f)) < tol, "L\\f"
+    close("L\\f", out, OL.inv(f), tol)
     gl = O.rfft2(g)
     out = (L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy()
-    assert rel(out, OL.adj(gl)) < tol, "L'*g"
+    close("L'*g", out, OL.adj(gl), tol)
     out = L.adjoint.ldiv(F(gl, C.FOURIER)).arr.cpu().numpy()
-    assert rel(out, OL.invadj(gl)) < tol, "L'\\g"
+    close("L'\\g", out, OL.invadj(gl), tol)
     # basis plumbing: harmonic in, map out == explicit conversion
     fh = O.to_harm(oproj, f)
     out = L._apply(C.FLOW_FWD, F(fh, C.HARMONIC), C.HARMONIC).arr.cpu().numpy()
-    assert rel(out, O.to_harm(oproj, OL.apply(f))) < 2 * tol
+    close("out", out, O.to_harm(oproj, OL.apply(f)), 2 * tol)
     # adjoint identity on the device itself (test/runtests.jl:556,570)
     lhs = p.dot(p.tensor(f), (L * F(g, C.MAP)).arr, C.MAP)
     rhs = (L.adjoint * F(O.rfft2(f), C.FOURIER)).dot(F(gl, C.FOURIER))
-    np.testing.assert_allclose(lhs, rhs, rtol=2e-4 if prec == "f32" else 1e-10)
+    scalars_close("adjoint identity", lhs, rhs, rtol=2e-4 if prec == "f32" else 1e-10)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -176,9 +174,9 @@ def test_lenseflow_gradient(camb, prec, Ny, Nx, P, B, Bphi, mode, n):
     for quirk in (False, True):
         f0, df, dp = (OL.grad_apply if mode == "fwd" else OL.grad_inv)(fe, delta, alias_quirk=quirk)
         gdp, gdf, gf0 = L.gradient(C.FLOW_FWD if mode == "fwd" else C.FLOW_INV, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=quirk)
-        assert rel(gf0.arr.cpu().numpy(), f0) < TOL[prec]["flow"], ("f", quirk)
-        assert rel(gdf.arr.cpu().numpy(), df) < TOL[prec]["flow"], ("df", quirk)
-        assert rel(gdp.arr.cpu().numpy(), dp) < TOL[prec]["grad"], ("dphi", quirk)
+        close(("f", quirk), gf0.arr.cpu().numpy(), f0, TOL[prec]["flow"])
+        close(("df", quirk), gdf.arr.cpu().numpy(), df, TOL[prec]["flow"])
+        close(("dphi", quirk), gdp.arr.cpu().numpy(), dp, TOL[prec]["grad"])
     # the two variants must differ (the flag is live)
     a = L.gradient(C.FLOW_FWD, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=False)[0].arr
     b = L.gradient(C.FLOW_FWD, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=True)[0].arr
@@ -214,9 +212,9 @@ def test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P):
     for n in (7, 10):
         L = C.LenseFlow(p, n)(F(phi[None, None], C.MAP))
         got = (L * F(f, C.MAP)).arr.cpu().numpy()
-        assert rel(got, want) < tol, (n, rel(got, want))
+        close(("exact remap, n", n), got, want, tol)
         assert rel(got, wrong) > 0.1
-        assert rel(L.ldiv(F(want, C.MAP)).arr.cpu().numpy(), f) < 3 * tol
+        close(("L\\ of the exact remap, n", n), L.ldiv(F(want, C.MAP)).arr.cpu().numpy(), f, 3 * tol)
         g = np.random.default_rng(3).standard_normal(f.shape)
         lhs = p.dot(p.tensor(g), p.tensor(want), C.MAP)[0]
         rhs = (L.adjoint * F(g, C.MAP).to(C.FOURIER)).dot(F(f, C.MAP).to(C.FOURIER))[0]
@@ -242,9 +240,9 @@ def test_dataset_gradientf_and_wiener(prec, pol, Nside, mask):
     ods, ds, p = so["ds"], sd["ds"], sd["proj"]
     tol = TOL[prec]
     # the simulated fields agree (same PCG64 seeds, same operators)
-    assert rel(sd["f"].arr.cpu().numpy(), so["f"]) < tol["fft"] * 10 + 1e-6 * (prec == "f32")
-    assert rel(sd["phi"].arr.cpu().numpy(), so["phi"]) < tol["fft"] * 10 + 1e-6 * (prec == "f32")
-    assert rel(sd["d"].arr.cpu().numpy(), so["d"]) < tol["flow"]
+    close("sd['f'].arr.cpu().numpy()", sd["f"].arr.cpu().numpy(), so["f"], tol["fft"] * 10 + 1e-6 * (prec == "f32"))
+    close("sd['phi'].arr.cpu().numpy()", sd["phi"].arr.cpu().numpy(), so["phi"], tol["fft"] * 10 + 1e-6 * (prec == "f32"))
+    close("sd['d'].arr.cpu().numpy()", sd["d"].arr.cpu().numpy(), so["d"], tol["flow"])
     # run both sides from the ORACLE's fields so that only the operator under test differs
     F = lambda a, b: C.Field(p, p.tensor(a), b)
     f, phi, d = so["f"], so["phi"], so["d"]
@@ -252,24 +250,24 @@ def test_dataset_gradientf_and_wiener(prec, pol, Nside, mask):
     OL = ods.L(phi)
     want = ods.gradientf_logpdf(f, OL, d)
     got = ds.gradientf_logpdf(F(f, C.HARMONIC), F(phi, C.FOURIER))
-    assert rel(got.arr.cpu().numpy(), want) < tol["flow"] * 4, "gradientf_logpdf"
+    close("gradientf_logpdf", got.arr.cpu().numpy(), want, tol["flow"] * 4)
     # Wiener filter: same tolerance-based stop; compare solution and history loosely, tight solve tightly
     fw_o, h_o = ods.argmaxf_logpdf(phi, tol=1e-1, nsteps=500)
     fw_g, h_g = ds.argmaxf_logpdf(F(phi, C.FOURIER), tol=1e-1, nsteps=500)
     # iteration count depends on round-off (SURVEY §7 'CG reproducibility'): ±1 in fp64, within 5 % in fp32
     assert abs(len(h_g) - len(h_o)) <= (1 if prec == "f64" else max(2, len(h_o) // 20)), (len(h_g), len(h_o))
     n = min(len(h_g), len(h_o)) - 1
-    np.testing.assert_allclose(h_g[0][1], h_o[0][1], rtol=1e-3 if prec == "f32" else 1e-8)
-    np.testing.assert_allclose(h_g[n // 2][1], h_o[n // 2][1], rtol=5e-2 if prec == "f32" else 1e-5)
+    scalars_close("cg first residual", h_g[0][1], h_o[0][1], rtol=1e-3 if prec == "f32" else 1e-8)
+    scalars_close("cg mid-run residual", h_g[n // 2][1], h_o[n // 2][1], rtol=5e-2 if prec == "f32" else 1e-5)
     # hundreds of CG iterations amplify round-off (loss of conjugacy): converged solutions agree loosely ...
-    assert rel(fw_g.arr.cpu().numpy(), fw_o) < (5e-3 if prec == "f32" else 1e-4)
+    close("cg converged solution", fw_g.arr.cpu().numpy(), fw_o, (5e-3 if prec == "f32" else 1e-4))
     # ... while a fixed, short run (no early stop) must agree tightly, iterate by iterate
     fw_o, h_o = ods.argmaxf_logpdf(phi, tol=0.0, nsteps=8)
     fw_g, h_g = ds.argmaxf_logpdf(F(phi, C.FOURIER), tol=0.0, nsteps=8)
     assert len(h_g) == len(h_o) == 8
     for (i, r_g), (_, r_o) in zip(h_g, h_o):
-        np.testing.assert_allclose(r_g, r_o, rtol=2e-3 if prec == "f32" else 1e-8)
-    assert rel(fw_g.arr.cpu().numpy(), fw_o) < (3e-4 if prec == "f32" else 1e-9)
+        scalars_close(("cg 8-step residual", i), r_g, r_o, rtol=2e-3 if prec == "f32" else 1e-8)
+    close("cg 8-step iterate", fw_g.arr.cpu().numpy(), fw_o, (3e-4 if prec == "f32" else 1e-9))
     # fstart (maximization.jl:26,37): restarting from the 8-step iterate continues to converge
     fw_g2, h_g2 = ds.argmaxf_logpdf(F(phi, C.FOURIER), fstart=fw_g, tol=1e-1, nsteps=500)
     assert h_g2[0][1][0] < h_g[0][1][0] and min(h[1][0] for h in h_g2) < h_g2[0][1][0]
@@ -292,17 +290,17 @@ def test_logpdf_mixed_and_gradient(prec, pol, Nside):
     check(ds.lib.cmbl_dataset_set_op(ds._h, 8, ctypes.c_void_p(ds.ops["G_inv"].data_ptr()), 1))
     fo, po = ods.mix(so["f"], so["phi"])
     gfo_d, gpo_d = ds.mix(F(so["f"], C.HARMONIC), F(so["phi"], C.FOURIER))
-    assert rel(gfo_d.arr.cpu().numpy(), fo) < TOL[prec]["flow"] * 2
-    assert rel(gpo_d.arr.cpu().numpy(), po) < TOL[prec]["fft"] * 10 + 1e-6
+    close("gfo_d.arr.cpu().numpy()", gfo_d.arr.cpu().numpy(), fo, TOL[prec]["flow"] * 2)
+    close("gpo_d.arr.cpu().numpy()", gpo_d.arr.cpu().numpy(), po, TOL[prec]["fft"] * 10 + 1e-6)
     lp_o = ods.logpdf_mixed(fo, po)
     lp_g = ds.logpdf_mixed(F(fo, C.MAP), F(po, C.FOURIER))
-    np.testing.assert_allclose(lp_g, lp_o, rtol=2e-5 if prec == "f32" else 1e-10)
+    scalars_close("logpdf_mixed", lp_g, lp_o, rtol=2e-5 if prec == "f32" else 1e-10)
     for quirk in (False, True):
         lp2, gf, gp = ods.grad_logpdf_mixed(fo, po, alias_quirk=quirk)
         lp3, gf_g, gp_g = ds.gradient_logpdf_mixed(F(fo, C.MAP), F(po, C.FOURIER), alias_quirk=quirk)
-        np.testing.assert_allclose(lp3, lp2, rtol=2e-5 if prec == "f32" else 1e-10)
-        assert rel(gf_g.arr.cpu().numpy(), gf) < TOL[prec]["grad"], ("grad f°", quirk)
-        assert rel(gp_g.arr.cpu().numpy(), gp) < TOL[prec]["grad"] * 3, ("grad ϕ°", quirk)
+        scalars_close("logpdf from the gradient call", lp3, lp2, rtol=2e-5 if prec == "f32" else 1e-10)
+        close(("grad f°", quirk), gf_g.arr.cpu().numpy(), gf, TOL[prec]["grad"])
+        close(("grad ϕ°", quirk), gp_g.arr.cpu().numpy(), gp, TOL[prec]["grad"] * 3)
 
 
 def test_errors_are_status_codes():

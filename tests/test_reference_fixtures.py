@@ -37,8 +37,7 @@ def ref(name):
     return np.load(p)
 
 
-def rel(a, b):
-    return float(np.linalg.norm((np.asarray(a) - np.asarray(b)).ravel()) / np.linalg.norm(np.asarray(b).ravel()))
+from _tol import close, rel
 
 
 # ---- always run --------------------------------------------------------------------------------------------------------------
@@ -48,7 +47,7 @@ def test_committed_inputs_are_what_the_seeds_generate():
     for k, v in now.items():
         c = inp(k)
         assert c.shape == v.shape and c.dtype == v.dtype, k
-        assert rel(c, v) < 1e-13, k
+        close(k, c, v, 1e-13)
 
 
 def test_npy_recipe_of_the_julia_script_is_numpy_readable(tmp_path):
@@ -85,16 +84,16 @@ def test_oracle_flows_against_the_reference():
     ref("flow_Lf")
     proj, L, f, gl = _oracle_flow()
     Lf = L.apply(f)
-    assert rel(Lf, ref("flow_Lf")) < 1e-10
-    assert rel(L.inv(f), ref("flow_Linvf")) < 1e-10
-    assert rel(L.adj(gl), ref("flow_Ladjg")) < 1e-10
-    assert rel(L.invadj(gl), ref("flow_Linvadjg")) < 1e-10
+    close("Lf", Lf, ref("flow_Lf"), 1e-10)
+    close("L.inv(f)", L.inv(f), ref("flow_Linvf"), 1e-10)
+    close("L.adj(gl)", L.adj(gl), ref("flow_Ladjg"), 1e-10)
+    close("L.invadj(gl)", L.invadj(gl), ref("flow_Linvadjg"), 1e-10)
     _, df, dp = L.grad_apply(Lf, gl, alias_quirk=True)
-    assert rel(df, ref("flow_grad_df")) < 1e-10
-    assert rel(dp, ref("flow_grad_dphi")) < 1e-9
+    close("df", df, ref("flow_grad_df"), 1e-10)
+    close("dp", dp, ref("flow_grad_dphi"), 1e-9)
     # ∇ϕ ‖L(ϕ)f‖ = pullback at cotangent f̃/‖f̃‖
     _, _, dpn = L.grad_apply(Lf, O.rfft2(Lf / np.sqrt(np.sum(Lf ** 2))), alias_quirk=True)
-    assert rel(dpn, ref("flow_gradnorm_dphi")) < 1e-9
+    close("dpn", dpn, ref("flow_gradnorm_dphi"), 1e-9)
 
 
 def _oracle_posterior(pol):
@@ -112,15 +111,15 @@ def test_oracle_posterior_against_the_reference(pol):
     s, ds, f, phi = _oracle_posterior(pol)
     np.testing.assert_allclose(ds.logpdf(f, phi), ref(t + "logpdf"), rtol=1e-10)
     fo, po = ds.mix(f, phi)
-    assert rel(fo, ref(t + "fo")) < 1e-10 and rel(po, ref(t + "phio")) < 1e-10
+    close("fo", fo, ref(t + "fo"), 1e-10 and rel(po, ref(t + "phio")) < 1e-10)
     np.testing.assert_allclose(ds.logpdf_mixed(fo, po), ref(t + "logpdf_mixed"), rtol=1e-10)
     lp, gf, gp = ds.grad_logpdf_mixed(fo, po, alias_quirk=True)
-    assert rel(gf, ref(t + "grad_fo")) < 1e-9 and rel(gp, ref(t + "grad_phio")) < 1e-8
+    close("gf", gf, ref(t + "grad_fo"), 1e-9 and rel(gp, ref(t + "grad_phio")) < 1e-8)
     L = ds.L(phi)
-    assert rel(ds.gradientf_logpdf(f, L, ds.d), ref(t + "gradientf")) < 1e-10
+    close("ds.gradientf_logpdf(f", ds.gradientf_logpdf(f, L, ds.d), ref(t + "gradientf"), 1e-10)
     fw, hist = ds.argmaxf_logpdf(phi, tol=0.0, nsteps=8)
     np.testing.assert_allclose([h[1][0] for h in hist], ref(t + "cg_res"), rtol=1e-8)
-    assert rel(fw, ref(t + "cg_f")) < 1e-8
+    close("fw", fw, ref(t + "cg_f"), 1e-8)
 
 
 @pytest.mark.parametrize("pol", ["P"])
@@ -133,9 +132,9 @@ def test_oracle_quadratic_estimate_against_the_reference(pol):
     TF = {k: pl(ds.Mf)[k] * pl(ds.B)[k] for k in key}
     dd = {k: ds.d[:, i:i + 1] for i, k in enumerate(key)}
     pq, AL, Nphi = O.quadratic_estimate(s["proj"], "EB", dd, dd, pl(ds.Cf), pl(ds.Cftilde), pl(ds.Cn), ds.Cphi, TF)
-    assert rel(Nphi, ref(t + "qe_Nphi")[0, 0]) < 1e-8
-    assert rel(pq, ref(t + "qe_phi")) < 1e-8
-    assert rel(Nphi / 2, ref(t + "Nphi")[0, 0]) < 1e-8                    # what load_sim stores (src/dataset.jl:312)
+    close("Nphi", Nphi, ref(t + "qe_Nphi")[0, 0], 1e-8)
+    close("pq", pq, ref(t + "qe_phi"), 1e-8)
+    close("Nphi / 2", Nphi / 2, ref(t + "Nphi")[0, 0], 1e-8)  # what load_sim stores (src/dataset.jl:312)
 
 
 # ---- the HIP engine, reference-exact mode ------------------------------------------------------------------------------------
@@ -168,7 +167,7 @@ def test_gpu_reference_exact_mode_equals_the_oracle_run_the_same_way(prec, refer
     lp, gf, gp = ds.gradient_logpdf_mixed(F(fo, C.MAP), F(po, C.FOURIER))          # defaults only
     tol = dict(f32=(2e-4, 2e-3, 5e-3), f64=(1e-10, 1e-8, 1e-8))[prec]
     np.testing.assert_allclose(lp, lp_o, rtol=tol[0])
-    assert rel(gf.arr.cpu().numpy(), gf_o) < tol[1]
+    close("gf.arr.cpu().numpy()", gf.arr.cpu().numpy(), gf_o, tol[1])
     e1, e0 = rel(gp.arr.cpu().numpy(), gp_o), rel(gp.arr.cpu().numpy(), gp_q0)
     assert e1 < tol[2] and (prec == "f32" or e0 > 100 * e1), (e1, e0)              # it IS the aliased form, not the consistent one
     # flows: the pullback default follows the switch too
@@ -179,8 +178,8 @@ def test_gpu_reference_exact_mode_equals_the_oracle_run_the_same_way(prec, refer
     Lf = Lg * G(ff, C.MAP)
     dp, df, _ = Lg.gradient(C.FLOW_FWD, Lf, G(gl, C.FOURIER))
     _, df_o, dp_o = L.grad_apply(L.apply(ff), gl, alias_quirk=True)
-    assert rel(dp.arr.cpu().numpy(), dp_o) < (5e-4 if prec == "f32" else 1e-9)
-    assert rel(df.arr.cpu().numpy(), df_o) < (1e-4 if prec == "f32" else 1e-10)
+    close("dp.arr.cpu().numpy()", dp.arr.cpu().numpy(), dp_o, (5e-4 if prec == "f32" else 1e-9))
+    close("df.arr.cpu().numpy()", df.arr.cpu().numpy(), df_o, (1e-4 if prec == "f32" else 1e-10))
 
 
 @pytest.mark.gpu
@@ -195,10 +194,10 @@ def test_gpu_flows_against_the_reference(reference_exact):
     f, gl = F(inp("flow_f"), C.MAP), F(O.rfft2(inp("flow_g")), C.FOURIER)
     Lf = L * f
     g = lambda x: x.arr.cpu().numpy()
-    assert rel(g(Lf), ref("flow_Lf")) < 1e-10 and rel(g(L.ldiv(f)), ref("flow_Linvf")) < 1e-10
-    assert rel(g(L.adjoint * gl), ref("flow_Ladjg")) < 1e-10 and rel(g(L.adjoint.ldiv(gl)), ref("flow_Linvadjg")) < 1e-10
+    close("g(Lf)", g(Lf), ref("flow_Lf"), 1e-10 and rel(g(L.ldiv(f)), ref("flow_Linvf")) < 1e-10)
+    close("g(L.adjoint * gl)", g(L.adjoint * gl), ref("flow_Ladjg"), 1e-10 and rel(g(L.adjoint.ldiv(gl)), ref("flow_Linvadjg")) < 1e-10)
     dp, df, _ = L.gradient(C.FLOW_FWD, Lf, gl)
-    assert rel(g(df), ref("flow_grad_df")) < 1e-10 and rel(g(dp), ref("flow_grad_dphi")) < 1e-9
+    close("g(df)", g(df), ref("flow_grad_df"), 1e-10 and rel(g(dp), ref("flow_grad_dphi")) < 1e-9)
 
 
 @pytest.mark.gpu
@@ -216,10 +215,10 @@ def test_gpu_posterior_against_the_reference(pol, reference_exact):
     ds.set_data(F(inp(t + "d"), C.HARMONIC))
     g = lambda x: x.arr.cpu().numpy()
     fo, po = ds.mix(F(inp(t + "f"), C.HARMONIC), F(inp(t + "phi"), C.FOURIER))
-    assert rel(g(fo), ref(t + "fo")) < 1e-10
+    close("g(fo)", g(fo), ref(t + "fo"), 1e-10)
     lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
     np.testing.assert_allclose(lp, ref(t + "logpdf_mixed"), rtol=1e-10)
-    assert rel(g(gf), ref(t + "grad_fo")) < 1e-9 and rel(g(gp), ref(t + "grad_phio")) < 1e-8
+    close("g(gf)", g(gf), ref(t + "grad_fo"), 1e-9 and rel(g(gp), ref(t + "grad_phio")) < 1e-8)
     fw, hist = ds.argmaxf_logpdf(F(inp(t + "phi"), C.FOURIER), tol=0.0, nsteps=8)
     np.testing.assert_allclose([h[1][0] for h in hist], ref(t + "cg_res"), rtol=1e-7)
-    assert rel(g(fw), ref(t + "cg_f")) < 1e-8
+    close("g(fw)", g(fw), ref(t + "cg_f"), 1e-8)
