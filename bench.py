@@ -210,9 +210,9 @@ def cg_block(C, torch, sim, nit=40):
     sz = 4 if proj.T == torch.float32 else 8
     dtype = "f32" if sz == 4 else "f64"
     traf, traf_unit, src = measured_traffic(N, P, 1, dtype, ds.L.nsteps, unit="cg")
-    os.environ["CMBL_SLICE_STREAMS"] = "1"
+    old = proj.set_option("slice_streams", 1)
     per = kernel_table(proj, lambda: ds.argmaxf_logpdf(phi, tol=0.0, nsteps=nit), nit, N, P, 1, ds.L.nsteps, sz, traf)
-    os.environ.pop("CMBL_SLICE_STREAMS")
+    proj.set_option("slice_streams", old)
     flow = ("x_grad", "flow_y_fwd", "adj_y", "adj_x")
     out = {"ms_per_iteration": dt / nit * 1e3, "iterations_timed": nit,
            "launches_per_iteration": sum(v["launches_per_unit"] for v in per.values()),
@@ -431,11 +431,11 @@ def main():
         # per-launch timestamps over a re-run of (at most 20 of) the same steps.  The timed region above runs each pol slice as its
         # own launch chain on its own stream (concurrent half-size launches have no individual bandwidth), so this leg switches that
         # off: one launch over all slices, the same kernels.
-        os.environ["CMBL_SLICE_STREAMS"] = "1"
+        old_ss = proj.set_option("slice_streams", 1)
         nprof = min(args.steps, 20)
         traf, traf_step, traf_src = measured_traffic(N, P, B, args.dtype, nrk)
         per = kernel_table(proj, lambda: [step() for _ in range(nprof)], nprof, N, P, B, nrk, sz, traf)
-        os.environ.pop("CMBL_SLICE_STREAMS")
+        proj.set_option("slice_streams", old_ss)
         tot = sum(v["ms_per_unit"] for v in per.values())
         dom = max((k for k in per if "frac" in per[k]), key=lambda k: per[k]["ms_per_unit"])
         d = per[dom]
@@ -460,7 +460,7 @@ def main():
                            "compulsory_bytes_per_launch": d["compulsory_bytes_per_launch"], "kernel_time_share": d["ms_per_unit"] / tot,
                            "note": "achieved = compulsory bytes of one launch (bench.py compulsory_bytes, DESIGN.md §5) / mean kernel duration "
                                    "(the kernel's own start/stop timestamps, hipExtLaunchKernel events; one launch over all pol slices, "
-                                   "CMBL_SLICE_STREAMS=1); value / ms_per_step / whole_step are the timed region with one launch chain per pol "
+                                   "option slice_streams = 1); value / ms_per_step / whole_step are the timed region with one launch chain per pol "
                                    "slice.  traffic = measured L2<->fabric bytes per launch (rocprofv3 PMC, Infinity-Cache hits included)",
                            "per_kernel": per, "whole_step": whole}
         pus, psrc = profiler_mean_us(dom, N, P, B, args.dtype)

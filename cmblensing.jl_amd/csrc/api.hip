@@ -125,6 +125,7 @@ extern "C" {
 
 const char* cmbl_last_error(void) { return g_last_error.c_str(); }
 int cmbl_version(void) { return 100; }
+int cmbl_abi_version(void) { return CMBL_ABI_VERSION; }
 
 int cmbl_ctx_create(int Ny, int Nx, double theta, int dtype, int device, void* stream, cmbl_ctx** out) {
   return guard([&] {
@@ -143,6 +144,22 @@ int cmbl_ctx_create(int Ny, int Nx, double theta, int dtype, int device, void* s
 int cmbl_ctx_destroy(cmbl_ctx* ctx) { return guard([&] { delete ctx; }); }
 int cmbl_ctx_synchronize(cmbl_ctx* ctx) { return guard([&] { NOTNULL(ctx); CMBL_HIP(hipStreamSynchronize(ctx->p->stream)); }); }
 
+int cmbl_ctx_set_option(cmbl_ctx* ctx, const char* name, int value) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(name);
+    int* o = ctx->p->opt_ptr(name);
+    CMBL_REQUIRE(o != nullptr, ERR_ARG, std::string("unknown option: ") + name);
+    *o = value;
+  });
+}
+int cmbl_ctx_get_option(cmbl_ctx* ctx, const char* name, int* value_host) {
+  return guard([&] {
+    NOTNULL(ctx); NOTNULL(name); NOTNULL(value_host);
+    int* o = ctx->p->opt_ptr(name);
+    CMBL_REQUIRE(o != nullptr, ERR_ARG, std::string("unknown option: ") + name);
+    *value_host = *o;
+  });
+}
 int cmbl_prof_enable(cmbl_ctx* ctx, int on) {
   return guard([&] { NOTNULL(ctx); if (!on) ctx->p->prof_collect(); ctx->p->prof_on = on != 0; });
 }

@@ -48,8 +48,9 @@ static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x
     if ((ctxp)->prof_on) {                                                            \
       auto& ev_ = (ctxp)->prof_next(kid);                                             \
       hipExtLaunchKernelGGL(kernel, grid, dim3(nthreads), (lds), (stream), ev_.first, ev_.second, 0, __VA_ARGS__); \
-    } else hipLaunchKernelGGL(kernel, grid, dim3(nthreads), (lds), (stream), __VA_ARGS__);   \
-    CMBL_HIP(hipGetLastError());                                                      \
+      CMBL_HIP(hipGetLastError());                                                    \
+      (ctxp)->prof_commit(kid);                                                       \
+    } else { hipLaunchKernelGGL(kernel, grid, dim3(nthreads), (lds), (stream), __VA_ARGS__); CMBL_HIP(hipGetLastError()); }   \
   } while (0)
 #define CMBL_LAUNCH(ctxp, kid, kernel, grid, lds, stream, ...) CMBL_LAUNCH_NT(ctxp, kid, NTP, kernel, grid, lds, stream, __VA_ARGS__)
 
@@ -78,6 +79,30 @@ struct CtxBase {
   // SUM_FLOAT64 by default (see kernels_pointwise.hpp); CMBL_REFERENCE_EXACT=1 starts a context with the reference's own default,
   // plain sums in the working precision (SUM_WORKING, src/util.jl:288-316)
   int sum_mode = env_int("CMBL_REFERENCE_EXACT", 0) ? 0 : 1;
+  // Behaviour switches (A/B and profiling aids).  The environment is read ONCE, when the context is created; afterwards they only
+  // change through cmbl_ctx_set_option -- never by a getenv in a launch path (not safe against a concurrent setenv of the host
+  // language, and a switch that flips between two launches of one flow would mix code paths).
+  struct Opts {
+    int slice_streams = env_int("CMBL_SLICE_STREAMS", 4);                 // launch chains per flow (1 = one launch over all slices)
+    int slice_streams_min_pix = env_int("CMBL_SLICE_STREAMS_MIN_PIX", 1 << 20);
+    int pcache = env_int("CMBL_NO_PCACHE", 0) == 0;                       // p(t_k) cache per phi (read when phi is set)
+    int pcache_max_mb = env_int("CMBL_PCACHE_MAX_MB", 16384);
+    int fused_harm = env_int("CMBL_NO_FUSED_HARM", 0) == 0;               // harmonic-space work on the row carrier (kernels_harm.hpp)
+    int gen_separable = env_int("CMBL_GEN_SEPARABLE", 1) != 0;            // any-size path: separable stages
+    int gen_prologue = env_int("CMBL_GEN_PROLOGUE", 1) != 0;              //   pointwise work in the fetch of the consuming transform
+    int gen_xderiv_fused = env_int("CMBL_GEN_XDERIV_FUSED", 1) != 0;      //   d/dx pass as one launch
+  } opts;
+  int* opt_ptr(const std::string& k) {
+    if (k == "slice_streams") return &opts.slice_streams;
+    if (k == "slice_streams_min_pix") return &opts.slice_streams_min_pix;
+    if (k == "pcache") return &opts.pcache;
+    if (k == "pcache_max_mb") return &opts.pcache_max_mb;
+    if (k == "fused_harm") return &opts.fused_harm;
+    if (k == "gen_separable") return &opts.gen_separable;
+    if (k == "gen_prologue") return &opts.gen_prologue;
+    if (k == "gen_xderiv_fused") return &opts.gen_xderiv_fused;
+    return nullptr;
+  }
   double theta = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -88,12 +113,15 @@ struct CtxBase {
   size_t prof_used[K_COUNT] = {};
   double prof_ms[K_COUNT] = {};
   long prof_n[K_COUNT] = {};
-  std::pair<hipEvent_t, hipEvent_t>& prof_next(int k) {                  // the event pair of the next profiled launch of class k
+  // the event pair of the next profiled launch of class k; it is COUNTED (prof_commit) only once the launch has been accepted, so a
+  // failed launch leaves no unrecorded pair for prof_collect to trip over (which would mask the launch error)
+  std::pair<hipEvent_t, hipEvent_t>& prof_next(int k) {
     if (prof_used[k] == prof_ev[k].size()) {
       hipEvent_t a, b; CMBL_HIP(hipEventCreate(&a)); CMBL_HIP(hipEventCreate(&b)); prof_ev[k].push_back({a, b});
     }
-    return prof_ev[k][prof_used[k]++];
+    return prof_ev[k][prof_used[k]];
   }
+  void prof_commit(int k) { ++prof_used[k]; }
   void prof_collect() {                         // synchronises; folds recorded pairs into the totals
     CMBL_HIP(hipDeviceSynchronize());
     for (int k = 0; k < K_COUNT; ++k) {
@@ -308,7 +336,7 @@ struct Ctx : CtxBase {
   }
   // out = ifft_x(i lx fft_x(in)) unnormalised, in ONE launch when the axis has a mixed-radix plan (else two: chirp-z transforms)
   bool gen_x_deriv(const cx<T>* in, cx<T>* out, cx<T>* tmp, const T* lx, long slices) {
-    if (genX.plan.nf == 0 || env_int("CMBL_GEN_XDERIV_FUSED", 1) == 0) {
+    if (genX.plan.nf == 0 || !opts.gen_xderiv_fused) {
       gen_x(in, tmp, false, lx, slices);
       gen_x(tmp, out, true, nullptr, slices);
       return false;
@@ -505,7 +533,9 @@ struct Ctx : CtxBase {
   // ---- fused harmonic work (kernels_harm.hpp) -----------------------------------------------------------------------------
   // partial sums of the fused launches: region r of dot_part holds [B][nblk] doubles of one producer (PART_*), finished by its consumer
   enum PartRegion { PART_QF = 0, PART_QP, PART_QN, PART_CG_RZ, PART_CG_PAP, PART_COUNT };
-  static constexpr size_t PART_STRIDE = (size_t)MAXBATCH * 2048;           // doubles per region: B <= MAXBATCH, blocks per slot <= 2048
+  // doubles per region: B <= MAXBATCH slots x blocks per slot <= 2056 (a row carrier at Ny = 4096 with one row per workgroup has
+  // Ny/2 + 1 = 2049 row groups per slot; the flat kernels at most 1024)
+  static constexpr size_t PART_STRIDE = (size_t)MAXBATCH * 2056;
   DevBuf dot_part;
   ModeGeom<T> geom() const { return ModeGeom<T>{cos2F.as<T>(), sin2F.as<T>(), lam.as<T>(), plane(), Nx}; }
   double dot_scale() const { return 1.0 / ((double)Ny * Nx); }
@@ -713,14 +743,14 @@ struct Flow {
     }
     if (evFork) (void)hipEventDestroy(evFork);
   }
-  // one slice per group; CMBL_SLICE_STREAMS is re-read per call so a profiler can switch the splitting off (bench.py roofline leg)
+  // one slice per group; the `slice_streams` option (cmbl_ctx_set_option) lets a profiler switch the splitting off (bench.py roofline leg)
   // Only where a launch is long enough (>= ~10 us: 2^20 pixels) for the host to keep several chains fed -- a launch costs the host
   // ~4 us, and at 512^2 the kernels last 7 us, so splitting there makes the flow host-bound (measured: 512^2 L*f 0.41 -> 0.52 ms).
   // B = 1: one pol slice per group.  B > 1: groups of whole batch slots (K = the largest divisor of B that fits), so that a group's
   // phi slots are contiguous (phi_off) -- fewer, larger launches per chain, still several chains in flight.
   int groups(int P, int B) const {
-    if (c->npix() < env_int("CMBL_SLICE_STREAMS_MIN_PIX", 1 << 20)) return 1;
-    const int cap = std::min(max_groups, env_int("CMBL_SLICE_STREAMS", MAXG));
+    if (c->npix() < c->opts.slice_streams_min_pix) return 1;
+    const int cap = std::min(max_groups, c->opts.slice_streams);
     if (B == 1) { if (Bphi == 1) for (int k = std::min(P, cap); k > 1; --k) if (P % k == 0) return k; return 1; }
     // measured at 1024^2 QU: B = 2 -> 2 chains +6 %; B = 4: 2 chains 262 evaluations/s, 4 chains 240, 1 chain 247; B = 8: 266 vs 258
     for (int k = std::min(cap, B >= 4 ? 2 : B); k > 1; --k) if (B % k == 0) return k;
@@ -768,7 +798,7 @@ struct Flow {
     // p(t) at the 2n+1 stage times (the reference caches p and M^-1, src/lenseflow.jl:45-46,88-90): 2(2n+1) maps per phi slot,
     // 120 MB at 1024^2 fp32 n = 7.  M^-1(t), needed only by the delta-phi kernel, is still formed on the fly.
     const size_t ntot = (size_t)nb * c->npix(), bytes = sizeof(T) * 2 * (2 * n + 1) * ntot;
-    use_pcache = env_int("CMBL_NO_PCACHE", 0) == 0 && bytes <= ((size_t)env_int("CMBL_PCACHE_MAX_MB", 16384) << 20);
+    use_pcache = c->opts.pcache && bytes <= ((size_t)c->opts.pcache_max_mb << 20);
     if (use_pcache) {
       pcache.ensure(bytes);
       const unsigned gx = (unsigned)std::min<size_t>((ntot + NTP - 1) / NTP, 16384);
@@ -833,7 +863,7 @@ struct Flow {
   // rfft2 -> (i lx, i ly) -> 2 x irfft2 (src/lenseflow.jl:155-157) incl. FFTW's c2r rule at ky = 0 / Nyquist, in 3 launches and
   // 3 slice-passes instead of 5 launches and 7.5.  CMBL_GEN_SEPARABLE=0: the reference's own pass structure (kept for A/B).
   DevBuf gA, gGx, gT, gW2;
-  bool gen_sep() const { return env_int("CMBL_GEN_SEPARABLE", 1) != 0; }
+  bool gen_sep() const { return c->opts.gen_separable != 0; }
   void gen_grad_sep(const cx<T>* A_, long slices) {
     const long pl = c->plane(), np = c->npix();
     gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); gmxy.ensure(sizeof(T) * 2 * slices * np);
@@ -852,7 +882,7 @@ struct Flow {
   }
   // d(Fourier state)/dt from the maps (Wx, Wy) = the halves of Wxy: rfft2 of both + the RK update with k = i lx Fx + i ly Fy
   // (separable form: the two real maps go through ONE complex y transform, then one x launch over both)
-  bool gen_pro() const { return env_int("CMBL_GEN_PROLOGUE", 1) != 0; }
+  bool gen_pro() const { return c->opts.gen_prologue != 0; }
   void gen_adj_update(const T* Wxy, cx<T>* Y0, cx<T>* Yacc_, cx<T>* Ys, const RKCoef<T>& rk, long slices, const GenPro<T>* pro = nullptr) {
     const long pl = c->plane(), np = c->npix();
     gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl);
@@ -961,7 +991,7 @@ struct Flow {
     else
       CMBL_LAUNCH(c, K_DPHI_Y, (k_dphi_reduce<T, 1>), dim3((unsigned)std::min<long>((np + NTP - 1) / NTP, 8192), (unsigned)B), 0, c->stream, ph(), Wst.as<T>(),
                   tcv, tcd, U5.as<T>(), np, P, B, nst, alias_quirk ? 1 : 0);
-    if (c->x_dphi_fits() && env_int("CMBL_NO_FUSED_HARM", 0) == 0) {
+    if (c->x_dphi_fits() && c->opts.fused_harm) {
       // the five x transforms and the l-multipliers in one row launch (five row sets in LDS), the caller's tail on top
       cx<T>* m5 = c->mixed_scratch(5L * B);
       c->y_r2c(U5.as<T>(), m5, 5L * B);
@@ -1251,7 +1281,7 @@ struct Dataset {
   }
 
   // ---- fused path (kernels_harm.hpp; power-of-two maps) ----------------------------------------------------------------------------
-  bool fused() const { return !c->generic && env_int("CMBL_NO_FUSED_HARM", 0) == 0; }
+  bool fused() const { return !c->generic && c->opts.fused_harm; }
   OpRef<T> opref(int which, bool transpose = false) const {
     const Op& o = op(which);
     OpRef<T> r{};
@@ -1369,7 +1399,7 @@ struct Dataset {
   // a0 = gradientf(f=0,d=0) is identically zero for this linear model (all operators finite), so it is not evaluated.
   // The scalars (res, alpha, beta, best residual, history, stop flag) live on the device (CgState): an iteration is enqueued
   // without waiting for its reductions; the host reads the stop flag of iteration i-1 while iteration i runs.
-  DevBuf cg_scal, cg_hist, qdev;
+  DevBuf cg_scal, cg_hist, qdev, cg_rzfin;
   int* cg_flag_host = nullptr;                 // pinned: [slot][done, nan]
   hipEvent_t cg_ev[2] = {nullptr, nullptr};
   ~Dataset() {
@@ -1387,6 +1417,7 @@ struct Dataset {
     cx<T>*Ap = aps.template as<cx<T>>(), *bx = best.template as<cx<T>>(), *b = bb.template as<cx<T>>();
     CMBL_REQUIRE(B <= MAXBATCH, ERR_ARG, "nbatch > 256 not supported in reductions");
     cg_scal.ensure(sizeof(double) * 7 * MAXBATCH + sizeof(int) * 8);
+    cg_rzfin.ensure(sizeof(double) * MAXBATCH);
     cg_hist.ensure(sizeof(double) * (size_t)maxit * B);
     if (!cg_flag_host) {
       CMBL_HIP(hipHostMalloc((void**)&cg_flag_host, sizeof(int) * 16, hipHostMallocDefault));
@@ -1432,7 +1463,11 @@ struct Dataset {
           constexpr int PP = decltype(pp)::value;
           const DotOut oA = c->pw_flat(PwCgAp<T, PP>{g, opref(OP_CF_INV), Y, p, Ap}, B, Ctx<T>::PART_CG_PAP);                // A p = Y - Cf^-1 p
           const DotOut oR = c->pw_flat(PwCgXr<T, PP>{g, opref(OP_PRECOND_INV), x, r, p, Ap, st, par, oA, sc}, B, Ctx<T>::PART_CG_RZ);   // alpha ; x, r
-          c->pw_flat(PwCgP<T, PP>{g, opref(OP_PRECOND_INV), x, r, p, bx, st, par, tol, oR, sc}, B);                          // beta, stop test ; p, best iterate
+          // beta, stop test ; p, best iterate.  Every block needs r'z of ALL slots (`all(res < bestres)`, :111): up to 16 slots it adds
+          // their partials itself in its prologue; beyond that one small launch finishes them first (O(B) instead of O(B^2) per block)
+          const double* rzf = nullptr;
+          if (B > 16) { double* const o1[1] = {cg_rzfin.as<double>()}; c->finish_parts(&oR, o1, 1, B); rzf = o1[0]; }
+          c->pw_flat(PwCgP<T, PP>{g, opref(OP_PRECOND_INV), x, r, p, bx, st, par, tol, oR, sc, rzf}, B);
         });
         par ^= 1;
         post_flags(it & 1);

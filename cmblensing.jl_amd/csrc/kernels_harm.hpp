@@ -312,6 +312,7 @@ template <typename T, int P> struct PwCgP {
   const cx<T>* x; const cx<T>* r; cx<T>* p; cx<T>* bestx;
   CgScal s; int par; double tol;
   DotOut rz; double scale;                     // PwCgXr's partials
+  const double* rz_fin;                        // r'z of every slot, already summed (k_finish_parts), or nullptr: summed here
   __device__ __forceinline__ Local prologue(int b, int B, double* scratch) const {
     const int nx = par ^ 1;
     const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
@@ -322,7 +323,7 @@ template <typename T, int P> struct PwCgP {
     int better = 1, done = 1, nanf = 0;
     double mine = 0;
     for (int bb = 0; bb < B; ++bb) {           // every block needs `better`, which looks at all batch slots (:111)
-      const double r2 = sum_partials<T, NTP>(rz.part + (size_t)bb * rz.nblk, rz.nblk, scale, rz.mode, scratch);
+      const double r2 = rz_fin ? rz_fin[bb] : sum_partials<T, NTP>(rz.part + (size_t)bb * rz.nblk, rz.nblk, scale, rz.mode, scratch);
       nanf |= isnan(r2);
       better &= (r2 < s.best[par * MAXBATCH + bb]); done &= (r2 < tol);
       if (bb == b) mine = r2;

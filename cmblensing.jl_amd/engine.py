@@ -252,6 +252,19 @@ class ProjLambert:
         m = {None: 0, "working": 0, "float64": 1, float: 1, np.float64: 1, "kahan": 2}[mode]
         check(self.lib.cmbl_set_sum_accuracy_mode(self._h, m))
 
+    def set_option(self, name, value):
+        """behaviour switch of this context (`cmbl_ctx_set_option`, include/cmblens.h): "slice_streams", "pcache", "fused_harm", ...
+        Returns the previous value."""
+        old = ctypes.c_int(0)
+        check(self.lib.cmbl_ctx_get_option(self._h, name.encode(), ctypes.byref(old)))
+        check(self.lib.cmbl_ctx_set_option(self._h, name.encode(), int(value)))
+        return old.value
+
+    def get_option(self, name):
+        v = ctypes.c_int(0)
+        check(self.lib.cmbl_ctx_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
     def timer_report(self):
         """text table of the per-kernel-class HIP-event timings (cmbl_timer_report)"""
         n = self.lib.cmbl_timer_report(self._h, None, 0)

@@ -8,7 +8,7 @@ _LIB = None
 
 # every symbol include/cmblens.h declares (tests/test_boundary.py checks the .so exports exactly these)
 SYMBOLS = [
-    "cmbl_last_error", "cmbl_version", "cmbl_ctx_create", "cmbl_ctx_destroy", "cmbl_ctx_synchronize",
+    "cmbl_last_error", "cmbl_version", "cmbl_abi_version", "cmbl_ctx_set_option", "cmbl_ctx_get_option", "cmbl_ctx_create", "cmbl_ctx_destroy", "cmbl_ctx_synchronize",
     "cmbl_ctx_geometry_host", "cmbl_prof_enable", "cmbl_prof_reset", "cmbl_prof_count", "cmbl_prof_name", "cmbl_prof_get", "cmbl_rfft", "cmbl_irfft", "cmbl_convert", "cmbl_diag_apply",
     "cmbl_blockdiag_ieb_apply", "cmbl_dot", "cmbl_logdet", "cmbl_lenseflow_create", "cmbl_lenseflow_destroy",
     "cmbl_lenseflow_set_phi", "cmbl_lenseflow_apply", "cmbl_lenseflow_grad", "cmbl_dataset_create",
@@ -17,6 +17,9 @@ SYMBOLS = [
     "cmbl_norm", "cmbl_logdet_diag", "cmbl_tr_diag", "cmbl_set_sum_accuracy_mode", "cmbl_timer_report",
     "cmbl_device_malloc", "cmbl_device_free", "cmbl_copy_to_device", "cmbl_copy_to_host",
 ]
+
+
+ABI_VERSION = 3          # CMBL_ABI_VERSION of include/cmblens.h this binding was written against
 
 
 class CmblError(RuntimeError):
@@ -61,6 +64,10 @@ def load_library():
     lib.cmbl_last_error.restype = ctypes.c_char_p
     lib.cmbl_last_error.argtypes = []
     lib.cmbl_version.restype = ci
+    lib.cmbl_abi_version.restype = ci
+    lib.cmbl_abi_version.argtypes = []
+    if lib.cmbl_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.cmbl_abi_version()} but this package binds version {ABI_VERSION} (include/cmblens.h): rebuild")
     lib.cmbl_prof_count.restype = ci
     lib.cmbl_prof_count.argtypes = []
     lib.cmbl_prof_name.restype = ctypes.c_char_p
@@ -68,6 +75,8 @@ def load_library():
     sig = {
         "cmbl_ctx_create": [ci, ci, cd, ci, ci, vp, ctypes.POINTER(vp)],
         "cmbl_ctx_destroy": [vp],
+        "cmbl_ctx_set_option": [vp, ctypes.c_char_p, ci],
+        "cmbl_ctx_get_option": [vp, ctypes.c_char_p, ctypes.POINTER(ci)],
         "cmbl_ctx_synchronize": [vp],
         "cmbl_ctx_geometry_host": [vp, ci, pd, ctypes.c_size_t],
         "cmbl_prof_enable": [vp, ci],

@@ -55,8 +55,15 @@ enum { CMBL_FLOW_FWD = 0,     /* L * f   : velocity,  t 0->1 */
 /* diagonal operator application kinds (src/specialops.jl:9-10) */
 enum { CMBL_DIAG_MUL = 1, CMBL_DIAG_DIV_NAN2ZERO = 3 };
 
+/* ABI revision of this header.  Bumped whenever an existing entry point changes its signature or meaning (additions do not bump
+ * it): 2 = cmbl_device_malloc / cmbl_device_free take the context (round 3); 3 = behaviour switches are read from the environment
+ * once per context and changed through cmbl_ctx_set_option (round 4).  A caller compiled against this header checks
+ * cmbl_abi_version() == CMBL_ABI_VERSION before anything else (julia/CMBLensingHIPExt.jl __init__, tests/c_abi/ *.c). */
+#define CMBL_ABI_VERSION 3
+
 const char* cmbl_last_error(void);
-int cmbl_version(void);
+int cmbl_version(void);          /* library release, 100 * major + minor */
+int cmbl_abi_version(void);      /* the CMBL_ABI_VERSION the library was built with */
 
 /* ---- context: replaces the memoized ProjLambert + FFT plans
  *      (src/proj_lambert.jl:48-75, src/util_fft.jl:32-39).  `stream` is a hipStream_t the caller owns
@@ -67,6 +74,18 @@ int cmbl_ctx_synchronize(cmbl_ctx* ctx);
 /* geometry queries, host output, double: which = 0 lx[Nx], 1 ly[Ny/2+1], 2 lambda_rfft[Ny/2+1],
  * 3 sin2phi[(Ny/2+1)*Nx], 4 cos2phi[...], 5 lmag[...]  (planes in the reference layout) */
 int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n);
+
+/* ---- behaviour switches of a context (A/B and profiling aids; none changes results beyond rounding).  Each starts from the
+ *      environment variable named below, read ONCE when the context is created, and afterwards changes only through this call:
+ *        "slice_streams"         CMBL_SLICE_STREAMS (4)            launch chains per flow: pol slices / batch-slot groups on their own streams; 1 = one launch over all slices
+ *        "slice_streams_min_pix" CMBL_SLICE_STREAMS_MIN_PIX (2^20) smallest map that is split
+ *        "pcache"                !CMBL_NO_PCACHE (1)               cache p(t_k) at the 2n+1 stage times per phi (src/lenseflow.jl:45-46,131-142); read by cmbl_lenseflow_set_phi
+ *        "pcache_max_mb"         CMBL_PCACHE_MAX_MB (16384)
+ *        "fused_harm"            !CMBL_NO_FUSED_HARM (1)           harmonic-space operator chains inside one row pass
+ *        "gen_separable", "gen_prologue", "gen_xderiv_fused"       any-size path stage fusions (CMBL_GEN_SEPARABLE / _PROLOGUE / _XDERIV_FUSED, all 1)
+ *      Unknown names return CMBL_ERR_ARG.  The reference has no counterpart (its switches are Julia keyword arguments). */
+int cmbl_ctx_set_option(cmbl_ctx* ctx, const char* name, int value);
+int cmbl_ctx_get_option(cmbl_ctx* ctx, const char* name, int* value_host);
 
 /* ---- optional per-launch timing of the library's kernel classes with HIP events on the context's stream
  *      (the reference wraps the same call sites in TimerOutputs `@⌛`, src/util.jl:351-390).  Disabled by default. */

@@ -3,7 +3,7 @@
 # STATUS: written against CMBLensing.jl v0.10.1 by reading its sources; **never executed** -- no Julia runtime exists in the build
 # image or on the GPU boxes.  What IS executed is the same set of C entry points through the Python mirror
 # (cmblensing.jl_amd/, ctypes) and through the plain-C callers tests/c_abi/*.c.  Citations are file:line of the reference.
-# julia/test_hipext.jl is the first thing to run on a machine that has Julia + AMDGPU.jl (it compares every binding below with the
+# julia/test_hipext.jl (also unexecuted) is the first thing to run on a machine that has Julia + AMDGPU.jl (it compares every binding below with the
 # reference's own CPU path); julia/make_reference_fixtures.jl needs no GPU at all.
 #
 # What plugs in where
@@ -38,6 +38,11 @@ reference_exact() = !(get(ENV, "CMBL_REFERENCE_EXACT", "0") in ("", "0"))
 
 # ---- status codes -> exceptions (include/cmblens.h: nothing throws across the ABI) ---------------------------------------
 chk(rc::Integer) = rc == 0 ? nothing : error("libcmblens_hip error $rc: ", unsafe_string(ccall((:cmbl_last_error, lib), Cstring, ())))
+const CMBL_ABI_VERSION = 3          # include/cmblens.h: the revision these ccall signatures were written against
+function __init__()
+    v = ccall((:cmbl_abi_version, lib), Cint, ())
+    v == CMBL_ABI_VERSION || error("libcmblens_hip.so has ABI version $v, this extension binds version $CMBL_ABI_VERSION: rebuild one of them")
+end
 
 const MAP, FOURIER, HARMONIC = Cint(0), Cint(1), Cint(2)                  # CMBL_MAP / CMBL_FOURIER / CMBL_HARMONIC
 const FLOW_FWD, FLOW_INV, FLOW_ADJ, FLOW_INVADJ = Cint(0), Cint(1), Cint(2), Cint(3)

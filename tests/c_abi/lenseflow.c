@@ -13,6 +13,7 @@
 
 #define SYM(name) name##_t p_##name = (name##_t)dlsym(lib, #name); if (!p_##name) { fprintf(stderr, "missing symbol %s\n", #name); return 2; }
 typedef const char* (*cmbl_last_error_t)(void);
+typedef int (*cmbl_abi_version_t)(void);
 typedef int (*cmbl_ctx_create_t)(int, int, double, int, int, void*, cmbl_ctx**);
 typedef int (*cmbl_ctx_destroy_t)(cmbl_ctx*);
 typedef int (*cmbl_device_malloc_t)(cmbl_ctx*, size_t, void**);
@@ -39,6 +40,8 @@ int main(int argc, char** argv) {
   SYM(cmbl_last_error) SYM(cmbl_ctx_create) SYM(cmbl_ctx_destroy) SYM(cmbl_device_malloc) SYM(cmbl_device_free)
   SYM(cmbl_copy_to_device) SYM(cmbl_copy_to_host) SYM(cmbl_lenseflow_create) SYM(cmbl_lenseflow_destroy)
   SYM(cmbl_lenseflow_set_phi) SYM(cmbl_lenseflow_apply) SYM(cmbl_lenseflow_grad) SYM(cmbl_dot)
+SYM(cmbl_abi_version)
+  if (p_cmbl_abi_version() != CMBL_ABI_VERSION) { fprintf(stderr, "ABI version %d, header %d\n", p_cmbl_abi_version(), CMBL_ABI_VERSION); return 2; }
 #define CHK(call) do { int rc_ = (call); if (rc_ != CMBL_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, p_cmbl_last_error()); return 1; } } while (0)
 
   FILE* fh = fopen(argv[2], "rb");

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from _tol import _record, scalars_close
+from _tol import sample_close, scalars_close
 from oracle.lenseflow import LenseFlow as OLF
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -16,8 +16,7 @@ def check_sample(z, key, arr, rtol):
     flat = np.asarray(arr).ravel()
     idx, val, l2 = z[f"{key}.idx"], z[f"{key}.val"], z[f"{key}.l2"]
     err = float(np.linalg.norm(flat[idx] - val) / np.linalg.norm(val))
-    _record("golden " + key, err, rtol)
-    assert err < rtol, f"{key}: relative L2 error on the golden sample {err:.3e} >= tolerance {rtol:.1e}"
+    sample_close("golden " + key, err, rtol)
     assert abs(np.sqrt(np.sum(np.abs(flat) ** 2)) - l2) < 10 * rtol * l2, key
 
 
@@ -69,7 +68,7 @@ def test_gpu_reproduces_golden_flows(prec, Ny, Nx, P):
     p = C.ProjLambert(Ny, Nx, 2.0, torch.float32 if prec == "f32" else torch.float64)
     F = lambda a, b: C.Field(p, p.tensor(a), b)
     L = C.LenseFlow(p, 7)(F(phi, C.MAP))
-    tol, gtol = (1e-4, 5e-4) if prec == "f32" else (1e-10, 1e-9)
+    tol, gtol = (5e-5, 1.4e-4) if prec == "f32" else (1e-10, 1e-9)      # fp32 measured: flows 2.5e-6 (forward) / 1.6e-5 (adjoint), δϕ 4.4e-5
     Lf = L * F(f, C.MAP)
     check_sample(z, "Lf", Lf.arr.cpu().numpy(), tol)
     check_sample(z, "Linvf", L.ldiv(F(f, C.MAP)).arr.cpu().numpy(), tol)
@@ -93,13 +92,12 @@ def test_gpu_reproduces_golden_posterior(prec, pol, Nside):
     s = C.load_sim(3.0, Nside, pol, synthetic_cls(), T=torch.float32 if prec == "f32" else torch.float64, beam_fwhm=3.0,
                    pixel_mask=dict(pad_deg=0.4, apod_deg=0.4))
     ds = s["ds"]
-    tol = 2e-4 if prec == "f32" else 1e-9
-    check_sample(z, "d", s["d"].arr.cpu().numpy(), tol)
+    check_sample(z, "d", s["d"].arr.cpu().numpy(), 2.1e-6 if prec == "f32" else 1e-9)              # measured 7.0e-7
     fo, po = ds.mix(s["f"], s["phi"])
     lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
-    scalars_close("golden logpdf_mixed", lp, z["logpdf_mixed"], rtol=5e-5 if prec == "f32" else 1e-9)
-    check_sample(z, "grad_fo", gf.arr.cpu().numpy(), 2e-3 if prec == "f32" else 1e-8)
-    check_sample(z, "grad_phio", gp.arr.cpu().numpy(), 5e-3 if prec == "f32" else 1e-8)
+    scalars_close("golden logpdf_mixed", lp, z["logpdf_mixed"], rtol=2.3e-7 if prec == "f32" else 1e-9)      # 7.7e-8
+    check_sample(z, "grad_fo", gf.arr.cpu().numpy(), 5.5e-5 if prec == "f32" else 1e-8)                       # 1.8e-5
+    check_sample(z, "grad_phio", gp.arr.cpu().numpy(), 6.4e-6 if prec == "f32" else 1e-8)                     # 2.1e-6
     fw, hist = ds.argmaxf_logpdf(s["phi"], tol=0.0, nsteps=8)
-    scalars_close("golden cg_res", [h[1][0] for h in hist], z["cg_res"], rtol=5e-3 if prec == "f32" else 1e-7)
-    check_sample(z, "cg_f", fw.arr.cpu().numpy(), 2e-3 if prec == "f32" else 1e-8)
+    scalars_close("golden cg_res", [h[1][0] for h in hist], z["cg_res"], rtol=1e-5 if prec == "f32" else 1e-7)   # 3.4e-6
+    check_sample(z, "cg_f", fw.arr.cpu().numpy(), 3.7e-6 if prec == "f32" else 1e-8)                          # 1.3e-6

@@ -43,7 +43,7 @@ def test_lenseflow_gradient(camb, prec, Ny, Nx, P, B, Bphi, mode):
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("Ny,Nx,P", [(36, 60, 2), (45, 27, 1)])
 def test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P):
-    TP.test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P)
+    TP.test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P, tol32=6.5e-5)          # any-size path, fp32: measured 2.2e-5
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -87,9 +87,10 @@ def test_anysize_path_equals_fused_path(camb, prec):
         gdp, gdf, gf0 = L.gradient(C.FLOW_FWD, Lf, F(delta, C.FOURIER))
         res[force] = [x.cpu().numpy() for x in (p.rfft(p.tensor(f)), Lf.arr, L.ldiv(F(f, C.MAP)).arr, (L.adjoint * F(g, C.MAP).to(C.FOURIER)).arr,
                                                 gdp.arr, gdf.arr, gf0.arr)]
-    tol = TOL[prec]["flow"] if prec == "f32" else 1e-11            # fp32: each side is within 5e-5 of the float64 oracle
+    # fp32: two single-precision implementations against each other; measured rfft 2e-7, L*f 3.4e-6, L'g / df 2.2e-5, dphi 5e-5
+    t32 = {"rfft": 6e-7, "L*f": 1.1e-5, "L\\f": 1.1e-5, "L'g": 6.5e-5, "dphi": 1.5e-4, "df": 6.5e-5, "f0": 1.2e-6}
     for name, a, b in zip(("rfft", "L*f", "L\\f", "L'g", "dphi", "df", "f0"), res["0"], res["1"]):
-        close(name, a, b, tol * (10 if name == "dphi" else 1))
+        close(name, a, b, t32[name] if prec == "f32" else (1e-10 if name == "dphi" else 1e-11))
 
 
 def test_largest_row_length_double_precision(camb):
@@ -101,30 +102,38 @@ def test_largest_row_length_double_precision(camb):
     # lowest lx modes deflect by many pixels and the flow amplifies rounding to 1e-3, tools/gpu_size_probe.py)
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("B,Bphi", [(1, 1), (2, 1), (2, 2)])
 @pytest.mark.parametrize("Ny,Nx", [(96, 160), (51, 38)])
-def test_stage_fusions_equal_the_plain_pass_structure(camb, monkeypatch, Ny, Nx):
-    """The any-size stages in their three forms -- the reference's pass structure (CMBL_GEN_SEPARABLE=0), the separable form with the
-    d/dx pass as two launches and the pointwise work in its own kernels (CMBL_GEN_XDERIV_FUSED=0, CMBL_GEN_PROLOGUE=0), and the default
+def test_stage_fusions_equal_the_plain_pass_structure(camb, Ny, Nx, B, Bphi, prec):
+    """The any-size stages in their three forms -- the reference's pass structure (option gen_separable = 0), the separable form with the
+    d/dx pass as two launches and the pointwise work in its own kernels (gen_xderiv_fused = 0, gen_prologue = 0), and the default
     (one-launch d/dx pass, pointwise work in the fetch of the consuming transform) -- are the same computation: flows and gradient flow
-    agree to rounding in double precision.  (51 x 38 runs chirp-z transforms, which have no one-launch d/dx pass.)"""
+    agree to rounding.  (51 x 38 runs chirp-z transforms, which have no one-launch d/dx pass; 96 x 160 the mixed-radix kernel: both
+    axis kernels carry the fetch-side prologue, whose state writes -- RK update of y0 / acc, per-stage products -- rely on every element
+    being fetched exactly once per launch, kernels_generic.hpp `gen_fetch`: a double fetch would apply the update twice and show
+    here at once.  B = 2 with one shared phi exercises the phi broadcast of the prologue.)"""
     C = _pkg()
     P, n = 2, 7
-    proj, simf, simp = sims(camb, Ny, Nx, P, 1)
-    f, g, phi = simf(1), simf(11), simp(2)
-    p = C.ProjLambert(Ny, Nx, 2.0, torch.float64)
+    tT, nT = DT[prec]
+    proj, simf, simp = sims(camb, Ny, Nx, P, B)
+    rnd = lambda a: a.astype(nT).astype(np.float64)
+    f, g, phi = rnd(simf(1)), rnd(simf(11)), rnd(simp(2, Bphi))
+    gl = O.rfft2(g).astype(np.complex64 if prec == "f32" else np.complex128).astype(np.complex128)
+    p = C.ProjLambert(Ny, Nx, 2.0, tT)
     F = lambda a, b: C.Field(p, p.tensor(a), b)
 
     def run():
         L = C.LenseFlow(p, n)(F(phi, C.MAP))
         Lf = L * F(f, C.MAP)
-        dp, df, f0 = L.gradient(C.FLOW_FWD, Lf, F(O.rfft2(g), C.FOURIER))
-        return [x.arr.cpu().numpy() for x in (Lf, L.adjoint * F(O.rfft2(g), C.FOURIER), dp, df, f0)]
+        dp, df, f0 = L.gradient(C.FLOW_FWD, Lf, F(gl, C.FOURIER))
+        return [x.arr.cpu().numpy() for x in (Lf, L.adjoint * F(gl, C.FOURIER), dp, df, f0)]
     ref = run()
-    for env in (dict(CMBL_GEN_SEPARABLE="0"), dict(CMBL_GEN_XDERIV_FUSED="0", CMBL_GEN_PROLOGUE="0"), dict(CMBL_GEN_PROLOGUE="0")):
+    for env in (dict(gen_separable=0), dict(gen_xderiv_fused=0, gen_prologue=0), dict(gen_prologue=0)):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            p.set_option(k, v)
         got = run()
         for k in env:
-            monkeypatch.delenv(k)
-        for a, b in zip(got, ref):
-            close(env, a, b, 1e-12)
+            p.set_option(k, 1)
+        for name, a, b in zip(("L*f", "L'g", "dphi", "df", "f0"), got, ref):
+            close((name, env), a, b, 1e-12 if prec == "f64" else (2e-4 if name == "dphi" else 3e-5))

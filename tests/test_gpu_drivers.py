@@ -34,7 +34,7 @@ def test_quadratic_estimate(prec, pol, which):
     pq, AL, Nphi = O.quadratic_estimate(so["proj"], which, dd, dd, planes(ods.Cf), planes(ods.Cftilde), planes(ods.Cn), ods.Cphi, TF)
     got = C.quadratic_estimate(ds, which)
     m = ods.Cphi > 0
-    np.testing.assert_allclose(got["AL"][m], AL[m], rtol=2e-3 if prec == "f32" else 1e-9)
+    scalars_close("QE normalisation AL", got["AL"][m], AL[m], rtol=2e-3 if prec == "f32" else 1e-9)
     close("got['phiqe'].arr.cpu().numpy()", got["phiqe"].arr.cpu().numpy(), pq, (2e-3 if prec == "f32" else 1e-9))
     # it is an estimate of ϕ: correlates with the truth
     phi = so["phi"]
@@ -74,7 +74,7 @@ def test_map_joint_step(prec, pol):
     close("st_g['dphi'].arr.cpu().numpy()", st_g["dphi"].arr.cpu().numpy(), st_o["dphi"], tol)
     # Brent (ours) vs SciPy's bounded Brent (oracle): same minimiser within the tolerance, same objective value
     assert abs(st_g["alpha"] - st_o["alpha"]) < 5e-3, (st_g["alpha"], st_o["alpha"])
-    np.testing.assert_allclose(st_g["logpdf"], st_o["logpdf"], rtol=2e-5)
+    scalars_close("MAP_joint step logpdf", st_g["logpdf"], st_o["logpdf"], rtol=2e-5)
     assert st_g["logpdf"][0] > st_g["logpdf_before"][0]
     close("st_g['phi'].arr.cpu().numpy()", st_g["phi"].arr.cpu().numpy(), st_o["phi"], 2e-2)
     # two more steps keep increasing the posterior and approach the true ϕ
@@ -109,8 +109,8 @@ def test_hmc_and_gibbs_step(prec, pol):
     f_g, _ = C.sample_f(ds, F(so["phi"], C.FOURIER), wf, wn, tol=0.0, nsteps=6)
     close("f_g.arr.cpu().numpy()", f_g.arr.cpu().numpy(), f_o, (2e-3 if prec == "f32" else 1e-8))
     # unmixed logpdf (gibbs_postprocess!, src/sampling.jl:455-464)
-    np.testing.assert_allclose(ds.logpdf(F(so["f"], C.HARMONIC), F(so["phi"], C.FOURIER)), ods.logpdf(so["f"], so["phi"]),
-                               rtol=2e-5 if prec == "f32" else 1e-10)
+    scalars_close("logpdf", ds.logpdf(F(so["f"], C.HARMONIC), F(so["phi"], C.FOURIER)), ods.logpdf(so["f"], so["phi"]),
+                  rtol=2e-5 if prec == "f32" else 1e-10)
     st = C.gibbs_step(ds, F(so["phi"], C.FOURIER), wf, wn, wp, logu, N=3, eps=0.01)
     assert np.all(np.isfinite(st["logpdf"])) and st["f"].arr.shape == (B, P, Nx, Ny // 2 + 1)
 
@@ -237,7 +237,7 @@ def test_gradientphi_and_map_marg(prec, pol):
     assert [len(t["ncg"]) for t in tr_g] == [3, 1][:nst]
     close("tr_g[0]['phi'].arr.cpu().numpy()", tr_g[0]["phi"].arr.cpu().numpy(), tr_o[0]["phi"], (2e-3 if prec == "f32" else 1e-7))
     close("phi_g.arr.cpu().numpy()", phi_g.arr.cpu().numpy(), phi_o, (2e-3 if prec == "f32" else 1e-7))
-    np.testing.assert_allclose([t["g_norm"] for t in tr_g], [t["g_norm"] for t in tr_o], rtol=2e-3 if prec == "f32" else 1e-7)
+    scalars_close("MAP_marg gradient norms", [t["g_norm"] for t in tr_g], [t["g_norm"] for t in tr_o], rtol=2e-3 if prec == "f32" else 1e-7)
 
 
 def test_map_marg_device_rng_converges():

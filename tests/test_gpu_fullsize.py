@@ -95,7 +95,7 @@ def test_fullsize_posterior_step():
 @pytest.mark.parametrize("P,B,Bphi", [(2, 1, 1), (3, 1, 1), (2, 2, 2), (1, 4, 1), (2, 3, 3)])
 def test_slice_streams_give_identical_results(P, B, Bphi):
     """Pol slices (B = 1) or groups of batch slots (B > 1) run as separate launch chains on separate streams (Flow::groups); they are
-    independent, so the results must be bit-identical to one launch over all slices (CMBL_SLICE_STREAMS=1) -- any difference would
+    independent, so the results must be bit-identical to one launch over all slices (option slice_streams = 1) -- any difference would
     be a race or a wrong phi-slot offset."""
     import os
     import cmblensing_jl_amd as C
@@ -113,17 +113,14 @@ def test_slice_streams_give_identical_results(P, B, Bphi):
         dphi, df, fs = L.gradient(C.FLOW_FWD, a, gl)
         torch.cuda.synchronize()
         return [x.arr.clone() for x in (a, b, c, dphi, df, fs)]
-    old = os.environ.get("CMBL_SLICE_STREAMS")
+    old = proj.get_option("slice_streams")
     try:
-        os.environ.pop("CMBL_SLICE_STREAMS", None)
+        proj.set_option("slice_streams", 4)
         r_split = [run() for _ in range(3)]
-        os.environ["CMBL_SLICE_STREAMS"] = "1"
+        proj.set_option("slice_streams", 1)
         r_one = run()
     finally:
-        if old is None:
-            os.environ.pop("CMBL_SLICE_STREAMS", None)
-        else:
-            os.environ["CMBL_SLICE_STREAMS"] = old
+        proj.set_option("slice_streams", old)
     for r in r_split:
         for x, y in zip(r, r_one):
             assert torch.equal(x, y)
@@ -146,10 +143,10 @@ def test_p_cache_matches_on_the_fly_p():
         torch.cuda.synchronize()
         return [x.arr.clone() for x in (a, c, dphi, df, fs)]
     try:
-        os.environ["CMBL_NO_PCACHE"] = "1"
+        proj.set_option("pcache", 0)               # read when phi is set (cmbl_lenseflow_set_phi)
         r0 = run()
     finally:
-        os.environ.pop("CMBL_NO_PCACHE", None)
+        proj.set_option("pcache", 1)
     r1 = run()
     for x, y in zip(r0, r1):
         assert float((x - y).abs().max() / y.abs().max()) < 2e-6

@@ -18,8 +18,11 @@ from oracle.lenseflow import LenseFlow as OLenseFlow
 from _tol import close, scalars_close
 from bench import synthetic_cls
 
-# fp32 tolerances = 3 x the largest error measured on MI355X at these sizes (profiles/r04_parity_measured.txt)
-TOL_LP, TOL_GF, TOL_GP = 2e-5, 6e-5, 2e-4
+# fp32 tolerances = 3 x the error measured on MI355X at these sizes (profiles/r04_parity_measured.txt): logpdf 9.0e-9 / 1.8e-8,
+# ∇f° 2.0e-6 / 4.1e-5, ∇ϕ° 2.5e-7 / 3.2e-6 for QU / T+QU (the T+QU f-gradient carries the TE block's cancellations)
+TOL_LP = 5e-8
+TOL_GF = {"P": 6e-6, "IP": 1.2e-4}
+TOL_GP = {"P": 7.5e-7, "IP": 9.5e-6}
 
 
 @pytest.mark.parametrize("pol", ["P", "IP"])
@@ -38,8 +41,8 @@ def test_grad_logpdf_mixed_1024_fp32_vs_oracle(pol):
         olp, ogf, ogp = ods.grad_logpdf_mixed(fo.arr.cpu().numpy().astype(np.float64), po.arr.cpu().numpy().astype(np.complex128), alias_quirk=quirk)
         scalars_close(f"logpdf(Mixed) 1024² {pol}", lp, olp, rtol=TOL_LP)
         scalars_close(f"logpdf(Mixed) 1024² {pol}, logpdf-only call", lp2, olp, rtol=TOL_LP)
-        close(f"∇f° 1024² {pol} quirk={quirk}", gf.arr.cpu().numpy(), ogf, TOL_GF)
-        close(f"∇ϕ° 1024² {pol} quirk={quirk}", gp.arr.cpu().numpy(), ogp, TOL_GP)
+        close(f"∇f° 1024² {pol} quirk={quirk}", gf.arr.cpu().numpy(), ogf, TOL_GF[pol])
+        close(f"∇ϕ° 1024² {pol} quirk={quirk}", gp.arr.cpu().numpy(), ogp, TOL_GP[pol])
 
 
 def test_lenseflow_and_pullback_2048_fp64_n10_vs_oracle():
@@ -58,11 +61,11 @@ def test_lenseflow_and_pullback_2048_fp64_n10_vs_oracle():
     L = C.LenseFlow(p, n)(F(phi, C.MAP))
     want = OL.apply(f)
     got = L * F(f, C.MAP)
-    close("L*f 2048² QU fp64 n=10", got.arr.cpu().numpy(), want, 1e-11)
+    close("L*f 2048² QU fp64 n=10", got.arr.cpu().numpy(), want, 1e-12)                       # measured 6.7e-14
     gl = O.rfft2(g)
-    close("L'g 2048² QU fp64 n=10", (L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy(), OL.adj(gl), 1e-11)
+    close("L'g 2048² QU fp64 n=10", (L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy(), OL.adj(gl), 1.3e-12)   # 4.2e-13
     f0, df, dp = OL.grad_apply(want, gl)
     gdp, gdf, gf0 = L.gradient(C.FLOW_FWD, F(want, C.MAP), F(gl, C.FOURIER), alias_quirk=False)
-    close("pullback f 2048²", gf0.arr.cpu().numpy(), f0, 1e-11)
-    close("pullback δf 2048²", gdf.arr.cpu().numpy(), df, 1e-11)
-    close("pullback δϕ 2048²", gdp.arr.cpu().numpy(), dp, 1e-10)
+    close("pullback f 2048²", gf0.arr.cpu().numpy(), f0, 1e-12)                               # 6.7e-14
+    close("pullback δf 2048²", gdf.arr.cpu().numpy(), df, 1.3e-12)                            # 4.2e-13
+    close("pullback δϕ 2048²", gdp.arr.cpu().numpy(), dp, 2.3e-12)                            # 7.6e-13

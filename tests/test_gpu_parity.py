@@ -1,8 +1,11 @@
 """GPU parity: every C-ABI entry point of libcmblens_hip.so against the NumPy oracle on identical inputs.
 
-Tolerances (relative L2 per field, vs the oracle run in the SAME precision class noted):
-    fp64: 1e-10 single transforms / pointwise, 1e-9 flows and gradients (vs float64 oracle)
-    fp32: 2e-6 transforms, 5e-5 flows, 2e-4 gradient flows            (vs float64 oracle on the fp32-rounded inputs)
+Tolerances (relative L2 per field; fp32 against the float64 oracle on the fp32-rounded inputs).  Two layers (tests/_tol.py):
+  * the class bounds in TOL below = 3 x the LARGEST error that class showed on MI355X (profiles/r04_parity_measured.txt):
+      fp32: transforms 5e-7 -> 1.5e-6; forward-type flows (L*f, L\f, the f part of a pullback) 6e-6 -> 2e-5; adjoint-type flows (L'g, L'\g,
+            the δf part: Fourier-space state, 7x less accurate) 2.3e-5 (3.4e-5 on the any-size path) -> 5e-5 / 1e-4; δϕ 5.8e-5 (7.3e-5) -> 1.8e-4
+      fp64: 1e-12 transforms / pointwise, 1e-10 flows, 1e-9 gradients (measured 1e-16..3e-11; the largest are the 4096-point rows)
+  * every single comparison is additionally held to 3 x ITS OWN measured error (tests/golden/parity_measured.json).
 """
 import numpy as np
 import pytest
@@ -23,7 +26,8 @@ from _tol import close, rel, scalars_close            # assertions that log what
 
 
 DT = {"f32": (torch.float32, np.float32), "f64": (torch.float64, np.float64)}
-TOL = {"f32": dict(fft=2e-6, flow=5e-5, grad=3e-4, cg=2e-3), "f64": dict(fft=1e-12, flow=1e-10, grad=1e-9, cg=1e-7)}
+LPTOL = {"f32": 5e-8, "f64": 1e-10}      # logpdf: fp32 terms, float64 sums; measured 1.3e-8 (64²) .. 1.8e-8 (1024² T+QU)
+TOL = {"f32": dict(fft=1.5e-6, flow=2e-5, adj=5e-5, grad=1.8e-4, cg=1e-3), "f64": dict(fft=1e-12, flow=1e-10, adj=1e-10, grad=1e-9, cg=1e-7)}
 
 
 @pytest.fixture(scope="module")
@@ -141,9 +145,9 @@ def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi, n):
     close("L\\f", out, OL.inv(f), tol)
     gl = O.rfft2(g)
     out = (L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy()
-    close("L'*g", out, OL.adj(gl), tol)
+    close("L'*g", out, OL.adj(gl), TOL[prec]["adj"])
     out = L.adjoint.ldiv(F(gl, C.FOURIER)).arr.cpu().numpy()
-    close("L'\\g", out, OL.invadj(gl), tol)
+    close("L'\\g", out, OL.invadj(gl), TOL[prec]["adj"])
     # basis plumbing: harmonic in, map out == explicit conversion
     fh = O.to_harm(oproj, f)
     out = L._apply(C.FLOW_FWD, F(fh, C.HARMONIC), C.HARMONIC).arr.cpu().numpy()
@@ -151,7 +155,7 @@ def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi, n):
     # adjoint identity on the device itself (test/runtests.jl:556,570)
     lhs = p.dot(p.tensor(f), (L * F(g, C.MAP)).arr, C.MAP)
     rhs = (L.adjoint * F(O.rfft2(f), C.FOURIER)).dot(F(gl, C.FOURIER))
-    scalars_close("adjoint identity", lhs, rhs, rtol=2e-4 if prec == "f32" else 1e-10)
+    scalars_close("adjoint identity", lhs, rhs, rtol=6e-6 if prec == "f32" else 1e-10)                # measured 1.8e-6
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -175,7 +179,7 @@ def test_lenseflow_gradient(camb, prec, Ny, Nx, P, B, Bphi, mode, n):
         f0, df, dp = (OL.grad_apply if mode == "fwd" else OL.grad_inv)(fe, delta, alias_quirk=quirk)
         gdp, gdf, gf0 = L.gradient(C.FLOW_FWD if mode == "fwd" else C.FLOW_INV, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=quirk)
         close(("f", quirk), gf0.arr.cpu().numpy(), f0, TOL[prec]["flow"])
-        close(("df", quirk), gdf.arr.cpu().numpy(), df, TOL[prec]["flow"])
+        close(("df", quirk), gdf.arr.cpu().numpy(), df, TOL[prec]["adj"])
         close(("dphi", quirk), gdp.arr.cpu().numpy(), dp, TOL[prec]["grad"])
     # the two variants must differ (the flag is live)
     a = L.gradient(C.FLOW_FWD, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=False)[0].arr
@@ -193,7 +197,7 @@ def test_lenseflow_gradient_many_steps(camb, prec):
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("Ny,Nx,P", [(32, 32, 1), (64, 32, 2), (32, 64, 3)])
-def test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P):
+def test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P, tol32=2.5e-5):
     """Independent known answer (tests/_known.py, no oracle involved): L(ϕ)*f = f(x + ∇ϕ(x)) by direct Fourier summation.
     Pins the deflection sign / axis conventions, which the reference's self-consistency properties cannot see."""
     from _known import bandlimited, remap_exact, deflection
@@ -208,7 +212,7 @@ def test_lenseflow_is_the_exact_remap(prec, Ny, Nx, P):
     wrong, _ = remap_exact(f, phi, theta, -1.0)
     p = C.ProjLambert(Ny, Nx, theta, tT)
     F = lambda a, b: C.Field(p, p.tensor(a), b)
-    tol = 5e-5 if prec == "f32" else 3e-5                                # fp64 floor 3e-6..8e-6 = aliasing of the lensed field
+    tol = tol32 if prec == "f32" else 2.5e-5                             # fp64 floor 3e-6..8e-6 = aliasing of the lensed field; fp32 measured 8.3e-6
     for n in (7, 10):
         L = C.LenseFlow(p, n)(F(phi[None, None], C.MAP))
         got = (L * F(f, C.MAP)).arr.cpu().numpy()
@@ -240,9 +244,9 @@ def test_dataset_gradientf_and_wiener(prec, pol, Nside, mask):
     ods, ds, p = so["ds"], sd["ds"], sd["proj"]
     tol = TOL[prec]
     # the simulated fields agree (same PCG64 seeds, same operators)
-    close("sd['f'].arr.cpu().numpy()", sd["f"].arr.cpu().numpy(), so["f"], tol["fft"] * 10 + 1e-6 * (prec == "f32"))
-    close("sd['phi'].arr.cpu().numpy()", sd["phi"].arr.cpu().numpy(), so["phi"], tol["fft"] * 10 + 1e-6 * (prec == "f32"))
-    close("sd['d'].arr.cpu().numpy()", sd["d"].arr.cpu().numpy(), so["d"], tol["flow"])
+    close("simulated f", sd["f"].arr.cpu().numpy(), so["f"], 8e-7 if prec == "f32" else 1e-11)               # measured 2.4e-7
+    close("simulated phi", sd["phi"].arr.cpu().numpy(), so["phi"], 5e-7 if prec == "f32" else 1e-11)           # 1.4e-7
+    close("simulated d", sd["d"].arr.cpu().numpy(), so["d"], 2.5e-6 if prec == "f32" else 1e-10)               # 7.1e-7
     # run both sides from the ORACLE's fields so that only the operator under test differs
     F = lambda a, b: C.Field(p, p.tensor(a), b)
     f, phi, d = so["f"], so["phi"], so["d"]
@@ -250,24 +254,25 @@ def test_dataset_gradientf_and_wiener(prec, pol, Nside, mask):
     OL = ods.L(phi)
     want = ods.gradientf_logpdf(f, OL, d)
     got = ds.gradientf_logpdf(F(f, C.HARMONIC), F(phi, C.FOURIER))
-    close("gradientf_logpdf", got.arr.cpu().numpy(), want, tol["flow"] * 4)
+    close("gradientf_logpdf", got.arr.cpu().numpy(), want, 1e-4 if prec == "f32" else 4e-10)                  # measured 3.4e-5
     # Wiener filter: same tolerance-based stop; compare solution and history loosely, tight solve tightly
     fw_o, h_o = ods.argmaxf_logpdf(phi, tol=1e-1, nsteps=500)
     fw_g, h_g = ds.argmaxf_logpdf(F(phi, C.FOURIER), tol=1e-1, nsteps=500)
     # iteration count depends on round-off (SURVEY §7 'CG reproducibility'): ±1 in fp64, within 5 % in fp32
     assert abs(len(h_g) - len(h_o)) <= (1 if prec == "f64" else max(2, len(h_o) // 20)), (len(h_g), len(h_o))
     n = min(len(h_g), len(h_o)) - 1
-    scalars_close("cg first residual", h_g[0][1], h_o[0][1], rtol=1e-3 if prec == "f32" else 1e-8)
-    scalars_close("cg mid-run residual", h_g[n // 2][1], h_o[n // 2][1], rtol=5e-2 if prec == "f32" else 1e-5)
+    scalars_close("cg first residual", h_g[0][1], h_o[0][1], rtol=2e-6 if prec == "f32" else 1e-8)            # measured 5.9e-7
+    scalars_close("cg mid-run residual", h_g[n // 2][1], h_o[n // 2][1], rtol=9e-3 if prec == "f32" else 1e-5)   # measured 2.9e-3
     # hundreds of CG iterations amplify round-off (loss of conjugacy): converged solutions agree loosely ...
-    close("cg converged solution", fw_g.arr.cpu().numpy(), fw_o, (5e-3 if prec == "f32" else 1e-4))
+    close("cg converged solution", fw_g.arr.cpu().numpy(), fw_o, (3.9e-3 if prec == "f32" else 1e-4))       # measured 8.7e-4 (1.3e-3 any-size)
     # ... while a fixed, short run (no early stop) must agree tightly, iterate by iterate
     fw_o, h_o = ods.argmaxf_logpdf(phi, tol=0.0, nsteps=8)
     fw_g, h_g = ds.argmaxf_logpdf(F(phi, C.FOURIER), tol=0.0, nsteps=8)
+    cgtol = dict(res=1e-3, x=4e-6) if prec == "f32" else dict(res=1e-8, x=1e-9)          # fp32 measured: residuals 3.2e-4, iterate 1.4e-6
     assert len(h_g) == len(h_o) == 8
     for (i, r_g), (_, r_o) in zip(h_g, h_o):
-        scalars_close(("cg 8-step residual", i), r_g, r_o, rtol=2e-3 if prec == "f32" else 1e-8)
-    close("cg 8-step iterate", fw_g.arr.cpu().numpy(), fw_o, (3e-4 if prec == "f32" else 1e-9))
+        scalars_close(("cg 8-step residual", i), r_g, r_o, rtol=cgtol["res"])
+    close("cg 8-step iterate", fw_g.arr.cpu().numpy(), fw_o, cgtol["x"])
     # fstart (maximization.jl:26,37): restarting from the 8-step iterate continues to converge
     fw_g2, h_g2 = ds.argmaxf_logpdf(F(phi, C.FOURIER), fstart=fw_g, tol=1e-1, nsteps=500)
     assert h_g2[0][1][0] < h_g[0][1][0] and min(h[1][0] for h in h_g2) < h_g2[0][1][0]
@@ -290,17 +295,17 @@ def test_logpdf_mixed_and_gradient(prec, pol, Nside):
     check(ds.lib.cmbl_dataset_set_op(ds._h, 8, ctypes.c_void_p(ds.ops["G_inv"].data_ptr()), 1))
     fo, po = ods.mix(so["f"], so["phi"])
     gfo_d, gpo_d = ds.mix(F(so["f"], C.HARMONIC), F(so["phi"], C.FOURIER))
-    close("gfo_d.arr.cpu().numpy()", gfo_d.arr.cpu().numpy(), fo, TOL[prec]["flow"] * 2)
-    close("gpo_d.arr.cpu().numpy()", gpo_d.arr.cpu().numpy(), po, TOL[prec]["fft"] * 10 + 1e-6)
+    close("mix: f°", gfo_d.arr.cpu().numpy(), fo, 2.7e-6 if prec == "f32" else 2e-10)                       # measured 8.8e-7
+    close("mix: ϕ°", gpo_d.arr.cpu().numpy(), po, 2.1e-7 if prec == "f32" else 1e-11)                       # 6.9e-8
     lp_o = ods.logpdf_mixed(fo, po)
     lp_g = ds.logpdf_mixed(F(fo, C.MAP), F(po, C.FOURIER))
-    scalars_close("logpdf_mixed", lp_g, lp_o, rtol=2e-5 if prec == "f32" else 1e-10)
+    scalars_close("logpdf_mixed", lp_g, lp_o, rtol=LPTOL[prec])
     for quirk in (False, True):
         lp2, gf, gp = ods.grad_logpdf_mixed(fo, po, alias_quirk=quirk)
         lp3, gf_g, gp_g = ds.gradient_logpdf_mixed(F(fo, C.MAP), F(po, C.FOURIER), alias_quirk=quirk)
-        scalars_close("logpdf from the gradient call", lp3, lp2, rtol=2e-5 if prec == "f32" else 1e-10)
-        close(("grad f°", quirk), gf_g.arr.cpu().numpy(), gf, TOL[prec]["grad"])
-        close(("grad ϕ°", quirk), gp_g.arr.cpu().numpy(), gp, TOL[prec]["grad"] * 3)
+        scalars_close("logpdf from the gradient call", lp3, lp2, rtol=LPTOL[prec])
+        close(("grad f°", quirk), gf_g.arr.cpu().numpy(), gf, 2.8e-5 if prec == "f32" else 1e-9)             # measured 9.3e-6
+        close(("grad ϕ°", quirk), gp_g.arr.cpu().numpy(), gp, 6e-6 if prec == "f32" else 3e-9)               # 2.0e-6
 
 
 def test_errors_are_status_codes():

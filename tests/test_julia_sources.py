@@ -7,7 +7,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = [os.path.join(ROOT, "julia", f) for f in ("CMBLensingHIPExt.jl", "make_reference_fixtures.jl")]
+FILES = [os.path.join(ROOT, "julia", f) for f in ("CMBLensingHIPExt.jl", "make_reference_fixtures.jl", "test_hipext.jl")]
 OPENERS = {"function", "struct", "if", "for", "while", "let", "do", "begin", "module", "try", "quote", "macro"}
 IDENT = re.compile("[A-Za-z_-￿][\\w-￿!]*|[()\\[\\]{}]")
 
