@@ -3,15 +3,22 @@
 Mirrors the reference's on-disk structure (src/sampling.jl:230-256,311-320; src/chains.jl:48-100): one file holding `rundat`
 (the run's settings) and numbered chunks `chunks_1, chunks_2, ...`; a chunk is, per chain, the list of samples since the
 previous write; a sample is a dict of scalars (every step) plus maps (first step, every `nsavemaps`-th step, and -- so that a
-resumed run continues exactly -- the last step of every chunk).  The reference stores this in JLD2 (an HDF5 dialect); the container written here is a plain zip archive whose members are `.npy`
-arrays, `chunks_<k>/chain<c>/<i>/<key>.npy`, appended in place chunk by chunk.
+resumed run continues exactly -- the last step of every chunk).  Two containers, chosen by the file name's extension:
 
-Compatibility with the reference's files: `load_chains`, `read_rundat`, `chunk_indices`, `read_chunk` and `last_state` also open a
-`.jld2` chain written by the Julia package (decoded by jld2.py: `rundat` + `chunks_k` = Vector{Vector{Any}} of Dict{Symbol,Any}
-states), so chains sampled with CMBLensing.jl can be analysed -- and resumed from -- here.  Field values (structs with `arr` and
-`metadata`) come back as their arrays in this package's axis order, NamedTuple θ as `theta_<name>` scalars, and the reference's
-keys are renamed to the ones used here (ϕ -> phi, ΔH -> dH, ...; unknown keys keep their Julia names).  This package does NOT write
-JLD2: a chain written here cannot be opened by the Julia `load_chains` (stated in DESIGN.md §1).
+  `.jld2`  the reference's own format (JLD2, an HDF5 dialect), written by jld2_writer.py: `rundat` and `chunks_k` =
+           Vector{Vector{Any}} of `Dict{Symbol,Any}` samples under the reference's key names (ϕ, f, lnP, ΔH, i, θ), appended like
+           `jldopen(filename, "a+")`.  Maps are stored as plain arrays, not as `BaseField` structs (jld2_writer.py says why), and
+           the file has never been opened by JLD2.jl itself (no Julia in the build image): the format follows the reference's own
+           data file structure by structure and round-trips through the reader here.
+  `.zip`   a plain zip archive whose members are `.npy` arrays, `chunks_<k>/chain<c>/<i>/<key>.npy`, appended in place.
+
+Reading: `load_chains`, `read_rundat`, `chunk_indices`, `read_chunk` and `last_state` open both, including `.jld2` chains written by
+the Julia package itself (decoded by jld2.py).  Field values (structs with `arr` and `metadata`) come back as their arrays in this
+package's axis order, NamedTuple θ as `theta_<name>` scalars, and the reference's keys are renamed to the ones used here (ϕ -> phi,
+ΔH -> dH, ...; unknown keys keep their Julia names).  A chain file the Julia package wrote is READ-ONLY here: analyse it with
+`load_chains`, or continue it in a NEW file with `sample_joint(filename=new, resume=path_of_the_jld2)` -- `last_state` then converts
+what differs between the two: a Map-basis ϕ goes through rfft2, and the reference's step counter, which stores the initial state as
+step 1 (src/sampling.jl:268,277), is shifted to this package's (first Gibbs pass = step 1).
 """
 import io
 import json
@@ -22,6 +29,7 @@ import numpy as np
 
 EXT = ".zip"
 JLD2_EXT = ".jld2"
+EXTS = (EXT, JLD2_EXT)
 # reference state keys (src/sampling.jl:388-464) -> the names this package's chain files use
 JLD2_KEYS = {"ϕ": "phi", "ϕ°": "phi_mixed", "f°": "f_mixed", "f̃": "ftilde", "ΔH": "dH", "lnP": "logpdf", "i": "step"}
 
@@ -45,7 +53,8 @@ def _jld2(filename):
 
 
 def _jld2_value(v):
-    """a decoded Julia value as a chain-sample entry: Field struct -> its array, scalars -> Python numbers"""
+    """a decoded Julia value as a chain-sample entry: Field struct -> its array, scalars -> Python numbers.  A Map-basis field
+    (`BaseField{Map,...}`: real array) stays real, a Fourier-basis one complex: `last_state` tells them apart by dtype."""
     if isinstance(v, dict):
         body = {k: x for k, x in v.items() if k != "__julia_type__"}
         if "arr" in body and "metadata" in body:                          # BaseField{B,M,T,A} (src/base_fields.jl:14-21)
@@ -78,18 +87,53 @@ def _get(z, name):
     return np.load(io.BytesIO(z.read(name)), allow_pickle=False)
 
 
+def written_by_julia(filename):
+    """a `.jld2` file that the Julia package wrote (as opposed to jld2_writer.py)"""
+    if not _is_jld2(filename):
+        return False
+    with open(filename, "rb") as fh:
+        return b" (cmblensing.jl_amd" not in fh.read(128)
+
+
 def check_filename(filename, resume):
-    """argument validation of src/sampling.jl:236-241"""
+    """argument validation of src/sampling.jl:236-241 (the reference accepts `.jld2` only; here also the `.zip` container)"""
     if filename is None:
         return
-    if os.path.splitext(filename)[1] != EXT:
-        raise ValueError(f"Chain filename '{filename}' should have '{EXT}' extension.")
+    if os.path.splitext(filename)[1] not in EXTS:
+        raise ValueError(f"Chain filename '{filename}' should have '{JLD2_EXT}' or '{EXT}' extension.")
     if os.path.isfile(filename) and resume is None:
         raise ValueError(f"'{filename}' exists so must specify `resume=True` or `resume=False`.")
+    if os.path.isfile(filename) and resume is True and written_by_julia(filename):
+        raise ValueError(f"'{filename}' was written by the Julia package and is read-only here: continue it in a new file with "
+                         f"`filename=<new file>, resume='{filename}'`.")
+
+
+_TO_JULIA = {v: k for k, v in JLD2_KEYS.items()}
+
+
+def _julia_sample(samp):
+    """sample dict with this package's key names -> the reference's (`theta_<name>` scalars fold into one θ entry)"""
+    out, theta = {}, {}
+    for k, v in samp.items():
+        if k.startswith("theta_"):
+            theta[k[6:]] = float(v)
+        else:
+            out[_TO_JULIA.get(k, k)] = v
+    if theta:
+        out["θ"] = theta
+    return out
 
 
 def write_chunk(filename, index, chains, rundat=None, clobber=False):
     """chains: list over chains of lists of sample dicts {key: scalar | ndarray}.  `clobber` starts a new file ("w" vs "a+")."""
+    if _is_jld2(filename):
+        from .jld2_writer import JLD2Writer
+        _jld2_open.clear()
+        with JLD2Writer(filename, "w" if clobber or not os.path.exists(filename) else "a") as w:
+            if "rundat" not in w:                                         # haskey(io, "rundat") || write(io, "rundat", ...)  (:313)
+                w.write("rundat", dict(rundat or {}))
+            w.write(f"chunks_{index}", [[_julia_sample(s) for s in ch] for ch in chains])
+        return
     with zipfile.ZipFile(filename, "w" if clobber else "a", compression=zipfile.ZIP_STORED) as z:
         if "rundat.json" not in z.namelist():
             z.writestr("rundat.json", json.dumps(rundat or {}, default=lambda o: np.asarray(o).tolist()))
@@ -203,7 +247,18 @@ def last_state(filename):
     ks = chunk_indices(filename)
     if not ks:
         raise ValueError(f"Can't resume chain which contains no samples: {filename}")
-    last = [c[-1] for c in read_chunk(filename, ks[-1])]
+    last = [dict(c[-1]) for c in read_chunk(filename, ks[-1])]
     if any("phi" not in s for s in last):
         raise ValueError(f"last sample of {filename} carries no maps")
-    return ks[-1] + 1, int(last[0]["step"]), last
+    step = int(last[0]["step"])
+    if written_by_julia(filename):
+        # what differs between the two packages: the basis a field was saved in (a Map-basis ϕ or f is a real array: transform it,
+        # NumPy (.., Nx, Ny) == Julia (Ny, Nx, ..) so the half-plane is the last axis) and the step counter (the reference stores the
+        # initial state as step 1, src/sampling.jl:268,277)
+        for s in last:
+            for k in ("phi", "f"):
+                if k in s and not np.iscomplexobj(s[k]):
+                    s[k] = np.fft.rfft2(np.asarray(s[k], float), axes=(-2, -1))
+            s["step"] = int(s["step"]) - 1
+        step -= 1
+    return ks[-1] + 1, step, last

@@ -414,11 +414,16 @@ def sample_joint(ds, nsamps_per_chain, chain_ids=(0,), base_seed=0, phi_start="p
     ntot = nchains_total if multi else B          # file / gather order: global chain id across ranks, position in a single process
     fidx = list(chain_ids) if multi else list(range(B))
     gdev = proj.device if multi and dist.get_backend() == "nccl" else "cpu"
-    CF.check_filename(filename, resume)
+    # resume: True / False / None as in the reference (:236-256), or the path of ANOTHER chain file (any readable format, e.g. a
+    # `.jld2` the Julia package wrote, which is read-only here) whose last state starts a new file `filename`
+    resume_src = resume if isinstance(resume, str) else None
+    CF.check_filename(filename, False if resume_src else resume)
     chunk_index, clobber, theta_resume = 1, True, None
-    if filename is not None and resume and os.path.isfile(filename):
-        chunk_index, first_step, last = CF.last_state(filename)
-        clobber = False
+    if resume_src is not None or (filename is not None and resume and os.path.isfile(filename)):
+        chunk_index, first_step, last = CF.last_state(resume_src or filename)
+        clobber = resume_src is not None
+        if resume_src is not None:
+            chunk_index = 1
         phi_start = Field(proj, proj.tensor(np.stack([last[c]["phi"] for c in fidx])[:, None]), FOURIER)
         theta_resume = {k[6:]: float(v) for k, v in last[fidx[0]].items() if k.startswith("theta_")}
     seeds = [chain_seed(base_seed, c) for c in chain_ids]

@@ -377,13 +377,14 @@ class JLD2File:
             if _is_bool(dt):
                 a = a.astype(bool)
             return a
-        if dt.cls == 6 and n > 16 and dt.members and all(m.cls in (0, 1) and m.np is not None for _, _, m in dt.members):
+        if dt.cls == 6 and dt.members and (n > 16 or [nm for nm, _, _ in dt.members] == ["re", "im"]) \
+                and all(m.cls in (0, 1) and m.np is not None for _, _, m in dt.members):
             # arrays of plain-number structs (ComplexF64 = {re, im} above all): one structured view instead of n dict decodes
             sd = np.dtype({"names": [nm for nm, _, _ in dt.members], "formats": [m.np for _, _, m in dt.members],
                            "offsets": [o for _, o, _ in dt.members], "itemsize": dt.size})
             a = np.frombuffer(raw, sd, n)
             if [nm for nm, _, _ in dt.members] == ["re", "im"]:
-                return a["re"] + 1j * a["im"]
+                return (a["re"] + 1j * a["im"]).astype(np.complex64 if a["re"].dtype == np.float32 else np.complex128)
             return a
         out = []
         for i in range(n):

@@ -29,7 +29,8 @@ def test_write_append_load(tmp_path):
     CF = _cf()
     fn = str(tmp_path / "chain.zip")
     with pytest.raises(ValueError):
-        CF.check_filename(str(tmp_path / "chain.jld2"), None)
+        CF.check_filename(str(tmp_path / "chain.h5"), None)            # `.jld2` (the reference's, src/sampling.jl:236-238) or `.zip`
+    CF.check_filename(str(tmp_path / "chain.jld2"), None)
     CF.check_filename(fn, None)
     CF.write_chunk(fn, 1, [_samples(c, range(1, 5)) for c in range(3)], rundat=dict(nchains=3, eps=0.01), clobber=True)
     with pytest.raises(ValueError):

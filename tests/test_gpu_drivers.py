@@ -257,16 +257,18 @@ def test_map_marg_device_rng_converges():
     close("phi1.arr.cpu().numpy()", phi1.arr.cpu().numpy(), phi8.arr.cpu().numpy(), 0.05)
 
 
-def test_sample_joint_chain_file_and_resume(tmp_path):
+@pytest.mark.parametrize("ext", [".zip", ".jld2"])
+def test_sample_joint_chain_file_and_resume(tmp_path, ext):
     """sample_joint(filename=...) writes chunks every nfilewrite steps; a run interrupted after 4 of 6 steps and resumed from the
-    file gives the same chain as the uninterrupted run (device RNG streams are indexed by step), and load_chains reads both."""
+    file gives the same chain as the uninterrupted run (device RNG streams are indexed by step), and load_chains reads both.  In
+    both containers: the package's zip of .npy and the reference's own JLD2 (src/sampling.jl:311-320; jld2_writer.py)."""
     import cmblensing_jl_amd as C
     from bench import synthetic_cls
     kw = dict(T=torch.float64, beam_fwhm=1.0, Nphi="flat")
     s = C.load_sim(3.0, (64, 64), "P", synthetic_cls(), Nbatch=2, **kw)
     ds = s["ds"]
     run = dict(chain_ids=(0, 1), base_seed=7, N=3, eps=0.01, rng="device", nfilewrite=2, nsavemaps=3)
-    fa, fb = str(tmp_path / "a.zip"), str(tmp_path / "b.zip")
+    fa, fb = str(tmp_path / ("a" + ext)), str(tmp_path / ("b" + ext))
     ra = C.sample_joint(ds, 6, filename=fa, **run)
     C.sample_joint(ds, 4, filename=fb, **run)
     with pytest.raises(ValueError):
@@ -284,6 +286,12 @@ def test_sample_joint_chain_file_and_resume(tmp_path):
     np.testing.assert_allclose(cb[1, -1]["phi"], ca[1, -1]["phi"], rtol=1e-8, atol=1e-14)
     np.testing.assert_allclose(ca[1, -1]["phi"], ra["phi"].arr[1, 0].cpu().numpy(), rtol=1e-12)
     assert C.load_chains(fa, thin="hasmaps")["step"].tolist() == [[1, 2, 3, 4, 6]] * 2
+    # a new file started from another file's last state (the way a chain the Julia package wrote is continued: read-only source)
+    fc = str(tmp_path / ("c" + ext))
+    C.sample_joint(ds, 4, filename=str(tmp_path / ("d" + ext)), **run)
+    rc = C.sample_joint(ds, 6, filename=fc, resume=str(tmp_path / ("d" + ext)), **run)
+    np.testing.assert_allclose(rc["logpdf"], ra["logpdf"][4:], rtol=1e-9)
+    assert C.load_chains(fc)["step"].tolist() == [[5, 6]] * 2
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -346,7 +354,7 @@ def test_sample_joint_theta_is_saved_and_resumed(tmp_path):
     ds = s["ds"]
     xs = np.linspace(0.5, 2.0, 10)
     run = dict(chain_ids=(0,), base_seed=5, N=3, eps=0.01, rng="device", theta_ranges=dict(Aphi=xs), nfilewrite=2, nsavemaps=2)
-    fa, fb = str(tmp_path / "a.zip"), str(tmp_path / "b.zip")
+    fa, fb = str(tmp_path / ("a" + ext)), str(tmp_path / ("b" + ext))
     ra = C.sample_joint(ds, 6, filename=fa, **run)
     C.set_theta(ds)
     C.sample_joint(ds, 4, filename=fb, **run)

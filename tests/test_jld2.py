@@ -116,7 +116,8 @@ def test_load_chains_opens_the_reference_container(tmp_path):
     assert len(CF.load_chains(p, join=True)) == 12 and len(CF.load_chains(p, thin="hasmaps")[0]) == 6
     assert "phi" not in CF.load_chains(p, dropmaps=True)[0][0]
     k, step, last = CF.last_state(p)                                                        # what resume=True continues from
-    assert (k, step) == (3, 6) and np.array_equal(last[1]["phi"], truth[(1, 6)][0])
+    # the reference stores the initial state as step 1 (src/sampling.jl:268,277): its step 6 is this package's step 5
+    assert (k, step) == (3, 5) and last[1]["step"] == 5 and np.array_equal(last[1]["phi"], truth[(1, 6)][0])
 
 
 def test_checksums_are_verified(tmp_path):
