@@ -1,5 +1,6 @@
 // C ABI of libcmblens_hip.so (see include/cmblens.h).  Single translation unit: all kernels are templates.
 #include "engine.hpp"
+#include "drivers.hpp"
 #include "../../include/cmblens.h"
 
 namespace cmbl { thread_local std::string g_last_error; }
@@ -7,7 +8,11 @@ using namespace cmbl;
 
 struct cmbl_ctx { std::unique_ptr<CtxBase> p; };
 struct cmbl_flow { cmbl_ctx* ctx; std::unique_ptr<Flow<float>> f32; std::unique_ptr<Flow<double>> f64; };
-struct cmbl_dataset { cmbl_ctx* ctx; std::unique_ptr<Dataset<float>> f32; std::unique_ptr<Dataset<double>> f64; };
+struct cmbl_dataset {
+  cmbl_ctx* ctx; std::unique_ptr<Dataset<float>> f32; std::unique_ptr<Dataset<double>> f64;
+  std::map<const void*, std::unique_ptr<Drivers<float>>> drv32;        // driver scratch per (dataset, flow) pair
+  std::map<const void*, std::unique_ptr<Drivers<double>>> drv64;
+};
 
 template <typename F>
 static int guard(F&& f) {
@@ -118,6 +123,65 @@ static void do_lpm(Dataset<T>& ds, Flow<T>& L, const void* fo, const void* phio,
   c->ref2F((const cx<T>*)phio, pF, B);
   ds.logpdf_mixed(L, (const T*)fo, pF, lp, (T*)gfo, gfo ? gF : nullptr, B, quirk != 0);
   if (gfo) c->F2ref(gF, (cx<T>*)gphio, B);
+  CMBL_HIP(hipStreamSynchronize(c->stream));
+}
+
+template <typename T> static Drivers<T>& drivers_of(std::map<const void*, std::unique_ptr<Drivers<T>>>& m, Dataset<T>& ds, Flow<T>& L) {
+  auto& p = m[&L];
+  if (!p) p = std::make_unique<Drivers<T>>(ds, L);
+  return *p;
+}
+template <typename T>
+static void do_hmc(Drivers<T>& dr, const void* fo, const void* phio, const void* mass, const void* white_p, const double* log_u, const uint64_t* seeds,
+                   uint64_t step, int nleap, double eps, int always, int quirk, int B, void* phio_out, double* dH, int* accept) {
+  Dataset<T>& ds = dr.ds;
+  Ctx<T>* c = ds.c;
+  const long pl = c->plane(), np = c->npix();
+  ds.cvt.ensure(sizeof(cx<T>) * 2 * B * pl + sizeof(T) * (pl + (long)B * np));
+  cx<T>* pF = ds.cvt.template as<cx<T>>(); cx<T>* oF = pF + (long)B * pl;
+  T* mF = reinterpret_cast<T*>(oF + (long)B * pl); T* w = mF + pl;
+  c->ref2F((const cx<T>*)phio, pF, B);
+  c->ref2F_real((const T*)mass, mF, 1);
+  const T* wp = (const T*)white_p;
+  if (!wp) {                                                             // randn!(rng, ...) with the drivers' stream convention (rng.py)
+    CMBL_REQUIRE(seeds != nullptr, ERR_ARG, "white_p == NULL needs seeds_host");
+    c->randn(w, seeds, B, stream_id(STREAM_P, step), np);
+    wp = w;
+  }
+  std::vector<double> lu(B);
+  for (int b = 0; b < B; ++b) {
+    if (log_u) lu[b] = log_u[b];
+    else { CMBL_REQUIRE(seeds != nullptr, ERR_ARG, "log_u_host == NULL needs seeds_host"); lu[b] = std::log(philox_uniform(seeds[b], stream_id(STREAM_U, step))); }
+  }
+  dr.hmc_step((const T*)fo, pF, mF, wp, lu.data(), nleap, eps, always != 0, quirk != 0, B, oF, dH, accept);
+  c->F2ref(oF, (cx<T>*)phio_out, B);
+  CMBL_HIP(hipStreamSynchronize(c->stream));
+}
+template <typename T>
+static void do_map_step(Drivers<T>& dr, const void* phi, const void* fstart, const void* hinv, double amax, double atol, double cg_tol, int cg_maxit, int quirk,
+                        int B, void* f_out, void* phi_out, double* logpdf, double* alpha, int* ncg, int* nls) {
+  Dataset<T>& ds = dr.ds;
+  Ctx<T>* c = ds.c;
+  const long pl = c->plane(), n = ds.fsize(B);
+  CMBL_REQUIRE(ds.Bd == B, ERR_SHAPE, "dataset data batch size differs from nbatch");
+  ds.cvt.ensure(sizeof(cx<T>) * (2 * B * pl + 2 * n) + sizeof(T) * 2 * pl);
+  cx<T>* pF = ds.cvt.template as<cx<T>>(); cx<T>* oF = pF + (long)B * pl; cx<T>* sF = oF + (long)B * pl; cx<T>* fF = sF + n;
+  T* hF = reinterpret_cast<T*>(fF + n); T* ones = hF + pl;
+  c->ref2F((const cx<T>*)phi, pF, B);
+  c->ref2F_real((const T*)hinv, hF, 1);
+  const cx<T>* fs = nullptr;
+  if (fstart) { c->ref2F((const cx<T>*)fstart, sF, (long)ds.P * B); fs = sF; }
+  // G = I for the duration of the step (src/maximization.jl:146), whatever G the dataset carries
+  std::vector<T> h1(pl, T(1));
+  CMBL_HIP(hipMemcpyAsync(ones, h1.data(), sizeof(T) * pl, hipMemcpyHostToDevice, c->stream));
+  CMBL_HIP(hipStreamSynchronize(c->stream));
+  struct Swap { const T*& slot; const T* old; ~Swap() { slot = old; } } sw{ds.ops[OP_G_INV].d[0], ds.ops[OP_G_INV].d[0]};
+  CMBL_REQUIRE(ds.ops[OP_G_INV].nplanes > 0, ERR_STATE, "a required dataset operator has not been set");
+  ds.ops[OP_G_INV].d[0] = ones;
+  std::vector<double> hist((size_t)cg_maxit * B);
+  dr.map_joint_step(pF, fs, hF, amax, atol, cg_tol, cg_maxit, quirk != 0, B, fF, oF, logpdf, alpha, ncg, nls, hist.data());
+  c->F2ref(fF, (cx<T>*)f_out, (long)ds.P * B);
+  c->F2ref(oF, (cx<T>*)phi_out, B);
   CMBL_HIP(hipStreamSynchronize(c->stream));
 }
 
@@ -420,6 +484,29 @@ int cmbl_grad_logpdf_mixed(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const
     NOTNULL(ds); NOTNULL(L); NOTNULL(fo); NOTNULL(phio); NOTNULL(lp); NOTNULL(gfo); NOTNULL(gphio); CMBL_REQUIRE(B >= 1, ERR_SHAPE, "nbatch >= 1");
     CMBL_REQUIRE(ds->ctx == L->ctx, ERR_ARG, "dataset and flow belong to different contexts");
     BY_DTYPE(ds->ctx, do_lpm<float>(*ds->f32, *L->f32, fo, phio, lp, gfo, gphio, B, quirk), do_lpm<double>(*ds->f64, *L->f64, fo, phio, lp, gfo, gphio, B, quirk));
+  });
+}
+
+int cmbl_hmc_step(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void* phio, const void* mass, const void* white_p, const double* log_u_host,
+                  const uint64_t* seeds_host, uint64_t step, int nleap, double eps, int always_accept, int alias_quirk, int B,
+                  void* phio_out, double* dH_host, int* accept_host) {
+  return guard([&] {
+    NOTNULL(ds); NOTNULL(L); NOTNULL(fo); NOTNULL(phio); NOTNULL(mass); NOTNULL(phio_out); NOTNULL(dH_host); NOTNULL(accept_host);
+    CMBL_REQUIRE(B >= 1 && B <= MAXBATCH && nleap >= 1, ERR_ARG, "1 <= nbatch <= 256 and nleap >= 1");
+    CMBL_REQUIRE(ds->ctx == L->ctx, ERR_ARG, "dataset and flow belong to different contexts");
+    BY_DTYPE(ds->ctx, do_hmc<float>(drivers_of(ds->drv32, *ds->f32, *L->f32), fo, phio, mass, white_p, log_u_host, seeds_host, step, nleap, eps, always_accept, alias_quirk, B, phio_out, dH_host, accept_host),
+             do_hmc<double>(drivers_of(ds->drv64, *ds->f64, *L->f64), fo, phio, mass, white_p, log_u_host, seeds_host, step, nleap, eps, always_accept, alias_quirk, B, phio_out, dH_host, accept_host));
+  });
+}
+int cmbl_map_joint_step(cmbl_dataset* ds, cmbl_flow* L, const void* phi, const void* fstart, const void* hinv, double alpha_max, double alpha_tol,
+                        double cg_tol, int cg_maxit, int alias_quirk, int B, void* f_out, void* phi_out, double* logpdf_host, double* alpha_host,
+                        int* ncg_host, int* nls_host) {
+  return guard([&] {
+    NOTNULL(ds); NOTNULL(L); NOTNULL(phi); NOTNULL(hinv); NOTNULL(f_out); NOTNULL(phi_out); NOTNULL(logpdf_host); NOTNULL(alpha_host); NOTNULL(ncg_host); NOTNULL(nls_host);
+    CMBL_REQUIRE(B >= 1 && B <= MAXBATCH && cg_maxit >= 1 && alpha_max > 0 && alpha_tol > 0, ERR_ARG, "1 <= nbatch <= 256, cg_maxit >= 1, alpha_max > 0, alpha_tol > 0");
+    CMBL_REQUIRE(ds->ctx == L->ctx, ERR_ARG, "dataset and flow belong to different contexts");
+    BY_DTYPE(ds->ctx, do_map_step<float>(drivers_of(ds->drv32, *ds->f32, *L->f32), phi, fstart, hinv, alpha_max, alpha_tol, cg_tol, cg_maxit, alias_quirk, B, f_out, phi_out, logpdf_host, alpha_host, ncg_host, nls_host),
+             do_map_step<double>(drivers_of(ds->drv64, *ds->f64, *L->f64), phi, fstart, hinv, alpha_max, alpha_tol, cg_tol, cg_maxit, alias_quirk, B, f_out, phi_out, logpdf_host, alpha_host, ncg_host, nls_host));
   });
 }
 

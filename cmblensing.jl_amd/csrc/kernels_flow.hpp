@@ -15,14 +15,6 @@
 #pragma once
 #include "kernels_fft.hpp"
 
-// A/B switches of the load order in the forward / adjoint column kernels (1: tile first, p(t) and the RK state after the tile's commit)
-#ifndef CMBL_FLOWY_LATE
-#define CMBL_FLOWY_LATE 0
-#endif
-#ifndef CMBL_ADJY_LATE
-#define CMBL_ADJY_LATE 0
-#endif
-
 namespace cmbl {
 
 
@@ -232,10 +224,11 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
   cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
   using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R], y0[R], acc[R];
-#if CMBL_FLOWY_LATE
+  // the pair tile alone gates the first transform: it is requested first and committed before p(t) and the RK state are asked for,
+  // which then fly during the transform (as in delta_y_body; A/B profiles/r04_ab_load_order.txt: L*f 0.564 -> 0.552 ms, CG iteration
+  // 1.341 -> 1.318 ms at 1024^2 QU.  The same order in k_adj_y, whose first transform is the short packed-real one, measured +1.5 %)
   twr.commit(tw);
   ps.template commit<LD>(s);
-#endif
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const unsigned e = PM::e(i);
@@ -243,10 +236,6 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
     y0[i] = at32(y0rp, e);
     acc[i] = a.rk.stage == 1 ? mk<T>(0, 0) : at32(accp, e);
   }
-#if !CMBL_FLOWY_LATE
-  twr.commit(tw);
-  ps.template commit<LD>(s);
-#endif
   __syncthreads();
   cx<T> fn[R], dx[R], dy[R];
   npt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, dx, dy);
@@ -294,19 +283,13 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   const size_t pbase = ((size_t)bphi * Nx + x0) * M;
   using PM = PairMap<R, NT, LGM>;
   cx<T> px[R], py[R];
-#if CMBL_ADJY_LATE
-  twr.commit(tw);
-  tl.template commit<LD>(s);
-#endif
 #pragma unroll
   for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase, (unsigned)PM::e(i), a.t, px[i], py[i]);
   T lyr[G::RZ];                                               // ly of this thread's half-spectrum entries (used after the last transform)
 #pragma unroll
   for (int i = 0; i < G::RZ; ++i) { const int e = threadIdx.x + i * NT; if (e < C * (M + 1)) lyr[i] = a.ly[e >> LGC]; }
-#if !CMBL_ADJY_LATE
   twr.commit(tw);
   tl.template commit<LD>(s);
-#endif
   __syncthreads();
   cx<T> yv[R];
   mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, yv);

@@ -354,6 +354,53 @@ def hmc_step(ds, fo, po, white_p, log_u, N=25, eps=0.01, always_accept=False, al
     return x, dH, accept
 
 
+def hmc_step_native(ds, fo, po, white_p=None, log_u=None, seeds=None, step=0, N=25, eps=0.01, always_accept=False, alias_quirk=None):
+    """The same update as `hmc_step`, as ONE library call (`cmbl_hmc_step`, include/cmblens.h): what a host that is neither Julia nor
+    Python calls.  white_p / log_u None: drawn inside the library from `seeds` (one key per batch slot) and `step`, with the stream ids
+    `sample_joint(rng="device")` uses.  Returns (ϕ°, ΔH, accept)."""
+    import ctypes
+    from .lib import check
+    proj = ds.proj
+    fo, po = fo.to(MAP), po.to(FOURIER)
+    B = fo.arr.shape[0]
+    alias_quirk = ds.alias_quirk if alias_quirk is None else alias_quirk
+    mass = proj.tensor(mass_matrix_phi(ds)[None, None]).contiguous()
+    wp = None if white_p is None else proj.tensor(white_p).contiguous()
+    lu = None if log_u is None else (ctypes.c_double * B)(*[float(x) for x in np.atleast_1d(log_u)])
+    sd = None if seeds is None else (ctypes.c_uint64 * B)(*[int(s) for s in seeds])
+    out = proj.empty(FOURIER, 1, B)
+    dH, acc = (ctypes.c_double * B)(), (ctypes.c_int * B)()
+    ds.L.invalidate()
+    ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    check(ds.lib.cmbl_hmc_step(ds._h, ds.L._h, ptr(fo.arr), ptr(po.arr), ptr(mass), ptr(wp), lu, sd, int(step), int(N), float(eps),
+                               1 if always_accept else 0, 1 if alias_quirk else 0, B, ptr(out), dH, acc))
+    return Field(proj, out, FOURIER), np.array(dH[:]), np.array(acc[:], bool)
+
+
+def MAP_joint_step_native(ds, phi, fstart=None, alpha_prev=1.0, alpha_tol=1e-4, alpha_max=None, cg_tol=1e-1, cg_nsteps=500, alias_quirk=None):
+    """The loop body of `MAP_joint_step` as ONE library call (`cmbl_map_joint_step`).  Returns dict(f, phi, alpha, logpdf, ncg, linesearch_evals)."""
+    import ctypes
+    from .lib import check
+    proj, h = ds.proj, ds.host
+    phi = phi.to(FOURIER)
+    B = ds.d.arr.shape[0]
+    alias_quirk = ds.alias_quirk if alias_quirk is None else alias_quirk
+    with np.errstate(divide="ignore"):
+        Hinv = 1 / (_pinv(h["Cphi"]) + _pinv(h["Nphi"]))                                       # dataset.jl:134-137
+    Hinv[~np.isfinite(Hinv)] = 0
+    hinv = proj.tensor(Hinv[None, None]).contiguous()
+    fs = None if fstart is None else fstart.to(HARMONIC).arr.contiguous()
+    f_out, phi_out = proj.empty(HARMONIC, ds.P, B), proj.empty(FOURIER, 1, B)
+    lp, alpha, ncg, nls = (ctypes.c_double * B)(), ctypes.c_double(0), ctypes.c_int(0), ctypes.c_int(0)
+    amax = 2 * alpha_prev if alpha_max is None else alpha_max
+    ds.L.invalidate()
+    ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    check(ds.lib.cmbl_map_joint_step(ds._h, ds.L._h, ptr(phi.arr), ptr(fs), ptr(hinv), float(amax), float(alpha_tol), float(cg_tol), int(cg_nsteps),
+                                     1 if alias_quirk else 0, B, ptr(f_out), ptr(phi_out), lp, ctypes.byref(alpha), ctypes.byref(ncg), ctypes.byref(nls)))
+    return dict(f=Field(proj, f_out, HARMONIC), phi=Field(proj, phi_out, FOURIER), alpha=alpha.value, logpdf=np.array(lp[:]) - ds.logdet_mix,
+                ncg=ncg.value, linesearch_evals=nls.value)
+
+
 def sample_f(ds, phi, white_f, white_n, fstart=None, tol=1e-1, nsteps=500):
     """`sample_f` (src/maximization.jl:56-62)"""
     proj, h = ds.proj, ds.host

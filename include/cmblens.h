@@ -223,6 +223,31 @@ int cmbl_logpdf_mixed(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void
 int cmbl_grad_logpdf_mixed(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void* phio, double* lp_host,
                            void* gfo, void* gphio, int nbatch, int alias_quirk);
 
+/* ---- loop bodies of the reference's drivers, for hosts that are neither Julia (which keeps src/maximization.jl:116-233 and
+ *      src/sampling.jl:388-464 itself on top of the entry points above) nor Python (cmblensing.jl_amd/drivers.py).  Control flow on the
+ *      host inside the library, every field operation one of the launches above; both return when their host outputs are final.
+ *
+ * hmc_step (src/sampling.jl:405-418; leapfrog = symplectic_integrate, :14-46): one HMC update of phi° at fixed f° with
+ *   U = logpdf(Mixed(ds)).  mass = Lambda, the real (Ny/2+1, Nx) plane of mass_matrix_phi (:422-425).  The momentum is
+ *   p0 = sqrt(Lambda) .* rfft(white_p), white_p a unit white-noise MAP (Ny, Nx, 1, nbatch); white_p == NULL draws it on the device and
+ *   log_u_host == NULL draws log(rand()) from the engine's counter-based generator with the stream convention of the Python drivers:
+ *   batch slot b uses key seeds_host[b], momentum stream 2 + 16 step, uniform stream 3 + 16 step (a chain is reproducible whatever
+ *   GPU or launch geometry runs it).  accept = always_accept || log_u < dH; a NaN dH (diverged trajectory) rejects.
+ *   phio_out (FOURIER, may alias phio) = accepted ? proposal : phio, per batch slot. */
+int cmbl_hmc_step(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void* phio, const void* mass, const void* white_p,
+                  const double* log_u_host, const uint64_t* seeds_host, uint64_t step, int nleap, double eps, int always_accept,
+                  int alias_quirk, int nbatch, void* phio_out, double* dH_host, int* accept_host);
+/* MAP_joint loop body (src/maximization.jl:160-206) with G = I as the reference sets it (:146; the dataset's own G is put back on
+ *   return): f = argmaxf_logpdf(phi; fstart, cg_tol, cg_maxit) [HARMONIC]; (f°, phi°) = mix(f, phi); g = d logpdf(Mixed) / d phi°;
+ *   step direction hinv .* g, hinv the real plane pinv(Cphi^-1 + Nphi^-1) (src/dataset.jl:134-137); alpha = argmin over [0, alpha_max]
+ *   of -sum_b logpdf(Mixed; f°, phi° + alpha * step) by Brent's method (abs_tol = alpha_tol, rel_tol = sqrt(eps(T)), a NaN logpdf is
+ *   penalised as (alpha / alpha_max) * floatmax(T), :194-199); phi_out = unmix(phi° + alpha * step).  One alpha for all batch slots.
+ *   Outputs: f_out HARMONIC (the Wiener-filtered f), phi_out FOURIER, logpdf_host[nbatch] at the new point, *alpha_host,
+ *   *ncg_host = CG iterations, *nls_host = logpdf evaluations of the line search. */
+int cmbl_map_joint_step(cmbl_dataset* ds, cmbl_flow* L, const void* phi, const void* fstart, const void* hinv, double alpha_max,
+                        double alpha_tol, double cg_tol, int cg_maxit, int alias_quirk, int nbatch, void* f_out, void* phi_out,
+                        double* logpdf_host, double* alpha_host, int* ncg_host, int* nls_host);
+
 #ifdef __cplusplus
 }
 #endif

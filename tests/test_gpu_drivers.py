@@ -345,7 +345,8 @@ def test_sample_joint_with_theta_pass():
     C.set_theta(ds)
 
 
-def test_sample_joint_theta_is_saved_and_resumed(tmp_path):
+@pytest.mark.parametrize("ext", [".zip", ".jld2"])
+def test_sample_joint_theta_is_saved_and_resumed(tmp_path, ext):
     """θ is part of every saved sample and a resumed θ chain continues the saved one (src/sampling.jl:226-228,247-256):
     4 + 2 resumed steps == 6 uninterrupted steps, and load_chains gives the θ posterior samples."""
     import cmblensing_jl_amd as C
@@ -432,3 +433,56 @@ def test_bandpower_theta_and_muse_adapter(prec):
     assert len(hist) == 2 and hist[1]["logpdf"][0] > hist[0]["logpdf"][0]
     assert abs(ds.d.arr - d.arr).max().item() == 0                      # the dataset's own data is restored
     C.set_theta(ds)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("pol", ["P", "IP"])
+def test_native_driver_exports_equal_the_python_drivers(prec, pol):
+    """`cmbl_hmc_step` / `cmbl_map_joint_step` (include/cmblens.h; the loop bodies of src/sampling.jl:405-418 and
+    src/maximization.jl:160-206 as ONE library call each, for hosts that are neither Julia nor Python) against the Python drivers,
+    which the tests above compare with the oracle: same launches in the same order, so agreement is to rounding -- and the library's own
+    draws (white_p / log_u = NULL) are the ones `sample_joint(rng="device")` makes."""
+    import cmblensing_jl_amd as C
+    from cmblensing_jl_amd import rng as R
+    from bench import synthetic_cls
+    T = torch.float32 if prec == "f32" else torch.float64
+    B = 2
+    s = C.load_sim(3.0, (64, 128), pol, synthetic_cls(), T=T, beam_fwhm=2.0, pixel_mask=dict(pad_deg=0.4, apod_deg=0.4), Nbatch=B, Nphi="flat")
+    ds, proj = s["ds"], s["proj"]
+    fo, po = ds.mix(s["f"], s["phi"])
+    rng = np.random.default_rng(5)
+    wp = rng.standard_normal((B, 1, proj.Nx, proj.Ny))
+    logu = np.log(rng.random(B))
+    tight = 2e-5 if prec == "f32" else 1e-10
+    # injected draws
+    x_p, dH_p, acc_p = C.hmc_step(ds, fo, po, wp, logu, N=4, eps=0.02)
+    x_n, dH_n, acc_n = C.hmc_step_native(ds, fo, po, white_p=wp, log_u=logu, N=4, eps=0.02)
+    close("native hmc_step: phi°", x_n.arr.cpu().numpy(), x_p.arr.cpu().numpy(), tight)
+    np.testing.assert_allclose(dH_n, dH_p, atol=(0.5 if prec == "f32" else 1e-6))       # ΔH: a difference of logpdfs ~ 1e6..1e7
+    assert acc_n.tolist() == acc_p.tolist()
+    # always_accept takes the proposal, a rejecting uniform keeps the start
+    x_a, _, acc_a = C.hmc_step_native(ds, fo, po, white_p=wp, log_u=np.full(B, 1e30), N=2, eps=0.02, always_accept=True)
+    x_r, _, acc_r = C.hmc_step_native(ds, fo, po, white_p=wp, log_u=np.full(B, 1e30), N=2, eps=0.02)
+    assert acc_a.all() and not acc_r.any() and torch.equal(x_r.arr, po.arr) and not torch.equal(x_a.arr, po.arr)
+    # the library's own draws = the device-RNG draws of sample_joint (rng.py stream ids)
+    seeds, step = [11, 12], 3
+    wdev = proj.randn(seeds, R.stream_id(R.STREAM_P, step), 1)
+    ludev = np.log(np.array([R.uniform(sd, R.stream_id(R.STREAM_U, step))[0] for sd in seeds]))
+    x_p2, dH_p2, acc_p2 = C.hmc_step(ds, fo, po, wdev, ludev, N=3, eps=0.02)
+    x_n2, dH_n2, acc_n2 = C.hmc_step_native(ds, fo, po, seeds=seeds, step=step, N=3, eps=0.02)
+    close("native hmc_step, library draws: phi°", x_n2.arr.cpu().numpy(), x_p2.arr.cpu().numpy(), tight)
+    assert acc_n2.tolist() == acc_p2.tolist()
+    # MAP_joint step
+    p0 = C.Field(proj, torch.zeros_like(po.arr), C.FOURIER)
+    st_p = C.MAP_joint_step(ds, p0, alpha_tol=1e-4, cg_tol=0.0, cg_nsteps=8)
+    Ginv_before = ds.ops["G_inv"].clone()
+    st_n = C.MAP_joint_step_native(ds, p0, alpha_tol=1e-4, cg_tol=0.0, cg_nsteps=8)
+    assert st_n["ncg"] == len(st_p["cg_hist"]) == 8
+    close("native MAP_joint step: f", st_n["f"].arr.cpu().numpy(), st_p["f"].arr.cpu().numpy(), tight)
+    assert abs(st_n["alpha"] - st_p["alpha"]) < (2e-3 if prec == "f32" else 1e-6) * max(1.0, st_p["alpha"]), (st_n["alpha"], st_p["alpha"])
+    close("native MAP_joint step: phi", st_n["phi"].arr.cpu().numpy(), st_p["phi"].arr.cpu().numpy(), 5e-3 if prec == "f32" else 1e-6)
+    scalars_close("native MAP_joint step: logpdf", st_n["logpdf"], st_p["logpdf"], rtol=2e-6 if prec == "f32" else 1e-10)
+    assert st_n["linesearch_evals"] == st_p["linesearch_evals"] or prec == "f32"
+    assert torch.equal(ds.ops["G_inv"], Ginv_before)                        # the dataset's G is back in place
+    lp_chk = ds.logpdf_mixed(*ds.mix(st_n["f"], st_n["phi"]))               # and the library still evaluates with it
+    assert np.all(np.isfinite(lp_chk))
