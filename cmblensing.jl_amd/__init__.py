@@ -11,7 +11,7 @@ from .engine import (ProjLambert, LenseFlow, BaseDataSet, Field, MAP, FOURIER, H
 from .sim import (Cls, load_sim, noise_cls, beam_cls, lowpass, cl_to_2d, HarmOp, border_mask)   # noqa: F401
 from .chains import partition_chains, chain_seed, gather_chain_values, allreduce_sum   # noqa: F401
 from .drivers import (quadratic_estimate, MAP_joint, MAP_joint_step, hmc_step, sample_f, gibbs_step, symplectic_integrate,   # noqa: F401
-                      mass_matrix_phi, brent_minimize, sample_joint, MAP_marg, simulate_data, hmc_step_native, MAP_joint_step_native)
+                      mass_matrix_phi, brent_minimize, sample_joint, MAP_marg, simulate_data, hmc_step_native, MAP_joint_step_native, quadratic_estimate_native)
 from . import rng                                                         # noqa: F401
 from .chainfile import load_chains, Chain, Chains                         # noqa: F401
 from .theta import (set_theta, logpdf_mixed_theta, grid_and_sample, gibbs_sample_theta, findbin, bandpower_rescale,   # noqa: F401

@@ -185,6 +185,26 @@ static void do_map_step(Drivers<T>& dr, const void* phi, const void* fstart, con
   CMBL_HIP(hipStreamSynchronize(c->stream));
 }
 
+template <typename T>
+static void do_qe(Dataset<T>& ds, int which, const double* Cf, const double* Cft, const double* Cn, const double* TF, const double* Cphi, int wiener,
+                  const double* AL_in, void* phiqe_out, double* AL_out, int B) {
+  Ctx<T>* c = ds.c;
+  const long pl = c->plane();
+  CMBL_REQUIRE(ds.Bd == B, ERR_SHAPE, "dataset data batch size differs from nbatch");
+  // data components the estimator uses: TT -> T; EE -> E; EB -> E, B  (component index inside the dataset's I / EB / IEB data)
+  const int P = ds.P;
+  int comp[2] = {0, 0};
+  if (which == 0) { CMBL_REQUIRE(P == 1 || P == 3, ERR_ARG, "TT needs a dataset with temperature"); comp[0] = 0; }
+  else { CMBL_REQUIRE(P >= 2, ERR_ARG, "EE / EB need a dataset with polarisation"); comp[0] = P - 2; comp[1] = P - 1; }
+  const int ncomp = which == 2 ? 2 : 1;
+  ds.cvt.ensure(sizeof(cx<T>) * (long)ncomp * B * pl);
+  cx<T>* dr[2] = {ds.cvt.template as<cx<T>>(), ds.cvt.template as<cx<T>>() + (long)B * pl};
+  for (int k = 0; k < ncomp; ++k)
+    for (int b = 0; b < B; ++b) c->F2ref(ds.d_h.template as<cx<T>>() + ((long)b * P + comp[k]) * pl, dr[k] + (long)b * pl, 1);
+  const cx<T>* drc[2] = {dr[0], dr[1]};
+  quadratic_estimate<T>(c, which, B, drc, Cf, Cft, Cn, TF, Cphi, wiener != 0, AL_in, (cx<T>*)phiqe_out, AL_out);
+}
+
 extern "C" {
 
 const char* cmbl_last_error(void) { return g_last_error.c_str(); }
@@ -507,6 +527,17 @@ int cmbl_map_joint_step(cmbl_dataset* ds, cmbl_flow* L, const void* phi, const v
     CMBL_REQUIRE(ds->ctx == L->ctx, ERR_ARG, "dataset and flow belong to different contexts");
     BY_DTYPE(ds->ctx, do_map_step<float>(drivers_of(ds->drv32, *ds->f32, *L->f32), phi, fstart, hinv, alpha_max, alpha_tol, cg_tol, cg_maxit, alias_quirk, B, f_out, phi_out, logpdf_host, alpha_host, ncg_host, nls_host),
              do_map_step<double>(drivers_of(ds->drv64, *ds->f64, *L->f64), phi, fstart, hinv, alpha_max, alpha_tol, cg_tol, cg_maxit, alias_quirk, B, f_out, phi_out, logpdf_host, alpha_host, ncg_host, nls_host));
+  });
+}
+
+int cmbl_quadratic_estimate(cmbl_dataset* ds, int which, const double* Cf_host, const double* Cftilde_host, const double* Cn_host, const double* TF_host,
+                            const double* Cphi_host, int wiener_filtered, const double* AL_in_host, void* phiqe_out, double* AL_out_host, int B) {
+  return guard([&] {
+    NOTNULL(ds); NOTNULL(Cf_host); NOTNULL(Cftilde_host); NOTNULL(Cn_host); NOTNULL(TF_host); NOTNULL(Cphi_host); NOTNULL(phiqe_out);
+    CMBL_REQUIRE(which >= 0 && which <= 2, ERR_ARG, "which: 0 = TT, 1 = EE, 2 = EB (src/quadratic_estimate.jl:41: the others are not implemented by the reference either)");
+    CMBL_REQUIRE(B >= 1, ERR_SHAPE, "nbatch >= 1");
+    BY_DTYPE(ds->ctx, do_qe<float>(*ds->f32, which, Cf_host, Cftilde_host, Cn_host, TF_host, Cphi_host, wiener_filtered, AL_in_host, phiqe_out, AL_out_host, B),
+             do_qe<double>(*ds->f64, which, Cf_host, Cftilde_host, Cn_host, TF_host, Cphi_host, wiener_filtered, AL_in_host, phiqe_out, AL_out_host, B));
   });
 }
 

@@ -202,6 +202,29 @@ def quadratic_estimate(ds, which=None, wiener_filtered=True, AL=None):
     return dict(phiqe=Field(proj, phiqe, FOURIER), AL=AL, Nphi=AL.copy())
 
 
+def quadratic_estimate_native(ds, which=None, wiener_filtered=True, AL=None):
+    """`quadratic_estimate` as ONE library call (`cmbl_quadratic_estimate`): the same legs and sums inside the library.  Returns the same dict."""
+    import ctypes
+    from .lib import check
+    proj, h = ds.proj, ds.host
+    which = which or ("TT" if ds.P == 1 else "EB")
+    off = {1: {"T": 0}, 2: {"E": 0, "B": 1}, 3: {"T": 0, "E": 3, "B": 4}}[ds.P]
+    comps = {"TT": ["T"], "EE": ["E"], "EB": ["E", "B"]}[which]
+    plane = lambda op, k: np.ascontiguousarray(np.asarray(op.p[off[k]], np.float64))
+    pack = lambda f: np.ascontiguousarray(np.stack([f(k) for k in comps]))
+    Cf, Cft, Cn = pack(lambda k: plane(h["Cf"], k)), pack(lambda k: plane(h["Cftilde"], k)), pack(lambda k: plane(h["Cn"], k))
+    TF = pack(lambda k: plane(h["Mf"], k) * plane(h["B"], k))
+    Cphi = np.ascontiguousarray(np.asarray(h["Cphi"], np.float64))
+    B = ds.d.arr.shape[0]
+    out = proj.empty(FOURIER, 1, B)
+    ALo = np.zeros_like(Cphi)
+    pd = lambda a: None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    ALi = None if AL is None else np.ascontiguousarray(np.asarray(AL, np.float64))
+    check(ds.lib.cmbl_quadratic_estimate(ds._h, {"TT": 0, "EE": 1, "EB": 2}[which], pd(Cf), pd(Cft), pd(Cn), pd(TF), pd(Cphi), 1 if wiener_filtered else 0,
+                                         pd(ALi), ctypes.c_void_p(out.data_ptr()), pd(ALo), B))
+    return dict(phiqe=Field(proj, out, FOURIER), AL=ALo, Nphi=ALo.copy())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def MAP_joint_step(ds, phi, fstart=None, alpha_prev=1.0, alpha_tol=1e-4, alpha_max=None, cg_tol=1e-1, cg_nsteps=500, alias_quirk=None):
     """One iteration of the `MAP_joint` loop body (src/maximization.jl:160-206) at fiducial θ with G = I (:146).

@@ -8,16 +8,14 @@ _LIB = None
 
 # every symbol include/cmblens.h declares (tests/test_boundary.py checks the .so exports exactly these)
 SYMBOLS = [
-    "cmbl_last_error", "cmbl_version", "cmbl_abi_version", "cmbl_ctx_set_option", "cmbl_ctx_get_option", "cmbl_ctx_create", "cmbl_ctx_destroy", "cmbl_ctx_synchronize",
-    "cmbl_ctx_geometry_host", "cmbl_prof_enable", "cmbl_prof_reset", "cmbl_prof_count", "cmbl_prof_name", "cmbl_prof_get", "cmbl_rfft", "cmbl_irfft", "cmbl_convert", "cmbl_diag_apply",
-    "cmbl_blockdiag_ieb_apply", "cmbl_dot", "cmbl_logdet", "cmbl_lenseflow_create", "cmbl_lenseflow_destroy",
-    "cmbl_lenseflow_set_phi", "cmbl_lenseflow_apply", "cmbl_lenseflow_grad", "cmbl_dataset_create",
-    "cmbl_dataset_destroy", "cmbl_dataset_set_op", "cmbl_dataset_set_data", "cmbl_dataset_set_logdet",
-    "cmbl_max_lensing_step", "cmbl_axpby", "cmbl_qe_leg", "cmbl_fourier_lmul", "cmbl_map_fma", "cmbl_randn", "cmbl_gradientf_logpdf", "cmbl_wiener_cg", "cmbl_logpdf_mixed", "cmbl_grad_logpdf_mixed",
-    "cmbl_hmc_step", "cmbl_map_joint_step",
-    "cmbl_hmc_step", "cmbl_map_joint_step",
-    "cmbl_norm", "cmbl_logdet_diag", "cmbl_tr_diag", "cmbl_set_sum_accuracy_mode", "cmbl_timer_report",
-    "cmbl_device_malloc", "cmbl_device_free", "cmbl_copy_to_device", "cmbl_copy_to_host",
+    "cmbl_last_error", "cmbl_version", "cmbl_abi_version", "cmbl_ctx_set_option", "cmbl_ctx_get_option", "cmbl_ctx_create", "cmbl_ctx_destroy",
+    "cmbl_ctx_synchronize", "cmbl_ctx_geometry_host", "cmbl_prof_enable", "cmbl_prof_reset", "cmbl_prof_count", "cmbl_prof_name", "cmbl_prof_get",
+    "cmbl_rfft", "cmbl_irfft", "cmbl_convert", "cmbl_diag_apply", "cmbl_blockdiag_ieb_apply", "cmbl_dot", "cmbl_logdet", "cmbl_lenseflow_create",
+    "cmbl_lenseflow_destroy", "cmbl_lenseflow_set_phi", "cmbl_lenseflow_apply", "cmbl_lenseflow_grad", "cmbl_dataset_create", "cmbl_dataset_destroy",
+    "cmbl_dataset_set_op", "cmbl_dataset_set_data", "cmbl_dataset_set_logdet", "cmbl_max_lensing_step", "cmbl_axpby", "cmbl_qe_leg",
+    "cmbl_fourier_lmul", "cmbl_map_fma", "cmbl_randn", "cmbl_gradientf_logpdf", "cmbl_wiener_cg", "cmbl_logpdf_mixed", "cmbl_grad_logpdf_mixed",
+    "cmbl_hmc_step", "cmbl_map_joint_step", "cmbl_quadratic_estimate", "cmbl_norm", "cmbl_logdet_diag", "cmbl_tr_diag", "cmbl_set_sum_accuracy_mode",
+    "cmbl_timer_report", "cmbl_device_malloc", "cmbl_device_free", "cmbl_copy_to_device", "cmbl_copy_to_host",
 ]
 
 
@@ -112,6 +110,7 @@ def load_library():
         "cmbl_logpdf_mixed": [vp, vp, vp, vp, pd, ci],
         "cmbl_grad_logpdf_mixed": [vp, vp, vp, vp, pd, vp, vp, ci, ci],
         "cmbl_hmc_step": [vp, vp, vp, vp, vp, vp, pd, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ci, cd, ci, ci, ci, vp, pd, ctypes.POINTER(ci)],
+        "cmbl_quadratic_estimate": [vp, ci, pd, pd, pd, pd, pd, ci, pd, vp, pd, ci],
         "cmbl_map_joint_step": [vp, vp, vp, vp, vp, cd, cd, cd, ci, ci, ci, vp, vp, pd, pd, ctypes.POINTER(ci), ctypes.POINTER(ci)],
         "cmbl_norm": [vp, ci, vp, ci, ci, pd],
         "cmbl_logdet_diag": [vp, ci, vp, ci, ci, pd],

@@ -247,6 +247,15 @@ int cmbl_hmc_step(cmbl_dataset* ds, cmbl_flow* L, const void* fo, const void* ph
 int cmbl_map_joint_step(cmbl_dataset* ds, cmbl_flow* L, const void* phi, const void* fstart, const void* hinv, double alpha_max,
                         double alpha_tol, double cg_tol, int cg_maxit, int alias_quirk, int nbatch, void* f_out, void* phi_out,
                         double* logpdf_host, double* alpha_host, int* ncg_host, int* nls_host);
+/* quadratic_estimate(ds, which) (src/quadratic_estimate.jl:29-200) on the dataset's data: which = 0 TT, 1 EE, 2 EB (the pairs the
+ *   reference implements, :41).  The *_host arguments are real (Ny/2+1, Nx) planes in double precision, one per component the
+ *   estimator uses (TT: T; EE: E; EB: E then B): Cf (unlensed), Cftilde (lensed), Cn, and TF = Mf .* B, the Fourier-diagonal
+ *   approximations of mask x beam and noise the reference uses (`ds.M̂`, `ds.B̂`, `ds.Cn̂`), plus Cphi.  AL_in_host != NULL skips the
+ *   normalisation sums and uses that plane (:38).  Outputs: phiqe_out FOURIER (Ny/2+1, Nx, 1, nbatch) = (wiener_filtered ?
+ *   Cphi/(Cphi+AL) : 1) .* AL .* unnormalised estimate; AL_out_host (may be NULL) the normalisation = N0 bias plane. */
+int cmbl_quadratic_estimate(cmbl_dataset* ds, int which, const double* Cf_host, const double* Cftilde_host, const double* Cn_host,
+                            const double* TF_host, const double* Cphi_host, int wiener_filtered, const double* AL_in_host,
+                            void* phiqe_out, double* AL_out_host, int nbatch);
 
 #ifdef __cplusplus
 }
