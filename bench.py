@@ -17,7 +17,7 @@ roofline: every fraction in the line is a bandwidth.
     derived per kernel in `compulsory_bytes()` below and in DESIGN.md §5 -- divided by the launch's mean duration (the kernel's own
     start/stop timestamps, recorded by the library with hipExtLaunchKernel events on the stream it launches on) and by 8 TB/s.
   * `traffic`: bytes the L2 exchanged with the fabric for the same launch, from separate rocprofv3 `--pmc FETCH_SIZE` / `--pmc
-    WRITE_SIZE` passes (profiles/r03_traffic_*.json, calibrated on known-size copies: profiles/r03_counter_calibration.json);
+    WRITE_SIZE` passes (profiles/rNN_traffic_*.json of the newest round, calibrated on known-size copies: profiles/rNN_counter_calibration.json);
     `traffic_over_compulsory` ≈ 1 means no wasted re-reads.  The counters include Infinity-Cache hits.
   * `survey_equivalent_*` (under `whole_step` only): SURVEY.md §8(d)'s pass structure of the REFERENCE divided by our step time -- a
     speed-up figure that may exceed the peak because the fused kernels do not move those bytes; never used for `frac`.
@@ -88,12 +88,16 @@ def compulsory_bytes(kernel, Ny, Nx, P, B, Bphi, n, s):
 
 
 def measured_traffic(N, P, B, dtype, n, unit="grad"):
-    """L2<->fabric bytes from the committed rocprofv3 PMC passes (profiles/r03_traffic_*.json, tools/run_traffic.sh): ({kernel class:
+    """L2<->fabric bytes from the committed rocprofv3 PMC passes (profiles/rNN_traffic_*.json, newest round; tools/run_traffic.sh): ({kernel class:
     bytes per launch}, bytes per step, file name) or ({}, None, None) when no profile matches this workload.  Counters cannot be
     read from inside this process."""
+    import glob
     pol = {1: "I", 2: "QU", 3: "IQU"}[P]
-    name = f"r03_traffic_{'cg_' if unit == 'cg' else ''}{N}{pol}_{dtype}{'_B%d' % B if B > 1 else ''}.json"
-    path = os.path.join(ROOT, "profiles", name)
+    tail = f"_traffic_{'cg_' if unit == 'cg' else ''}{N}{pol}_{dtype}{'_B%d' % B if B > 1 else ''}.json"
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]" + tail)))      # the newest round's profile of this workload
+    if not found:
+        return {}, None, None
+    path, name = found[-1], os.path.basename(found[-1])
     try:
         z = json.load(open(path))
         w = z["workload"]
@@ -114,8 +118,11 @@ def profiler_mean_us(kernel, N, P, B, dtype):
     import csv
     pol = {1: "I", 2: "QU", 3: "IQU"}[P]
     tag = f"{N}{pol}_{dtype}{'_B%d' % B if B > 1 else ''}"
-    for name in (f"r03_kernel_stats_{tag}_50steps.csv", f"r03_kernel_stats_{tag}.csv"):
-        path = os.path.join(ROOT, "profiles", name)
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_kernel_stats_{tag}_50steps.csv")))[-1:] \
+        + sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_kernel_stats_{tag}.csv")))[-1:]
+    for path in cands:
+        name = os.path.basename(path)
         if kernel in PROF_KERNEL and os.path.isfile(path):
             for r in csv.DictReader(open(path)):
                 if PROF_KERNEL[kernel] in r["Name"]:

@@ -15,6 +15,10 @@
 #pragma once
 #include "kernels_fft.hpp"
 
+#ifndef CMBL_ADJX_EARLY
+#define CMBL_ADJX_EARLY 0
+#endif
+
 namespace cmbl {
 
 
@@ -335,15 +339,47 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   using V = typename vreg<T>::type;
   constexpr int XLG = row_xlg(LGNX), NS = num_stages(LGNX - 1, XLG), LG = stage_lg(LGNX - 1, NS - 1, XLG), r = 1 << LG;
   constexpr int VE = 16 / (int)sizeof(cx<T>), NV = r / VE;
-  fft_dif_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW>, 0, 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
   const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
   const T inv = T(1) / T(Nx);
   const bool last = a.rk.last;
+  // The Fourier state of the thread's butterflies (Y0, acc: 64 contiguous bytes each per butterfly) and lx do not depend on the
+  // transforms: they are requested BEFORE the forward stages and arrive while those run (CMBL_ADJX_EARLY = 1; 0 requests them inside
+  // the register phase, where the wave then waits a full memory latency; 2 requests them ahead of the row tiles)
+  constexpr int ITEMS = 1 << (LGNX - LG), IT = (ROW_RT == 128 && ITEMS / 2 >= 64) ? ITEMS / 128 : 1;
+  CxVec<T> y0p[IT][NV], acp[IT][NV];
+  T lxp[IT][r];
+  auto prefetch = [&]() {
+    int it = 0;
+    wk.template each<LGNX - LG>([&](int row, int rr) {
+      const int b0 = rr << LG;
+      const size_t g0 = ((size_t)rg.sl * a.Nyh + rg.ky0 + row) * Nx + b0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        y0p[it][i] = *reinterpret_cast<const CxVec<T>*>(a.Y0 + g0 + i * VE);
+        if (a.rk.stage != 1) acp[it][i] = *reinterpret_cast<const CxVec<T>*>(a.acc + g0 + i * VE);
+      }
+#pragma unroll
+      for (int i = 0; i < r; ++i) lxp[it][i] = a.lx_r[b0 + i];
+      ++it;
+    });
+  };
+#if CMBL_ADJX_EARLY == 1
+  prefetch();
+#endif
+  fft_dif_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW>, 0, 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
+  int item = 0;
   wk.template each<LGNX - LG>([&](int row, int rr) {
     const int b0 = rr << LG;
     const size_t g0 = ((size_t)rg.sl * a.Nyh + rg.ky0 + row) * Nx + b0;
     CxVec<T> y0v[NV], acv[NV];
     T lxr[r];
+#if CMBL_ADJX_EARLY
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { y0v[i] = y0p[item][i]; acv[i] = acp[item][i]; }
+#pragma unroll
+    for (int i = 0; i < r; ++i) lxr[i] = lxp[item][i];
+    ++item;
+#else
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       y0v[i] = *reinterpret_cast<const CxVec<T>*>(a.Y0 + g0 + i * VE);
@@ -351,6 +387,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
     }
 #pragma unroll
     for (int i = 0; i < r; ++i) lxr[i] = a.lx_r[b0 + i];
+#endif
     cx<T>* p1 = s + row * LD + pad(b0);
     const cx<T>* p2 = s2 + row * LD + pad(b0);
     V va[r], vb[r], u[r];

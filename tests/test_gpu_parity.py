@@ -1,4 +1,4 @@
-"""GPU parity: every C-ABI entry point of libcmblens_hip.so against the NumPy oracle on identical inputs.
+r"""GPU parity: every C-ABI entry point of libcmblens_hip.so against the NumPy oracle on identical inputs.
 
 Tolerances (relative L2 per field; fp32 against the float64 oracle on the fp32-rounded inputs).  Two layers (tests/_tol.py):
   * the class bounds in TOL below = 3 x the LARGEST error that class showed on MI355X (profiles/r04_parity_measured.txt):

@@ -20,7 +20,7 @@ for ((i = 0; i < ${#args[@]}; i++)); do
   esac
 done
 nunits=$((steps + warm))
-cmd="python bench.py --warmup $warm --no-cpu-baseline --no-roofline --no-extras --steps $steps $*"
+cmd="python bench.py --warmup $warm --no-ramp --no-cpu-baseline --no-roofline --no-extras --steps $steps $*"
 case $pol in I) np=1;; P) np=2;; IP) np=3;; esac
 CMBL_SLICE_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $out/tr_$name -o b -- $cmd > $out/tr_$name.log 2>&1
 CMBL_SLICE_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $out/pf_$name -o p -- $cmd > $out/pf_$name.log 2>&1
@@ -28,7 +28,7 @@ CMBL_SLICE_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f cs
 f=$(find $out/pf_$name -name '*counter_collection.csv' | head -1); w=$(find $out/pw_$name -name '*counter_collection.csv' | head -1)
 s=$(find $out/tr_$name -name '*kernel_stats.csv' | head -1)
 [ -n "$s" ] && cp $s $out/kernel_stats_$name.csv
-cal=$out/counter_calibration.json; [ -f $cal ] || cal=profiles/r03_counter_calibration.json; [ -f $cal ] || cal=-
+cal=$out/counter_calibration.json; [ -f $cal ] || cal=$(ls profiles/r*_counter_calibration.json 2>/dev/null | sort | tail -1); [ -n "$cal" ] && [ -f $cal ] || cal=-
 python tools/make_traffic_json.py "$f" "$w" $out/traffic_$name.json $nside $np $nb $dtype $nrk $nunits $cal "$unit" > $out/traffic_$name.log 2>&1
 tail -4 $out/traffic_$name.log
 # keep the merge-back small: the raw per-dispatch csv files are tens of MB
