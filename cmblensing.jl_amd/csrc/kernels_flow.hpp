@@ -15,10 +15,6 @@
 #pragma once
 #include "kernels_fft.hpp"
 
-#ifndef CMBL_ADJX_EARLY
-#define CMBL_ADJX_EARLY 0
-#endif
-
 namespace cmbl {
 
 
@@ -343,8 +339,9 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   const T inv = T(1) / T(Nx);
   const bool last = a.rk.last;
   // The Fourier state of the thread's butterflies (Y0, acc: 64 contiguous bytes each per butterfly) and lx do not depend on the
-  // transforms: they are requested BEFORE the forward stages and arrive while those run (CMBL_ADJX_EARLY = 1; 0 requests them inside
-  // the register phase, where the wave then waits a full memory latency; 2 requests them ahead of the row tiles)
+  // transforms: they are requested BEFORE the forward stages and arrive while those run, instead of inside the register phase, where
+  // the wave then waited a full memory latency (A/B profiles/r04_ab_adjx_prefetch.txt: L'g 0.866 -> 0.835 ms and the Wiener-CG
+  // iteration 1.726 -> 1.694 ms at 1024^2 T+QU; QU within the run-to-run spread)
   constexpr int ITEMS = 1 << (LGNX - LG), IT = (ROW_RT == 128 && ITEMS / 2 >= 64) ? ITEMS / 128 : 1;
   CxVec<T> y0p[IT][NV], acp[IT][NV];
   T lxp[IT][r];
@@ -363,9 +360,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
       ++it;
     });
   };
-#if CMBL_ADJX_EARLY == 1
   prefetch();
-#endif
   fft_dif_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW>, 0, 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
   int item = 0;
   wk.template each<LGNX - LG>([&](int row, int rr) {
@@ -373,21 +368,11 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
     const size_t g0 = ((size_t)rg.sl * a.Nyh + rg.ky0 + row) * Nx + b0;
     CxVec<T> y0v[NV], acv[NV];
     T lxr[r];
-#if CMBL_ADJX_EARLY
 #pragma unroll
     for (int i = 0; i < NV; ++i) { y0v[i] = y0p[item][i]; acv[i] = acp[item][i]; }
 #pragma unroll
     for (int i = 0; i < r; ++i) lxr[i] = lxp[item][i];
     ++item;
-#else
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      y0v[i] = *reinterpret_cast<const CxVec<T>*>(a.Y0 + g0 + i * VE);
-      if (a.rk.stage != 1) acv[i] = *reinterpret_cast<const CxVec<T>*>(a.acc + g0 + i * VE);
-    }
-#pragma unroll
-    for (int i = 0; i < r; ++i) lxr[i] = a.lx_r[b0 + i];
-#endif
     cx<T>* p1 = s + row * LD + pad(b0);
     const cx<T>* p2 = s2 + row * LD + pad(b0);
     V va[r], vb[r], u[r];
