@@ -496,6 +496,15 @@ def main():
                 fo3, po3 = sim3["ds"].mix(sim3["f"], sim3["phi"])
                 ex["grad_lnP_ms_IP"] = timeit(lambda: sim3["ds"].gradient_logpdf_mixed(fo3, po3), n=20)
                 ex["grad_lnP_IP_note"] = f"{N}² T+QU (BASELINE configs[2] workload, the north_star target): ∇logpdf(Mixed) step, mean of 20"
+                del sim3, fo3, po3
+                # the same step with 8 independent chains per GPU as batch slots (north_star: chains / batch slots fill the chip): launches are
+                # several residency rounds long and the phases of a launch overlap -- what the part delivers when it is not latency-bound
+                sim8 = C.load_sim(2.0, N, pol, synthetic_cls(), T=tT, device=local, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=nrk, Nbatch=8)
+                fo8, po8 = sim8["ds"].mix(sim8["f"], sim8["phi"])
+                ms8 = timeit(lambda: sim8["ds"].gradient_logpdf_mixed(fo8, po8), n=10)
+                ex["eight_chains_per_gpu"] = {"ms_per_call": ms8, "evaluations_per_s": 8e3 / ms8,
+                                              "note": f"{N}² {pol}, Nbatch = 8 in one call (bench.py --nbatch 8 is the full line of this workload)"}
+                del sim8, fo8, po8
             out["extras"] = ex
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dev = None

@@ -36,6 +36,9 @@ def test_quadratic_estimate(prec, pol, which):
     m = ods.Cphi > 0
     scalars_close("QE normalisation AL", got["AL"][m], AL[m], rtol=2e-3 if prec == "f32" else 1e-9)
     close("got['phiqe'].arr.cpu().numpy()", got["phiqe"].arr.cpu().numpy(), pq, (2e-3 if prec == "f32" else 1e-9))
+    nat = C.quadratic_estimate_native(ds, which)                        # cmbl_quadratic_estimate, directly against the oracle
+    scalars_close("cmbl_quadratic_estimate vs oracle: AL", nat["AL"][m], AL[m], rtol=2e-3 if prec == "f32" else 1e-9)
+    close("cmbl_quadratic_estimate vs oracle: phiqe", nat["phiqe"].arr.cpu().numpy(), pq, (2e-3 if prec == "f32" else 1e-9))
     # it is an estimate of ϕ: correlates with the truth
     phi = so["phi"]
     r = O.dot_fourier(so["proj"], pq, phi) / np.sqrt(O.dot_fourier(so["proj"], pq, pq) * O.dot_fourier(so["proj"], phi, phi))
@@ -77,6 +80,12 @@ def test_map_joint_step(prec, pol):
     scalars_close("MAP_joint step logpdf", st_g["logpdf"], st_o["logpdf"], rtol=2e-5)
     assert st_g["logpdf"][0] > st_g["logpdf_before"][0]
     close("st_g['phi'].arr.cpu().numpy()", st_g["phi"].arr.cpu().numpy(), st_o["phi"], 2e-2)
+    # the same loop body as ONE library call (cmbl_map_joint_step), directly against the oracle
+    st_n = C.MAP_joint_step_native(ds, C.Field(p, p.tensor(phi0), C.FOURIER), alpha_tol=1e-4, cg_tol=0.0, cg_nsteps=10)
+    close("cmbl_map_joint_step vs oracle: f", st_n["f"].arr.cpu().numpy(), st_o["f"], (2e-3 if prec == "f32" else 1e-8))
+    assert abs(st_n["alpha"] - st_o["alpha"]) < 5e-3, (st_n["alpha"], st_o["alpha"])
+    scalars_close("cmbl_map_joint_step vs oracle: logpdf", st_n["logpdf"], st_o["logpdf"], rtol=2e-5)
+    close("cmbl_map_joint_step vs oracle: phi", st_n["phi"].arr.cpu().numpy(), st_o["phi"], 2e-2)
     # two more steps keep increasing the posterior and approach the true ϕ
     f, phi, hist = C.MAP_joint(ds, nsteps=3)
     lps = [h["logpdf"][0] for h in hist]
@@ -104,6 +113,12 @@ def test_hmc_and_gibbs_step(prec, pol):
     if prec == "f64":
         assert bool(acc_g[0]) == bool(acc_o[0])
     close("x_g.arr.cpu().numpy()", x_g.arr.cpu().numpy(), x_o, (2e-3 if prec == "f32" else 1e-7))
+    # the same update as ONE library call (cmbl_hmc_step), directly against the oracle
+    x_n, dH_n, acc_n = C.hmc_step_native(ds, F(fo, C.MAP), F(po, C.FOURIER), white_p=wp, log_u=logu, N=5, eps=0.01)
+    np.testing.assert_allclose(dH_n, dH_o, atol=5.0 if prec == "f32" else 2e-3)
+    close("cmbl_hmc_step vs oracle: phi°", x_n.arr.cpu().numpy(), x_o, (2e-3 if prec == "f32" else 1e-7))
+    if prec == "f64":
+        assert bool(acc_n[0]) == bool(acc_o[0])
     # posterior sample of f (src/maximization.jl:56-62): fixed short CG so both sides stop at the same iterate
     f_o, _ = O.sample_f(ods, so["phi"], wf, wn, tol=0.0, nsteps=6)
     f_g, _ = C.sample_f(ds, F(so["phi"], C.FOURIER), wf, wn, tol=0.0, nsteps=6)
