@@ -12,6 +12,7 @@ struct cmbl_dataset {
   cmbl_ctx* ctx; std::unique_ptr<Dataset<float>> f32; std::unique_ptr<Dataset<double>> f64;
   std::map<const void*, std::unique_ptr<Drivers<float>>> drv32;        // driver scratch per (dataset, flow) pair
   std::map<const void*, std::unique_ptr<Drivers<double>>> drv64;
+  std::vector<std::unique_ptr<DevBuf>> qe_pool;                        // legs and products of cmbl_quadratic_estimate, reused between calls
 };
 
 template <typename F>
@@ -186,7 +187,7 @@ static void do_map_step(Drivers<T>& dr, const void* phi, const void* fstart, con
 }
 
 template <typename T>
-static void do_qe(Dataset<T>& ds, int which, const double* Cf, const double* Cft, const double* Cn, const double* TF, const double* Cphi, int wiener,
+static void do_qe(Dataset<T>& ds, std::vector<std::unique_ptr<DevBuf>>& pool, int which, const double* Cf, const double* Cft, const double* Cn, const double* TF, const double* Cphi, int wiener,
                   const double* AL_in, void* phiqe_out, double* AL_out, int B) {
   Ctx<T>* c = ds.c;
   const long pl = c->plane();
@@ -202,7 +203,7 @@ static void do_qe(Dataset<T>& ds, int which, const double* Cf, const double* Cft
   for (int k = 0; k < ncomp; ++k)
     for (int b = 0; b < B; ++b) c->F2ref(ds.d_h.template as<cx<T>>() + ((long)b * P + comp[k]) * pl, dr[k] + (long)b * pl, 1);
   const cx<T>* drc[2] = {dr[0], dr[1]};
-  quadratic_estimate<T>(c, which, B, drc, Cf, Cft, Cn, TF, Cphi, wiener != 0, AL_in, (cx<T>*)phiqe_out, AL_out);
+  quadratic_estimate<T>(c, pool, which, B, drc, Cf, Cft, Cn, TF, Cphi, wiener != 0, AL_in, (cx<T>*)phiqe_out, AL_out);
 }
 
 extern "C" {
@@ -536,8 +537,8 @@ int cmbl_quadratic_estimate(cmbl_dataset* ds, int which, const double* Cf_host, 
     NOTNULL(ds); NOTNULL(Cf_host); NOTNULL(Cftilde_host); NOTNULL(Cn_host); NOTNULL(TF_host); NOTNULL(Cphi_host); NOTNULL(phiqe_out);
     CMBL_REQUIRE(which >= 0 && which <= 2, ERR_ARG, "which: 0 = TT, 1 = EE, 2 = EB (src/quadratic_estimate.jl:41: the others are not implemented by the reference either)");
     CMBL_REQUIRE(B >= 1, ERR_SHAPE, "nbatch >= 1");
-    BY_DTYPE(ds->ctx, do_qe<float>(*ds->f32, which, Cf_host, Cftilde_host, Cn_host, TF_host, Cphi_host, wiener_filtered, AL_in_host, phiqe_out, AL_out_host, B),
-             do_qe<double>(*ds->f64, which, Cf_host, Cftilde_host, Cn_host, TF_host, Cphi_host, wiener_filtered, AL_in_host, phiqe_out, AL_out_host, B));
+    BY_DTYPE(ds->ctx, do_qe<float>(*ds->f32, ds->qe_pool, which, Cf_host, Cftilde_host, Cn_host, TF_host, Cphi_host, wiener_filtered, AL_in_host, phiqe_out, AL_out_host, B),
+             do_qe<double>(*ds->f64, ds->qe_pool, which, Cf_host, Cftilde_host, Cn_host, TF_host, Cphi_host, wiener_filtered, AL_in_host, phiqe_out, AL_out_host, B));
   });
 }
 

@@ -207,11 +207,18 @@ template <typename T>
 struct QuadEst {
   Ctx<T>* c;
   int B;
-  std::map<std::tuple<const void*, int, int, int>, std::unique_ptr<DevBuf>> legs;
-  std::vector<std::unique_ptr<DevBuf>> keep;
+  std::vector<std::unique_ptr<DevBuf>>& pool;                  // device buffers kept by the caller between calls (no hipMalloc after the first)
+  size_t used = 0;
+  std::map<std::tuple<const void*, int, int, int>, T*> legs;
 
-  cx<T>* new_fourier(int nb) { keep.emplace_back(new DevBuf()); keep.back()->ensure(sizeof(cx<T>) * nb * c->plane()); return keep.back()->template as<cx<T>>(); }
-  T* new_map(int nb) { keep.emplace_back(new DevBuf()); keep.back()->ensure(sizeof(T) * nb * c->npix()); return keep.back()->template as<T>(); }
+  void* take(size_t bytes) {
+    if (used == pool.size()) pool.emplace_back(new DevBuf());
+    DevBuf& b = *pool[used++];
+    b.ensure(bytes);
+    return b.p;
+  }
+  cx<T>* new_fourier(int nb) { return (cx<T>*)take(sizeof(cx<T>) * nb * c->plane()); }
+  T* new_map(int nb) { return (T*)take(sizeof(T) * nb * c->npix()); }
 
   // a real (Nyh x Nx, reference layout) host plane as a complex S0 Fourier field of one batch slot
   cx<T>* upload_plane(const std::vector<double>& p) {
@@ -228,12 +235,11 @@ struct QuadEst {
     auto key = std::make_tuple((const void*)C, n, p1, p2);
     auto it = legs.find(key);
     if (it == legs.end()) {
-      auto buf = std::make_unique<DevBuf>();
-      buf->ensure(sizeof(T) * nb * c->npix());
-      c->qe_leg(C, buf->template as<T>(), n, p1, p2, nb);
-      it = legs.emplace(key, std::move(buf)).first;
+      T* m = new_map(nb);
+      c->qe_leg(C, m, n, p1, p2, nb);
+      it = legs.emplace(key, m).first;
     }
-    return it->second->template as<T>();
+    return it->second;
   }
   // acc (+)= s * a .* b ; acc == nullptr allocates
   T* mul(const T* a, const T* b, double s, T* acc, int nb) {
@@ -248,11 +254,11 @@ inline int eps3(int a, int b) { return (a == 1 && b == 2) ? 1 : ((a == 2 && b ==
 // planes (host, reference layout [x][ky], double): for each of the ncomp components (TT: T; EE: E; EB: E then B) Cf, Cftilde, Cn and
 // TF = Mf .* B.  dref[comp]: that component of the data, S0 Fourier reference layout, B slots (device).
 template <typename T>
-void quadratic_estimate(Ctx<T>* c, int which, int B, const cx<T>* const* dref, const double* Cf, const double* Cft, const double* Cn, const double* TF,
+void quadratic_estimate(Ctx<T>* c, std::vector<std::unique_ptr<DevBuf>>& pool, int which, int B, const cx<T>* const* dref, const double* Cf, const double* Cft, const double* Cn, const double* TF,
                         const double* Cphi, bool wiener, const double* AL_in, cx<T>* phiqe_ref, double* AL_out) {
   const long pl = c->plane();
   const int ncomp = which == 2 ? 2 : 1;
-  QuadEst<T> q{c, B, {}, {}};
+  QuadEst<T> q{c, B, pool};
   auto finite0 = [](double v) { return std::isfinite(v) ? v : 0.0; };
   // inverse-variance filtered data legs  extra * (Sigma_tot \ (TF d))  and the weight planes of orders 0, 1, 2 in Cf  (:52-62, 100-110)
   std::vector<std::vector<double>> w0(ncomp), w1(ncomp), w2(ncomp), fil(ncomp), filC(ncomp);
