@@ -114,7 +114,7 @@ PROF_KERNEL = {"delta_cols": "k_delta_cols<", "delta_rows": "k_delta_rows<", "fl
 
 def profiler_mean_us(kernel, N, P, B, dtype):
     """Mean duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this workload (profiles/), or None.  The
-    profiler's kernel times run ~7 % above the un-profiled ones; reported next to the live figure, never instead of it."""
+    profiler's kernel times run 3-7 % above the un-profiled ones; reported next to the live figure, never instead of it."""
     import csv
     pol = {1: "I", 2: "QU", 3: "IQU"}[P]
     tag = f"{N}{pol}_{dtype}{'_B%d' % B if B > 1 else ''}"
@@ -475,7 +475,7 @@ def main():
         if pus:
             out["roofline"]["rocprofv3"] = {"avg_launch_us": pus, "frac": d["compulsory_bytes_per_launch"] / (pus * 1e-6) / 1e9 / PEAK_GBS, "source": psrc,
                                             "note": "the same kernel's mean in the committed rocprofv3 kernel-trace summary of this workload; the profiler's "
-                                                    "kernel times are ~7 % above the un-profiled ones (DESIGN.md §5)"}
+                                                    "kernel times are 3-7 % above the un-profiled ones (DESIGN.md §5)"}
     if rank == 0 and not args.no_extras and world == 1:
         def timeit(fn, n=10):
             for _ in range(2):
