@@ -319,3 +319,40 @@ def test_errors_are_status_codes():
     with pytest.raises(C.CmblError) as e:
         L * f                                       # set_phi not called
     assert e.value.code == 5                       # CMBL_ERR_STATE
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("pol", ["I", "P"])
+def test_wiener_filter_and_logpdf_closed_form(prec, pol):
+    """Oracle-independent known answer for the data model, the operator chain, the reductions and the PCG (src/dataset.jl:59-66,76-80,
+    129-132, src/maximization.jl:17-42, src/numerical_algorithms.jl:73-134): without lensing (ϕ = 0: the flow is the identity) and without a
+    pixel mask every operator is diagonal in ℓ, so the Wiener filter is f = pinv(Cf⁻¹ + T²Cn⁻¹)·T·Cn⁻¹·d per mode (T = Mf·B), the `:diag`
+    preconditioner is the exact inverse (one CG step), and logpdf is a sum over modes -- all formed here in NumPy from the operator
+    planes, with nothing from `oracle/`."""
+    C = _pkg()
+    from bench import synthetic_cls
+    tT, nT = DT[prec]
+    s = C.load_sim(3.0, (64, 128), pol, synthetic_cls(), T=tT, beam_fwhm=3.0, pixel_mask=None, Nphi="flat")
+    ds, p, h = s["ds"], s["proj"], s["ds"].host
+    P = ds.P
+    pinv = lambda a: np.where(a != 0, 1.0 / np.where(a != 0, a, 1.0), 0.0)
+    Cf, Cn, T = np.asarray(h["Cf"].p, float), np.asarray(h["Cn"].p, float), np.asarray(h["Mf"].p, float) * np.asarray(h["B"].p, float)   # (P, Nx, Nyh)
+    d = s["d"].arr.cpu().numpy().astype(np.complex128)                                                       # (1, P, Nx, Nyh), harmonic
+    A = pinv(Cf) + T ** 2 * pinv(Cn)
+    want = pinv(A) * T * pinv(Cn) * d
+    phi0 = C.Field(p, torch.zeros_like(s["phi"].arr), C.FOURIER)
+    got, hist = ds.argmaxf_logpdf(phi0, tol=1e-12 if prec == "f64" else 1e-4, nsteps=20)
+    assert len(hist) <= 3, len(hist)                                          # the preconditioner is the exact inverse here
+    close("Wiener filter, closed form", got.arr.cpu().numpy(), want, 3e-6 if prec == "f32" else 1e-12)
+    # logpdf(f, ϕ = 0) = -1/2 [ z'Cn⁻¹z + f'Cf⁻¹f + logdets ],  z = T f - d,  <a, b> = Σ λ Re(conj a · b) / (Ny Nx)  (src/proj_lambert.jl:322-325)
+    lam = np.asarray(p.lam, float)[None, None, None, :]
+    dotF = lambda a, b: float(np.sum(lam * (np.conj(a) * b).real) / (p.Ny * p.Nx))
+    f = want
+    z = T * f - d
+    lp_want = -0.5 * (dotF(z, pinv(Cn) * z) + dotF(f, pinv(Cf) * f) + ds.logdet_sum)
+    lp_got = ds.logpdf(C.Field(p, p.tensor(f), C.HARMONIC), phi0)
+    scalars_close("logpdf, closed form", lp_got, [lp_want], rtol=1e-6 if prec == "f32" else 1e-12)
+    # and the gradient with respect to f vanishes at the Wiener-filtered field (src/dataset.jl:76-80)
+    g = ds.gradientf_logpdf(C.Field(p, p.tensor(f), C.HARMONIC), phi0)
+    rhs = T * pinv(Cn) * d
+    assert rel(g.arr.cpu().numpy() + rhs, rhs) < (1e-5 if prec == "f32" else 1e-11)
