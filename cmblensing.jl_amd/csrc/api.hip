@@ -204,6 +204,11 @@ static void do_qe(Dataset<T>& ds, std::vector<std::unique_ptr<DevBuf>>& pool, in
     for (int b = 0; b < B; ++b) c->F2ref(ds.d_h.template as<cx<T>>() + ((long)b * P + comp[k]) * pl, dr[k] + (long)b * pl, 1);
   const cx<T>* drc[2] = {dr[0], dr[1]};
   quadratic_estimate<T>(c, pool, which, B, drc, Cf, Cft, Cn, TF, Cphi, wiener != 0, AL_in, (cx<T>*)phiqe_out, AL_out);
+  // the legs and products stay allocated for the next call (a one-off estimator otherwise spends half its time in hipMalloc), unless
+  // they are large: ~100 maps, 3 GB at 2048^2 in double precision
+  size_t held = 0;
+  for (const auto& b : pool) held += b->bytes;
+  if (held > ((size_t)1 << 30)) pool.clear();
 }
 
 extern "C" {
