@@ -82,6 +82,35 @@ template <typename V> __device__ __forceinline__ const V& at32(const V* base, un
 template <typename V> __device__ __forceinline__ V& at32(V* base, unsigned idx) {
   return *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(V));
 }
+// Hand-off stores.  The mixed-layout arrays a column kernel hands to the next row kernel (and back) are read by workgroups on all
+// eight XCDs, i.e. through the fabric, whatever the producer's L2 holds.  Written with plain stores they stay dirty in the producing
+// XCD's L2 until the write-back at the kernel boundary, and the dependent launch waits for it (MI355X_MICROARCH.md: + B / 6 TB/s for B
+// dirty bytes); written through (`sc1`) they leave while the kernel still computes.  Measured at 1024^2 QU, per launch
+// (profiles/r04_ab_write_through.txt): x_grad 7.6 -> 6.7 us, adj_y 12.0 -> 10.8 us, flow_y_fwd 13.5 -> 12.7 us, delta_cols 20.3 -> 19.5 us.
+// NOT for arrays the same workgroup index re-reads in the next stage (the RK state): sc1 drops the line from the L2 and those
+// re-reads then miss (adj_x +14 %).  One store per complex value (8 bytes in single precision): 16-byte forms measured the same.
+#ifndef CMBL_WT_STORES
+#define CMBL_WT_STORES 1
+#endif
+typedef float wt_f2 __attribute__((ext_vector_type(2)));
+typedef float wt_f4 __attribute__((ext_vector_type(4)));
+template <int BYTES> __device__ __forceinline__ void store_wt(void* q, const void* v) {
+  static_assert(BYTES == 8 || BYTES == 16, "hand-off stores are 8 or 16 bytes");
+#if CMBL_WT_STORES
+  // The compiler cannot see that the asm is a store of more than 64 bits, so it does not keep the two wait states gfx950 needs before a
+  // vector instruction overwrites the store's data registers (it scheduled `v_or_b32 v2, ...` right behind `global_store_dwordx4 .., v[2:5]`
+  // in k_delta_rows: wrong Gx in single AND double precision).  The s_nop supplies them.
+  if constexpr (BYTES == 16) { const wt_f4 d = *reinterpret_cast<const wt_f4*>(v); asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(q), "v"(d) : "memory"); }
+  else { const wt_f2 d = *reinterpret_cast<const wt_f2*>(v); asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(q), "v"(d) : "memory"); }
+#else
+  if constexpr (BYTES == 16) *reinterpret_cast<wt_f4*>(q) = *reinterpret_cast<const wt_f4*>(v);
+  else *reinterpret_cast<wt_f2*>(q) = *reinterpret_cast<const wt_f2*>(v);
+#endif
+}
+template <typename T> __device__ __forceinline__ void handoff_store(cx<T>* base, unsigned idx, cx<T> v) {
+  store_wt<(int)sizeof(cx<T>)>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(cx<T>), &v);
+}
+
 // A column tile of C = MIXW columns is ONE contiguous block of the mixed layout: entry (ky, c) of the tile at x0 sits at
 // tile_base(g, x0) + ky * MIXW + c.  Other widths go through mix_idx.
 template <typename V> __device__ __forceinline__ V* tile_base(V* g, int x0, int NyhP) { return g + (size_t)(x0 >> LGMIXW) * NyhP * MIXW; }
@@ -261,13 +290,13 @@ __device__ __forceinline__ void half_store(const cx<T>* __restrict__ s, cx<T>* _
     const cx<T>* p = s + c * LD;
     if (k == 0) {
       const cx<T> z = p[0];
-      at32(tg, tile_off<C>(0, c, x0, NyhP)) = mk<T>(z.x + z.y, 0); at32(tg, tile_off<C>(M, c, x0, NyhP)) = mk<T>(z.x - z.y, 0);
+      handoff_store<T>(tg, tile_off<C>(0, c, x0, NyhP), mk<T>(z.x + z.y, 0)); handoff_store<T>(tg, tile_off<C>(M, c, x0, NyhP), mk<T>(z.x - z.y, 0));
     } else {
       const cx<T> a = p[pad(brevc<LGM>(k))], b = p[pad(brevc<LGM>(k2))];
       const cx<T> e = mk<T>(T(0.5) * (a.x + b.x), T(0.5) * (a.y - b.y)), o = mk<T>(T(0.5) * (a.x - b.x), T(0.5) * (a.y + b.y));
       const cx<T> wo = mul_mi(o * tw[k]);
-      at32(tg, tile_off<C>(k, c, x0, NyhP)) = e + wo;
-      if (k2 != k) at32(tg, tile_off<C>(k2, c, x0, NyhP)) = conj(e - wo);
+      handoff_store<T>(tg, tile_off<C>(k, c, x0, NyhP), e + wo);
+      if (k2 != k) handoff_store<T>(tg, tile_off<C>(k2, c, x0, NyhP), conj(e - wo));
     }
   }
 }
@@ -504,8 +533,8 @@ __device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s
         if (nyq >= 0 && (ky0 + r == 0 || ky0 + r == nyq)) { oa.v[e].y = T(0); ob.v[e].y = T(0); }
       }
       cx<T>* gk = g + (size_t)ky0 * MIXW;                                  // uniform part of the address
-      vec32(gk, (unsigned)((xt * NyhP + r) * MIXW + c)) = oa;
-      vec32(gk, (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c)) = ob;
+      store_wt<16>(reinterpret_cast<char*>(gk) + (unsigned)((xt * NyhP + r) * MIXW + c) * (unsigned)sizeof(cx<T>), &oa);      // hand-off: see handoff_store
+      store_wt<16>(reinterpret_cast<char*>(gk) + (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c) * (unsigned)sizeof(cx<T>), &ob);
     }
   }
 }
