@@ -95,16 +95,18 @@ template <typename V> __device__ __forceinline__ V& at32(V* base, unsigned idx) 
 typedef float wt_f2 __attribute__((ext_vector_type(2)));
 typedef float wt_f4 __attribute__((ext_vector_type(4)));
 template <int BYTES> __device__ __forceinline__ void store_wt(void* q, const void* v) {
-  static_assert(BYTES == 8 || BYTES == 16, "hand-off stores are 8 or 16 bytes");
+  static_assert(BYTES == 4 || BYTES == 8 || BYTES == 16, "hand-off stores are 4, 8 or 16 bytes");
 #if CMBL_WT_STORES
   // The compiler cannot see that the asm is a store of more than 64 bits, so it does not keep the two wait states gfx950 needs before a
   // vector instruction overwrites the store's data registers (it scheduled `v_or_b32 v2, ...` right behind `global_store_dwordx4 .., v[2:5]`
   // in k_delta_rows: wrong Gx in single AND double precision).  The s_nop supplies them.
   if constexpr (BYTES == 16) { const wt_f4 d = *reinterpret_cast<const wt_f4*>(v); asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(q), "v"(d) : "memory"); }
-  else { const wt_f2 d = *reinterpret_cast<const wt_f2*>(v); asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(q), "v"(d) : "memory"); }
+  else if constexpr (BYTES == 8) { const wt_f2 d = *reinterpret_cast<const wt_f2*>(v); asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(q), "v"(d) : "memory"); }
+  else { const float d = *reinterpret_cast<const float*>(v); asm volatile("global_store_dword %0, %1, off sc1" : : "v"(q), "v"(d) : "memory"); }
 #else
   if constexpr (BYTES == 16) *reinterpret_cast<wt_f4*>(q) = *reinterpret_cast<const wt_f4*>(v);
-  else *reinterpret_cast<wt_f2*>(q) = *reinterpret_cast<const wt_f2*>(v);
+  else if constexpr (BYTES == 8) *reinterpret_cast<wt_f2*>(q) = *reinterpret_cast<const wt_f2*>(v);
+  else *reinterpret_cast<float*>(q) = *reinterpret_cast<const float*>(v);
 #endif
 }
 template <typename T> __device__ __forceinline__ void handoff_store(cx<T>* base, unsigned idx, cx<T> v) {

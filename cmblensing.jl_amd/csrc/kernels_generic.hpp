@@ -121,25 +121,36 @@ __device__ __forceinline__ cx<T> gen_fetch(const GenDft<T>& a, size_t sl, int se
   }
   return a.inverse ? conj(v) : v;                                     // e^{+i} transform = conj(forward(conj x))
 }
+#ifndef CMBL_WT_GEN
+#define CMBL_WT_GEN 1
+#endif
+template <typename V> __device__ __forceinline__ void gen_wt(V* p, V v) {
+#if CMBL_WT_GEN
+  store_wt<(int)sizeof(V)>(p, &v);
+#else
+  *p = v;
+#endif
+}
 // y = Z[k]; yr = Z[(N - k) % N] (only read for a real pair)
 template <typename T>
 __device__ __forceinline__ void gen_put(const GenDft<T>& a, size_t sl, int seq, int k, cx<T> y, cx<T> yr = cx<T>{}) {
   if (a.inverse) y = conj(y);
   const size_t o = sl * a.out_slice + (size_t)seq * a.out_seq + (size_t)k * a.out_elem;
+  // every output of a transform launch is read by workgroups of the next launch on other XCDs: written through (see handoff_store)
   if (a.out_real) {
-    reinterpret_cast<T*>(a.out)[o] = a.scale * y.x;
-    if (a.out2) reinterpret_cast<T*>(a.out2)[o] = a.scale2 * y.y;
+    gen_wt(reinterpret_cast<T*>(a.out) + o, T(a.scale * y.x));
+    if (a.out2) gen_wt(reinterpret_cast<T*>(a.out2) + o, T(a.scale2 * y.y));
     return;
   }
   if (a.in_real && a.in2) {                                           // split the transform of in + i in2
     const cx<T> c = conj(yr);
     const cx<T> x1 = mk<T>(T(0.5) * (y.x + c.x), T(0.5) * (y.y + c.y)), d = mk<T>(T(0.5) * (y.x - c.x), T(0.5) * (y.y - c.y));
-    reinterpret_cast<cx<T>*>(a.out)[o] = mk<T>(a.scale * x1.x, a.scale * x1.y);
-    reinterpret_cast<cx<T>*>(a.out2)[o] = mk<T>(a.scale2 * d.y, -a.scale2 * d.x);            // d / i
+    gen_wt(reinterpret_cast<cx<T>*>(a.out) + o, mk<T>(a.scale * x1.x, a.scale * x1.y));
+    gen_wt(reinterpret_cast<cx<T>*>(a.out2) + o, mk<T>(a.scale2 * d.y, -a.scale2 * d.x));            // d / i
     return;
   }
   if (a.lmul_out) y = mul_il(y, a.lmul_out[k]);
-  reinterpret_cast<cx<T>*>(a.out)[o] = mk<T>(a.scale * y.x, a.scale * y.y);
+  gen_wt(reinterpret_cast<cx<T>*>(a.out) + o, mk<T>(a.scale * y.x, a.scale * y.y));
 }
 
 template <typename T, int LGL>
