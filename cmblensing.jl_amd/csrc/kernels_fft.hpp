@@ -109,8 +109,16 @@ template <int BYTES> __device__ __forceinline__ void store_wt(void* q, const voi
   else *reinterpret_cast<float*>(q) = *reinterpret_cast<const float*>(v);
 #endif
 }
-template <typename T> __device__ __forceinline__ void handoff_store(cx<T>* base, unsigned idx, cx<T> v) {
-  store_wt<(int)sizeof(cx<T>)>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(cx<T>), &v);
+// Only for transforms whose lines (a column of the column kernels, a row of the row kernels) are at most 16 KB.  Above that -- 2048^2 in
+// double, 4096^2 in single precision -- sc1 LOSES: delta_cols 198 -> 236 us at 2048^2 fp64 and 497 -> 590 us at 4096^2 fp32 with it in
+// the column kernels, and with it in the row storers alone grad lnP +3.4 % at 4096^2 fp32 (the consumers of the written-through rows
+// slow down).  Every shape up to 16 KB gains or is neutral: 512^2 .. 2048^2 fp32, 512^2 and 1024^2 fp64
+// (profiles/r04_ab_write_through.txt).
+template <typename T> __host__ __device__ constexpr bool wt_line(long n) { return (size_t)n * sizeof(cx<T>) <= 16 * 1024; }
+template <typename T> __host__ __device__ constexpr bool wt_cols(int /*C*/, int M) { return wt_line<T>(2 * M); }
+template <typename T, bool WT> __device__ __forceinline__ void handoff_store(cx<T>* base, unsigned idx, cx<T> v) {
+  if constexpr (WT) store_wt<(int)sizeof(cx<T>)>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(cx<T>), &v);
+  else at32(base, idx) = v;
 }
 
 // A column tile of C = MIXW columns is ONE contiguous block of the mixed layout: entry (ky, c) of the tile at x0 sits at
@@ -292,13 +300,13 @@ __device__ __forceinline__ void half_store(const cx<T>* __restrict__ s, cx<T>* _
     const cx<T>* p = s + c * LD;
     if (k == 0) {
       const cx<T> z = p[0];
-      handoff_store<T>(tg, tile_off<C>(0, c, x0, NyhP), mk<T>(z.x + z.y, 0)); handoff_store<T>(tg, tile_off<C>(M, c, x0, NyhP), mk<T>(z.x - z.y, 0));
+      handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<C>(0, c, x0, NyhP), mk<T>(z.x + z.y, 0)); handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<C>(M, c, x0, NyhP), mk<T>(z.x - z.y, 0));
     } else {
       const cx<T> a = p[pad(brevc<LGM>(k))], b = p[pad(brevc<LGM>(k2))];
       const cx<T> e = mk<T>(T(0.5) * (a.x + b.x), T(0.5) * (a.y - b.y)), o = mk<T>(T(0.5) * (a.x - b.x), T(0.5) * (a.y + b.y));
       const cx<T> wo = mul_mi(o * tw[k]);
-      handoff_store<T>(tg, tile_off<C>(k, c, x0, NyhP), e + wo);
-      if (k2 != k) handoff_store<T>(tg, tile_off<C>(k2, c, x0, NyhP), conj(e - wo));
+      handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<C>(k, c, x0, NyhP), e + wo);
+      if (k2 != k) handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<C>(k2, c, x0, NyhP), conj(e - wo));
     }
   }
 }
@@ -418,6 +426,9 @@ __host__ __device__ constexpr int row_ld(int n) { return pad(n) + ((4 - pad(n) %
 #ifndef CMBL_RPW_SMALL
 #define CMBL_RPW_SMALL 4
 #endif
+#ifndef CMBL_RPW_BIG
+#define CMBL_RPW_BIG 4
+#endif
 #ifndef CMBL_XLG_SMALL
 #define CMBL_XLG_SMALL 3      // Nx < 1024: radix-8 stages keep 64+ butterflies per stage for the two waves of a row (512²: step 2.58 -> 2.32 ms)
 #endif
@@ -429,7 +440,7 @@ __host__ __device__ constexpr int row_tw(int nx) { return nx >> 1; }
 // fused radix-2 levels per stage of a row transform
 __host__ __device__ constexpr int row_xlg(int lgnx) { return lgnx >= 10 ? CMBL_XLG : CMBL_XLG_SMALL; }
 template <typename T> __host__ __device__ constexpr int row_rpw(int lgnx, int na) {
-  for (int rpw = (lgnx >= 10 ? 4 : CMBL_RPW_SMALL); rpw >= 1; rpw >>= 1)
+  for (int rpw = (lgnx >= 10 ? CMBL_RPW_BIG : CMBL_RPW_SMALL); rpw >= 1; rpw >>= 1)
     if (((size_t)row_tw(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024) return rpw;
   return 0;
 }
@@ -535,8 +546,11 @@ __device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s
         if (nyq >= 0 && (ky0 + r == 0 || ky0 + r == nyq)) { oa.v[e].y = T(0); ob.v[e].y = T(0); }
       }
       cx<T>* gk = g + (size_t)ky0 * MIXW;                                  // uniform part of the address
-      store_wt<16>(reinterpret_cast<char*>(gk) + (unsigned)((xt * NyhP + r) * MIXW + c) * (unsigned)sizeof(cx<T>), &oa);      // hand-off: see handoff_store
-      store_wt<16>(reinterpret_cast<char*>(gk) + (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c) * (unsigned)sizeof(cx<T>), &ob);
+      const unsigned ia = (unsigned)((xt * NyhP + r) * MIXW + c), ib = (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c);
+      if constexpr (wt_line<T>(Nx)) {                                   // hand-off: see handoff_store
+        store_wt<16>(reinterpret_cast<char*>(gk) + ia * (unsigned)sizeof(cx<T>), &oa);
+        store_wt<16>(reinterpret_cast<char*>(gk) + ib * (unsigned)sizeof(cx<T>), &ob);
+      } else { vec32(gk, ia) = oa; vec32(gk, ib) = ob; }
     }
   }
 }

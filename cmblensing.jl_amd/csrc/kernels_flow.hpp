@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   cx<T>* Wx = tile_base(a.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(a.Wy + moff, x0, NyhP);
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
     const unsigned gi = tile_off<C>(k, c, x0, NyhP);
-    handoff_store<T>(Wx, gi, A); handoff_store<T>(Wy, gi, mul_il(B, lyr[i]));
+    handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, lyr[i]));
   });
 }
 
@@ -530,7 +530,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
     cx<T>* Wx = tile_base(d.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(d.Wy + moff, x0, NyhP);
     pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
       const unsigned gi = tile_off<C>(k, c, x0, NyhP);
-      handoff_store<T>(Wx, gi, A); handoff_store<T>(Wy, gi, mul_il(B, ps.l[i]));    // ly[k] is still in registers from the pair load (same entry mapping)
+      handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, ps.l[i]));    // ly[k] is still in registers from the pair load (same entry mapping)
     });
   }
   CMBL_STAMP(9);

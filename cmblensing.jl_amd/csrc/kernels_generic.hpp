@@ -124,9 +124,9 @@ __device__ __forceinline__ cx<T> gen_fetch(const GenDft<T>& a, size_t sl, int se
 #ifndef CMBL_WT_GEN
 #define CMBL_WT_GEN 1
 #endif
-template <typename V> __device__ __forceinline__ void gen_wt(V* p, V v) {
+template <typename V> __device__ __forceinline__ void gen_wt(V* p, V v, bool wt) {
 #if CMBL_WT_GEN
-  store_wt<(int)sizeof(V)>(p, &v);
+  if (wt) store_wt<(int)sizeof(V)>(p, &v); else *p = v;
 #else
   *p = v;
 #endif
@@ -136,21 +136,22 @@ template <typename T>
 __device__ __forceinline__ void gen_put(const GenDft<T>& a, size_t sl, int seq, int k, cx<T> y, cx<T> yr = cx<T>{}) {
   if (a.inverse) y = conj(y);
   const size_t o = sl * a.out_slice + (size_t)seq * a.out_seq + (size_t)k * a.out_elem;
-  // every output of a transform launch is read by workgroups of the next launch on other XCDs: written through (see handoff_store)
+  // every output of a transform launch is read by workgroups of the next launch on other XCDs: written through (see handoff_store, wt_line)
+  const bool wt = wt_line<T>(a.N);
   if (a.out_real) {
-    gen_wt(reinterpret_cast<T*>(a.out) + o, T(a.scale * y.x));
-    if (a.out2) gen_wt(reinterpret_cast<T*>(a.out2) + o, T(a.scale2 * y.y));
+    gen_wt(reinterpret_cast<T*>(a.out) + o, T(a.scale * y.x), wt);
+    if (a.out2) gen_wt(reinterpret_cast<T*>(a.out2) + o, T(a.scale2 * y.y), wt);
     return;
   }
   if (a.in_real && a.in2) {                                           // split the transform of in + i in2
     const cx<T> c = conj(yr);
     const cx<T> x1 = mk<T>(T(0.5) * (y.x + c.x), T(0.5) * (y.y + c.y)), d = mk<T>(T(0.5) * (y.x - c.x), T(0.5) * (y.y - c.y));
-    gen_wt(reinterpret_cast<cx<T>*>(a.out) + o, mk<T>(a.scale * x1.x, a.scale * x1.y));
-    gen_wt(reinterpret_cast<cx<T>*>(a.out2) + o, mk<T>(a.scale2 * d.y, -a.scale2 * d.x));            // d / i
+    gen_wt(reinterpret_cast<cx<T>*>(a.out) + o, mk<T>(a.scale * x1.x, a.scale * x1.y), wt);
+    gen_wt(reinterpret_cast<cx<T>*>(a.out2) + o, mk<T>(a.scale2 * d.y, -a.scale2 * d.x), wt);            // d / i
     return;
   }
   if (a.lmul_out) y = mul_il(y, a.lmul_out[k]);
-  gen_wt(reinterpret_cast<cx<T>*>(a.out) + o, mk<T>(a.scale * y.x, a.scale * y.y));
+  gen_wt(reinterpret_cast<cx<T>*>(a.out) + o, mk<T>(a.scale * y.x, a.scale * y.y), wt);
 }
 
 template <typename T, int LGL>

@@ -1,12 +1,14 @@
-"""Wall clock (timed mode) of ∇lnP and a CG iteration at 1024² QU / T+QU plus the per-launch kernel times (one launch over all pol
-slices) -- the A/B probe for experiment builds: CMBL_LIB=... python tools/gpu_probe_kernels.py"""
+"""Wall clock (timed mode) of ∇lnP and a CG iteration at N² QU / T+QU plus the per-launch kernel times (one launch over all pol
+slices) -- the A/B probe for experiment builds: CMBL_LIB=... python tools/gpu_probe_kernels.py [N=1024] [f32|f64] [pols=P,IP]"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import cmblensing_jl_amd as C
 from bench import synthetic_cls
-for pol in ("P", "IP"):
-    s = C.load_sim(2.0, 1024, pol, synthetic_cls(), T=torch.float32, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0))
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+DT = torch.float64 if len(sys.argv) > 2 and sys.argv[2] == "f64" else torch.float32
+for pol in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("P", "IP")):
+    s = C.load_sim(2.0, N, pol, synthetic_cls(), T=DT, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0))
     ds, proj, f, phi = s["ds"], s["proj"], s["f"], s["phi"]
     fo, po = ds.mix(f, phi)
     def timeit(fn, n=20):
