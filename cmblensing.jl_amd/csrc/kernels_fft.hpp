@@ -427,7 +427,7 @@ __host__ __device__ constexpr int row_ld(int n) { return pad(n) + ((4 - pad(n) %
 #define CMBL_RPW_SMALL 4
 #endif
 #ifndef CMBL_RPW_BIG
-#define CMBL_RPW_BIG 4
+#define CMBL_RPW_BIG 4        // Nx >= 1024; 2 measured slower for every row kernel in the timed mode (profiles/r04_probe_short_row_groups.txt)
 #endif
 #ifndef CMBL_XLG_SMALL
 #define CMBL_XLG_SMALL 3      // Nx < 1024: radix-8 stages keep 64+ butterflies per stage for the two waves of a row (512²: step 2.58 -> 2.32 ms)
