@@ -100,6 +100,8 @@ template <int BYTES> __device__ __forceinline__ void store_wt(void* q, const voi
   // The compiler cannot see that the asm is a store of more than 64 bits, so it does not keep the two wait states gfx950 needs before a
   // vector instruction overwrites the store's data registers (it scheduled `v_or_b32 v2, ...` right behind `global_store_dwordx4 .., v[2:5]`
   // in k_delta_rows: wrong Gx in single AND double precision).  The s_nop supplies them.
+  // (A relaxed agent-scope __hip_atomic_store compiles to the same `global_store_dword[x2] ... sc1` without asm; measured equal for the
+  // 4 / 8-byte sites, but there is no 16-byte form and two 8-byte stores cost the row storers 2.5 us per launch: r04_ab_write_through.txt)
   if constexpr (BYTES == 16) { const wt_f4 d = *reinterpret_cast<const wt_f4*>(v); asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(q), "v"(d) : "memory"); }
   else if constexpr (BYTES == 8) { const wt_f2 d = *reinterpret_cast<const wt_f2*>(v); asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(q), "v"(d) : "memory"); }
   else { const float d = *reinterpret_cast<const float*>(v); asm volatile("global_store_dword %0, %1, off sc1" : : "v"(q), "v"(d) : "memory"); }
