@@ -130,19 +130,24 @@ def profiler_mean_us(kernel, N, P, B, dtype):
     return None, None
 
 
-def cpu_baseline(N, pol, nsteps, npT=np.float32, dev=None):
+def cpu_baseline(N, pol, nsteps, npT=np.float32, dev=None, dev_exact=None):
     """The NumPy oracle (kind 'port': the Julia reference cannot run here) on the host cores: one ∇lnP evaluation of the same
     workload (bounded sample), timed in the workload's precision.  With `dev` (the device's own inputs and outputs of the timed step,
     as host arrays) the FLOAT64 oracle is also evaluated on exactly those fp32/fp64-rounded inputs and the HIP results are compared with
     it: `parity_at_config` -- the parity statement at the headline size, where the GPU tests' oracle comparisons used to stop at 512².
-    Returns (cpu_baseline, parity_at_config | None)."""
+    `dev_exact`: the same for the step run with the REFERENCE's arithmetic (aliased δϕ velocity, src/lenseflow.jl:198-200; plain
+    working-precision sums, src/util.jl:288-316), against the oracle run the same way.
+    Returns (cpu_baseline, parity_at_config | None, parity of dev_exact | None)."""
     import oracle as O
     rel = lambda a, b: float(np.linalg.norm((np.asarray(a) - b).ravel()) / np.linalg.norm(np.asarray(b).ravel()))
     pm = dict(pad_deg=1.0, apod_deg=1.0)
+    sims = {}
 
     def one(T, inputs=None):
         t0 = time.time()
-        so = O.load_sim(2.0, N, pol, T, pixel_mask=pm, nsteps=nsteps)
+        if T not in sims:
+            sims[T] = O.load_sim(2.0, N, pol, T, pixel_mask=pm, nsteps=nsteps)
+        so = sims[T]
         ds = so["ds"]
         if inputs is None:
             fo, po = ds.mix(so["f"], so["phi"])
@@ -156,7 +161,17 @@ def cpu_baseline(N, pol, nsteps, npT=np.float32, dev=None):
         res = ds.grad_logpdf_mixed(fo, po, alias_quirk=quirk)
         return res, time.time() - t0, t_setup
 
-    parity = None
+    def parity_of(dv, lp, gf, gp):
+        return {"logpdf_rel": float(np.max(np.abs((np.asarray(dv["lp"]) - lp) / lp))), "gf_rel_l2": rel(dv["gf"], gf), "gphi_rel_l2": rel(dv["gp"], gp),
+                "logpdf_hip": [float(x) for x in np.atleast_1d(dv["lp"])], "logpdf_oracle": [float(x) for x in np.atleast_1d(lp)],
+                "alias_quirk": bool(dv["alias_quirk"]), "sum_mode": dv["sum_mode"],
+                "oracle": "float64 NumPy/SciPy oracle (oracle/dataset.py grad_logpdf_mixed) on the device's own rounded f°, ϕ°, d; operators "
+                          "rebuilt from the same spectra / seeds in float64",
+                "tolerance": {"f32": "3 x the errors measured at this size, tests/test_gpu_headline_parity.py: logpdf 5e-8, ∇f° 6e-6 (QU) / 1.2e-4 (T+QU), "
+                                     "∇ϕ° 7.5e-7 / 9.5e-6", "f64": "1e-10 / 1e-9 / 1e-9"}[
+                    "f32" if dv["fo"].dtype == np.float32 else "f64"]}
+
+    parity = parity_exact = None
     if dev is not None and npT == np.float64:
         (lp, gf, gp), dt, t_setup = one(np.float64, dev)               # one evaluation serves both legs
     else:
@@ -164,18 +179,17 @@ def cpu_baseline(N, pol, nsteps, npT=np.float32, dev=None):
         if dev is not None:
             (lp, gf, gp), dt64, _ = one(np.float64, dev)
     if dev is not None:
-        parity = {"logpdf_rel": float(np.max(np.abs((np.asarray(dev["lp"]) - lp) / lp))), "gf_rel_l2": rel(dev["gf"], gf), "gphi_rel_l2": rel(dev["gp"], gp),
-                  "logpdf_hip": [float(x) for x in np.atleast_1d(dev["lp"])], "logpdf_oracle": [float(x) for x in np.atleast_1d(lp)],
-                  "alias_quirk": bool(dev["alias_quirk"]), "sum_mode": dev["sum_mode"],
-                  "oracle": "float64 NumPy/SciPy oracle (oracle/dataset.py grad_logpdf_mixed) on the device's own rounded f°, ϕ°, d; operators "
-                            "rebuilt from the same spectra / seeds in float64",
-                  "tolerance": {"f32": "3 x the errors measured at this size, tests/test_gpu_headline_parity.py: logpdf 5e-8, ∇f° 6e-6 (QU) / 1.2e-4 (T+QU), "
-                                       "∇ϕ° 7.5e-7 / 9.5e-6", "f64": "1e-10 / 1e-9 / 1e-9"}[
-                      "f32" if dev["fo"].dtype == np.float32 else "f64"]}
+        parity = parity_of(dev, lp, gf, gp)
+    if dev_exact is not None:
+        (lpe, gfe, gpe), _, _ = one(np.float64, dev_exact)
+        parity_exact = parity_of(dev_exact, lpe, gfe, gpe)
+        parity_exact["note"] = ("the step run with the reference's arithmetic as written (alias_quirk = true: src/lenseflow.jl:198-200; sums in the "
+                                "working precision: src/util.jl:288-316) against the float64 oracle with the same aliasing; logpdf carries the "
+                                "rounding of a working-precision sum over all modes")
     base = dict(value=1.0 / dt, unit="steps/s", cores=int(os.environ.get("CMBL_ORACLE_FFT_WORKERS", os.cpu_count() or 1)),
                 kind="port", sample=f"1 ∇logpdf(Mixed) evaluation, {N}² {pol} {np.dtype(npT).name}, n={nsteps}, NumPy/SciPy-pocketfft oracle "
                 f"({dt:.2f} s; setup {t_setup:.1f} s not counted)")
-    return base, parity
+    return base, parity, parity_exact
 
 
 CONFIGS = {2: dict(nside=512, pol="P", dtype="f32", nrk=7), 3: dict(nside=1024, pol="IP", dtype="f32", nrk=7),
@@ -252,9 +266,16 @@ def config_extras(C, torch, cfg, sim, timeit):
                   map_joint_note="one MAP_joint step from ϕ = 0: Wiener CG capped at 100 iterations + ∇logpdf(Mixed) + Brent line search")
         ex["cg_iteration"] = cg_block(C, torch, sim)
     if cfg == 5:
-        C.quadratic_estimate(ds, "EB")
-        t0 = time.perf_counter(); C.quadratic_estimate(ds, "EB"); torch.cuda.synchronize()
-        ex["quadratic_estimate_EB_ms"] = (time.perf_counter() - t0) * 1e3
+        # quadratic_estimate(:EB) (src/quadratic_estimate.jl:29-200): the library's own loop body (cmbl_quadratic_estimate: control flow on
+        # the host inside the library, every field operation a launch) is what a non-Python host calls; the Python driver of the same
+        # estimator (host-side NumPy algebra between the launches) is kept beside it
+        for name, fn in (("quadratic_estimate_EB_ms", C.quadratic_estimate_native), ("quadratic_estimate_EB_python_driver_ms", C.quadratic_estimate)):
+            fn(ds, "EB"); torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); fn(ds, "EB"); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+            ex[name] = min(ts)
+        ex["quadratic_estimate_note"] = "best of 3; quadratic_estimate_EB_ms = cmbl_quadratic_estimate (C ABI), *_python_driver_ms = drivers.quadratic_estimate"
     return ex
 
 
@@ -284,6 +305,47 @@ def assign_devices(world, ndev, backend):
     if backend != "gloo" and ndev < world:
         raise SystemExit(f"--gpus {world} but only {ndev} GPU(s) visible: one rank per GPU (use --dist-backend gloo to share devices in tests)")
     return [r % ndev for r in range(world)]
+
+
+def dry_run(args, torch, dist, rank, world, local, seeds):
+    """`--dry-run-ranks N`: everything of the N-GPU run except the kernels -- N processes, rendezvous on 127.0.0.1, one (mocked) device
+    per rank, seeds = base + 1000 rank, W + K stand-in steps between the same barriers, MAX over ranks, the per-chain gather and the
+    collective report -- over gloo on the CPU, so that the launch path of `python bench.py --gpus 8` is exercised where no 8-GPU node
+    exists (tests/test_bench_launch.py).  The reference's counterpart: one worker per GPU, src/util_parallel.jl:73-102."""
+    def step():
+        time.sleep(1e-3)
+        return [float(seeds[0])]
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    barrier(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lp = step()
+    barrier(); dt = time.perf_counter() - t0
+    coll = None
+    lps = lp
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        mine = torch.tensor(lp, dtype=torch.float64)
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        lps = [float(x) for x in torch.cat(allp)]
+        me = {"rank": rank, "device": local, "name": "mock device (dry run)", "pci_bus_id": "mock:%02x" % local, "uuid": "mock-%d" % local,
+              "pid": os.getpid(), "seeds": list(seeds)}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        coll = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": everyone}
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the N-rank launch path (NOT a measurement)", "dry_run": True, "value": world * args.steps / dt, "unit": "stand-in steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
+                          "config": {"workload": "stand-in step (1 ms sleep); mocked devices", "parallelism": f"{world} independent chains (no data-path collective)"},
+                          "logpdf": lps, "collective": coll}, ensure_ascii=False))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def clock_ramp(step, sync, block=5, tol=0.01, max_blocks=60):
@@ -320,7 +382,15 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets the N>1 logic be exercised on a box with fewer GPUs than ranks")
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp spin before the warm-up steps")
+    ap.add_argument("--dry-run-ranks", type=int, default=0, metavar="N",
+                    help="dress rehearsal of the N-GPU run on a box without the GPUs: the self-launch, rank -> device assignment (N mocked devices), "
+                         "per-rank seeds, barriers, MAX-over-ranks timing, the result gather and the collective report all run (gloo, CPU); the "
+                         "step itself is a stand-in.  The line carries \"dry_run\": true and is never a measurement")
     args = ap.parse_args()
+    dry = args.dry_run_ranks > 0
+    if dry:
+        args.gpus, args.dist_backend = args.dry_run_ranks, "gloo"
+        args.no_roofline = args.no_extras = args.no_cpu_baseline = args.no_ramp = True
     if args.config:
         for k, v in CONFIGS[args.config].items():
             setattr(args, k, v)
@@ -333,15 +403,16 @@ def main():
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
-    import cmblensing_jl_amd as C
+    if not dry:
+        import cmblensing_jl_amd as C
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = None
     rccl = None
-    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    local = assign_devices(world, ndev, args.dist_backend)[local]
+    ndev = args.dry_run_ranks if dry else (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    local = assign_devices(world, ndev, "nccl" if dry else args.dist_backend)[local]        # the rehearsal keeps the one-GPU-per-rank rule
     if world > 1 or os.environ.get("CMBL_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -360,6 +431,8 @@ def main():
     tT, npT, sz = (torch.float32, np.float32, 4) if args.dtype == "f32" else (torch.float64, np.float64, 8)
     # every rank = an independent chain: different simulation seeds per rank (seed = base + chain id)
     seeds = (1 + 1000 * rank, 2 + 1000 * rank, 3 + 1000 * rank)
+    if dry:
+        return dry_run(args, torch, dist, rank, world, local, seeds)
     sim = C.load_sim(2.0, N, pol, synthetic_cls(), T=tT, device=local, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0),
                      nsteps=nrk, Nbatch=B, seeds=seeds)
     ds, proj = sim["ds"], sim["proj"]
@@ -427,7 +500,9 @@ def main():
                    "nside": N, "npol": P, "chains_per_gpu": B, "rk4_steps": nrk, "parallelism": f"{world} independent chains (no data-path collective)",
                    # the arithmetic that was timed: CMBL_REFERENCE_EXACT=1 switches both to the reference's
                    "alias_quirk": bool(ds.alias_quirk), "sum_accuracy_mode": "working" if C.reference_exact() else "float64",
-                   "reference_exact": bool(C.reference_exact())},
+                   "reference_exact": bool(C.reference_exact()),
+                   "arithmetic_note": "default of the Python host: consistent δϕ velocity + float64 accumulation (DESIGN.md §3 Q1); the reference's own "
+                                      "arithmetic is timed and compared under extras.reference_exact"},
         "clock_ramp": {"untimed_steps": ramp_steps, "last_block_ms_per_step": ramp_ms,
                        "note": "untimed spin before the W warm-up steps, until two consecutive 5-step blocks agree to 1 %"},
         "logpdf": [float(x) for x in lps],
@@ -435,7 +510,8 @@ def main():
     if rccl is not None:
         out["collective"] = rccl
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # (N > 1: no rank does extra work after the timed region, so none idles at destroy_process_group while rank 0 profiles)
         # per-launch timestamps over a re-run of (at most 20 of) the same steps.  The timed region above runs each pol slice as its
         # own launch chain on its own stream (concurrent half-size launches have no individual bandwidth), so this leg switches that
         # off: one launch over all slices, the same kernels.
@@ -506,6 +582,34 @@ def main():
                                               "note": f"{N}² {pol}, Nbatch = 8 in one call (bench.py --nbatch 8 is the full line of this workload)"}
                 del sim8, fo8, po8
             out["extras"] = ex
+    dev_exact = None
+    if rank == 0 and world == 1 and B == 1 and not args.no_extras and not C.reference_exact():
+        # The same step with the REFERENCE's arithmetic as written: the aliased δϕ velocity (src/lenseflow.jl:198-200 + src/field_vectors.jl:48-49)
+        # and plain sums in the working precision (src/util.jl:288-316).  The default line above times the consistent form with float64
+        # accumulation; this is the mode a Julia caller of julia/CMBLensingHIPExt.jl gets by default.
+        host = lambda t: t.detach().cpu().numpy()
+        old_q = ds.alias_quirk
+        ds.alias_quirk = True
+        proj.set_sum_accuracy_mode("working")
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nex = min(args.steps, 50)
+            for _ in range(nex):
+                lpe, gfe, gpe = step()
+            torch.cuda.synchronize()
+            ms_exact = (time.perf_counter() - t0) / nex * 1e3
+            dev_exact = dict(fo=host(fo.arr), po=host(po.arr), d=host(sim["d"].arr), lp=np.asarray(lpe), gf=host(gfe.arr), gp=host(gpe.arr),
+                             alias_quirk=True, sum_mode="working")
+        finally:
+            ds.alias_quirk = old_q
+            proj.set_sum_accuracy_mode("float64")
+        out.setdefault("extras", {})["reference_exact"] = {
+            "ms_per_step": ms_exact, "steps_per_s": 1e3 / ms_exact, "steps_timed": nex, "alias_quirk": True, "sum_accuracy_mode": "working",
+            "note": "the headline workload with the reference's arithmetic as written (CMBL_REFERENCE_EXACT=1 makes it the default of a process; "
+                    "it is the default of the Julia glue julia/CMBLensingHIPExt.jl); same launches, the switch sits in k_dphi_reduce and in "
+                    "the accumulators of the reductions"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dev = None
         if B == 1:
@@ -513,9 +617,11 @@ def main():
             host = lambda t: t.detach().cpu().numpy()
             dev = dict(fo=host(fo.arr), po=host(po.arr), d=host(sim["d"].arr), lp=np.asarray(lp), gf=host(gf.arr), gp=host(gp.arr),
                        alias_quirk=bool(ds.alias_quirk), sum_mode="working" if C.reference_exact() else "float64")
-        out["cpu_baseline"], par = cpu_baseline(N, pol, nrk, npT, dev)
+        out["cpu_baseline"], par, par_exact = cpu_baseline(N, pol, nrk, npT, dev, dev_exact)
         if par is not None:
             out["parity_at_config"] = par
+        if par_exact is not None:
+            out["extras"]["reference_exact"]["parity_at_config"] = par_exact
     if rank == 0:
         print(json.dumps(out, ensure_ascii=False))
     if dist is not None:

@@ -5,11 +5,13 @@ Mirrors the reference's on-disk structure (src/sampling.jl:230-256,311-320; src/
 previous write; a sample is a dict of scalars (every step) plus maps (first step, every `nsavemaps`-th step, and -- so that a
 resumed run continues exactly -- the last step of every chunk).  Two containers, chosen by the file name's extension:
 
-  `.jld2`  the reference's own format (JLD2, an HDF5 dialect), written by jld2_writer.py: `rundat` and `chunks_k` =
-           Vector{Vector{Any}} of `Dict{Symbol,Any}` samples under the reference's key names (ϕ, f, lnP, ΔH, i, θ), appended like
-           `jldopen(filename, "a+")`.  Maps are stored as plain arrays, not as `BaseField` structs (jld2_writer.py says why), and
-           the file has never been opened by JLD2.jl itself (no Julia in the build image): the format follows the reference's own
-           data file structure by structure and round-trips through the reader here.
+  `.jld2`  EXPERIMENTAL output in the reference's container (JLD2, an HDF5 dialect), written by jld2_writer.py: `rundat` and `chunks_k` =
+           Vector{Vector{Any}} of `Dict{Symbol,Any}` samples under the reference's state keys (ϕ, f, logpdf, ΔH, accept, step, θ;
+           src/sampling.jl:290,396-402,446) with the reference's step numbering (initial state = step 1), appended like
+           `jldopen(filename, "a+")`.  Stated limits: maps are stored as plain arrays, not as `BaseField` structs, θ as a `Dict` rather than a
+           `NamedTuple`, the initial state is not saved as a first sample, and NO file written here has ever been opened by JLD2.jl (no Julia
+           in the build image) -- the layout follows the reference's own data file structure by structure and round-trips through the
+           reader here, which cannot prove that Julia's `load_chains` accepts it.  `.zip` is the documented container of this package.
   `.zip`   a plain zip archive whose members are `.npy` arrays, `chunks_<k>/chain<c>/<i>/<key>.npy`, appended in place.
 
 Reading: `load_chains`, `read_rundat`, `chunk_indices`, `read_chunk` and `last_state` open both, including `.jld2` chains written by
@@ -30,7 +32,7 @@ import numpy as np
 EXT = ".zip"
 JLD2_EXT = ".jld2"
 EXTS = (EXT, JLD2_EXT)
-# reference state keys (src/sampling.jl:388-464) -> the names this package's chain files use
+# reference state keys (src/sampling.jl:388-464; `i` / `lnP`: legacy aliases, read side only) -> the names this package's chain files use
 JLD2_KEYS = {"ϕ": "phi", "ϕ°": "phi_mixed", "f°": "f_mixed", "f̃": "ftilde", "ΔH": "dH", "lnP": "logpdf", "i": "step"}
 
 
@@ -108,15 +110,22 @@ def check_filename(filename, resume):
                          f"`filename=<new file>, resume='{filename}'`.")
 
 
-_TO_JULIA = {v: k for k, v in JLD2_KEYS.items()}
+# this package's sample keys -> the state keys of the reference (src/sampling.jl:396-402 `@pack! state = ϕ°, Ω, ΔH, accept`, :446
+# `@pack! state = f̃, logpdf`, :290 `setindex!.(states, step, :step)`).  `step` and `logpdf` ARE the reference's names and stay; the
+# legacy aliases `i` / `lnP` of JLD2_KEYS are understood on the read side only.
+_TO_JULIA = {"phi": "ϕ", "phi_mixed": "ϕ°", "f_mixed": "f°", "ftilde": "f̃", "dH": "ΔH"}
 
 
 def _julia_sample(samp):
-    """sample dict with this package's key names -> the reference's (`theta_<name>` scalars fold into one θ entry)"""
+    """sample dict with this package's key names -> the reference's (`theta_<name>` scalars fold into one θ entry).  The step counter
+    is written in the reference's numbering -- its initial state is step 1 and the first Gibbs pass step 2 (src/sampling.jl:263,288-290),
+    here the first pass is step 1 -- so that `@unpack step = states[1]` (:256) of a resuming Julia session continues at the right pass."""
     out, theta = {}, {}
     for k, v in samp.items():
         if k.startswith("theta_"):
             theta[k[6:]] = float(v)
+        elif k == "step":
+            out["step"] = int(v) + 1
         else:
             out[_TO_JULIA.get(k, k)] = v
     if theta:
@@ -251,10 +260,10 @@ def last_state(filename):
     if any("phi" not in s for s in last):
         raise ValueError(f"last sample of {filename} carries no maps")
     step = int(last[0]["step"])
-    if written_by_julia(filename):
-        # what differs between the two packages: the basis a field was saved in (a Map-basis ϕ or f is a real array: transform it,
-        # NumPy (.., Nx, Ny) == Julia (Ny, Nx, ..) so the half-plane is the last axis) and the step counter (the reference stores the
-        # initial state as step 1, src/sampling.jl:268,277)
+    if _is_jld2(filename):
+        # a `.jld2` chain file -- the Julia package's or jld2_writer.py's -- holds the reference's conventions: a field may be saved in
+        # the Map basis (a real array: transform it; NumPy (.., Nx, Ny) == Julia (Ny, Nx, ..) so the half-plane is the last axis), and the
+        # step counter has the initial state as step 1 (src/sampling.jl:263,288-290)
         for s in last:
             for k in ("phi", "f"):
                 if k in s and not np.iscomplexobj(s[k]):

@@ -283,7 +283,7 @@ int cmbl_timer_report(cmbl_ctx* ctx, char* buf, size_t buflen) {
   return rc == CMBL_OK ? need : -rc;
 }
 int cmbl_device_malloc(cmbl_ctx* ctx, size_t bytes, void** out) {
-  return guard([&] { NOTNULL(ctx); NOTNULL(out); CMBL_HIP(hipSetDevice(ctx->p->device)); hipError_t e = hipMalloc(out, bytes); if (e != hipSuccess) { *out = nullptr; fail(ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e)); } });
+  return guard([&] { NOTNULL(ctx); NOTNULL(out); CMBL_HIP(hipSetDevice(ctx->p->device)); hipError_t e = hipMalloc(out, bytes); if (e != hipSuccess) { *out = nullptr; (void)hipGetLastError(); fail(ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e)); } });
 }
 int cmbl_device_free(cmbl_ctx* ctx, void* p) { return guard([&] { NOTNULL(ctx); CMBL_HIP(hipSetDevice(ctx->p->device)); if (p) CMBL_HIP(hipFree(p)); }); }
 int cmbl_copy_to_device(cmbl_ctx* ctx, void* dst, const void* src, size_t bytes) {

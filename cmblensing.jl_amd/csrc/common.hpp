@@ -60,7 +60,9 @@ struct DevBuf {
     if (n <= bytes) return;
     release();
     hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) { p = nullptr; fail(ERR_ALLOC, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e)); }
+    // (a failed hipMalloc also leaves its code in the runtime's last-error slot: cleared here, or the hipGetLastError behind the NEXT
+    //  kernel launch would report an out-of-memory error for a launch that succeeded)
+    if (e != hipSuccess) { p = nullptr; bytes = 0; (void)hipGetLastError(); fail(ERR_ALLOC, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e)); }
     bytes = n;
   }
   template <typename U> U* as() const { return reinterpret_cast<U*>(p); }

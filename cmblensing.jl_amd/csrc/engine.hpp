@@ -59,7 +59,7 @@ static const char* const kKernelNames[K_COUNT] = {"layout", "y_r2c", "y_c2r", "x
 // plus one wider / narrower neighbour for CMBL_TUNE_C sweeps; 1024-thread and R = 16 variants of lgM 9 / 10 spilled registers and were
 // never selected.
 #ifndef CMBL_COL_LIST
-#define CMBL_COL_LIST(X) X(4, 1, 256) X(5, 1, 256) X(5, 2, 256) X(6, 1, 256) X(6, 2, 256) X(7, 2, 256) X(7, 4, 256) X(8, 4, 256) X(8, 8, 256) \
+#define CMBL_COL_LIST(X) X(4, 1, 256) X(5, 1, 256) X(5, 2, 256) X(6, 1, 256) X(6, 2, 256) X(7, 2, 128) X(7, 2, 256) X(7, 4, 256) X(8, 2, 256) X(8, 4, 256) X(8, 8, 256) \
                          X(9, 4, 256) X(9, 8, 256) X(10, 8, 256) X(11, 4, 1024) X(11, 2, 1024) \
                          X(8, 2, 512) X(8, 4, 512) X(9, 4, 512) X(9, 8, 512) X(10, 4, 512) X(10, 8, 512)
 #endif
@@ -91,6 +91,13 @@ struct CtxBase {
     int gen_separable = env_int("CMBL_GEN_SEPARABLE", 1) != 0;            // any-size path: separable stages
     int gen_prologue = env_int("CMBL_GEN_PROLOGUE", 1) != 0;              //   pointwise work in the fetch of the consuming transform
     int gen_xderiv_fused = env_int("CMBL_GEN_XDERIV_FUSED", 1) != 0;      //   d/dx pass as one launch
+    // launch geometry that fills the chip on small maps (profiles/r05_ab_occupancy_tiles.txt): narrower column tiles while a launch has
+    // fewer workgroups than `fill_target` (0: twice the number of CUs), shorter row groups while it has fewer than `row_fill_target`
+    // (0: half the number of CUs -- 130 -> 258 row workgroups at 512^2 QU measured slower, 34 -> 130 at 128^2 17 % faster)
+    int col_pipeline = env_int("CMBL_COL_PIPELINE", 1);                   // only in -DCMBL_EXPERIMENT_COL_PIPELINE builds: two tiles per column workgroup
+    int occupancy_tiles = env_int("CMBL_OCCUPANCY_TILES", 3);             // bit 0: narrower column tiles, bit 1: shorter row groups
+    int fill_target = env_int("CMBL_FILL_TARGET", 0);
+    int row_fill_target = env_int("CMBL_ROW_FILL_TARGET", 0);
   } opts;
   int* opt_ptr(const std::string& k) {
     if (k == "slice_streams") return &opts.slice_streams;
@@ -101,6 +108,10 @@ struct CtxBase {
     if (k == "gen_separable") return &opts.gen_separable;
     if (k == "gen_prologue") return &opts.gen_prologue;
     if (k == "gen_xderiv_fused") return &opts.gen_xderiv_fused;
+    if (k == "col_pipeline") return &opts.col_pipeline;
+    if (k == "occupancy_tiles") return &opts.occupancy_tiles;
+    if (k == "fill_target") return &opts.fill_target;
+    if (k == "row_fill_target") return &opts.row_fill_target;
     return nullptr;
   }
   double theta = 0;
@@ -367,10 +378,15 @@ struct Ctx : CtxBase {
   // NT threads and R packed pairs per thread.
   // CMBL_TUNE_C forces a width, CMBL_TUNE_RX the rows per workgroup of the row kernels (tuning aids).
   struct TileY { int C, NT, R; };
-  mutable TileY tile_cache[2] = {{0, 0, 0}, {0, 0, 0}};       // the choice does not depend on `slices`: made once (host launch path)
+  mutable TileY tile_cache[2][2] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};   // [pair][narrow]: made once per kind (host launch path)
   const int tuneC = env_int("CMBL_TUNE_C", 0), tuneNT = env_int("CMBL_TUNE_NT", 0);
+  // workgroups a launch needs before the tallest row group / the four-column tile is taken (see row_rpw_variants)
+  long fill_target() const { return opts.fill_target > 0 ? opts.fill_target : 2 * num_cus; }
+  long row_fill_target() const { return opts.row_fill_target > 0 ? opts.row_fill_target : num_cus / 2; }
   TileY tileY(long slices, bool pair, int preferNT = 0) const {
-    if (preferNT == 0 && tile_cache[pair].C > 0) return tile_cache[pair];
+    // small maps: a launch of four-column tiles leaves CUs idle (512^2: 128 tiles per slice) -- take the two-column tile where compiled
+    const bool narrow = (opts.occupancy_tiles & 1) && (long)(Nx / 4) * slices < fill_target();
+    if (preferNT == 0 && tile_cache[pair][narrow].C > 0) return tile_cache[pair][narrow];
     static const int list[][3] = {
 #define CMBL_X(lgm, r, nt) {lgm, r, nt},
         CMBL_COL_LIST(CMBL_X)
@@ -386,13 +402,13 @@ struct Ctx : CtxBase {
       const int C = (int)(((long)e[1] * e[2]) >> lgM);
       if (C > Nx || ldsY(C, pair) > 160 * 1024) continue;
       const TileY t{C, e[2], e[1]};
-      if (forceC == C && (forceNT == 0 || forceNT == e[2])) { if (preferNT == 0) tile_cache[pair] = t; return t; }
-      const long score = (C >= 4 ? 1000 - C : C) * 10 + (e[2] == preferNT ? 3 : (e[2] == 512 ? 2 : (e[2] == 256 ? 1 : 0)));
+      if (forceC == C && (forceNT == 0 || forceNT == e[2])) { if (preferNT == 0) tile_cache[pair][narrow] = t; return t; }
+      const int wantC = narrow ? 2 : 4;
+      const long score = (C >= wantC ? 1000 - C : C) * 10 + (e[2] == preferNT ? 3 : (e[2] == 512 ? 2 : (e[2] == 256 ? 1 : 0)));
       if (score > bestScore) { bestScore = score; best = t; }
     }
-    (void)slices;
     CMBL_REQUIRE(best.C > 0, ERR_SHAPE, "no compiled column-tile shape fits this Ny / precision");
-    if (preferNT == 0) tile_cache[pair] = best;
+    if (preferNT == 0) tile_cache[pair][narrow] = best;
     return best;
   }
   // column tile: twiddles + C columns of an N-point (pair) or M-point (packed) transform, padded rows
@@ -413,6 +429,13 @@ struct Ctx : CtxBase {
     }
     return tileY(slices, true);
   }
+  // tiles per workgroup of the experimental software-pipelined column kernel (-DCMBL_EXPERIMENT_COL_PIPELINE; col_pipelined shapes)
+  int col_tpw(int tiles, long slices) const {
+    if (opts.col_pipeline <= 0) return 1;
+    int tpw = 2;
+    while (tpw > 1 && (tiles % (8 * tpw) != 0 || (long)(tiles / tpw) * slices < num_cus)) tpw >>= 1;
+    return tpw;
+  }
   size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
   // Row launches: one workgroup per group of RPW adjacent ky rows of a slice (RPW = row_rpw<T>(lgNx, row sets), kernels_fft.hpp)
   // Row launches of about one workgroup per CU (258 row groups at 1024^2 QU) run faster when no CU hosts two of them: two co-resident
@@ -422,6 +445,21 @@ struct Ctx : CtxBase {
   size_t lds_apart(size_t lds, long nblk) const { return (lds_one_per_cu && nblk <= num_cus + num_cus / 8) ? std::max(lds, lds_one_per_cu) : lds; }
   size_t ldsX(int rpw, int nbuf) const { return ((size_t)row_tw(Nx) + (size_t)nbuf * rpw * row_ld(Nx)) * sizeof(cx<T>); }
   long row_groups(long slices, int rpw) const { return slices * ((Nyh + rpw - 1) / rpw); }
+  // rows per row workgroup of a launch over `slices` slices: the LDS-fit maximum unless the launch would then leave CUs idle
+  int pick_rpw(int rpw_max, int lgnx, long slices) const {
+    if (!(opts.occupancy_tiles & 2) || !row_rpw_variants(lgnx)) return rpw_max;
+    int rpw = rpw_max;
+    while (rpw > 1 && row_groups(slices, rpw) < row_fill_target()) rpw >>= 1;
+    return rpw;
+  }
+  template <int RPWMAX, int LGNX, typename Fn> void dispatch_rpw(long slices, Fn&& fn) const {
+    if constexpr (row_rpw_variants(LGNX)) {
+      const int rpw = pick_rpw(RPWMAX, LGNX, slices);
+      if constexpr (RPWMAX >= 4) { if (rpw == 4) return fn(std::integral_constant<int, 4>{}); }
+      if constexpr (RPWMAX >= 2) { if (rpw == 2) return fn(std::integral_constant<int, 2>{}); }
+      fn(std::integral_constant<int, 1>{});
+    } else fn(std::integral_constant<int, RPWMAX>{});
+  }
 
   template <typename Fn> void dispatch_col(const TileY& t, Fn&& fn) const {
     bool done = false;
@@ -482,11 +520,14 @@ struct Ctx : CtxBase {
     CMBL_REQUIRE(in != out, ERR_ARG, "x pass cannot run in place (tiled mixed layout on one side)");
     CMBL_REQUIRE(!generic, ERR_STATE, "fused row pass called on the any-size path");
     dispatch_row([&](auto lgnx) {
-      constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 1);
-      if constexpr (RPW > 0) {
-        CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), row_nt(RPW), (k_x_fft<T, MODE, LGNX, RPW>), dim3((unsigned)row_groups(slices, RPW)),
-                       ldsX(RPW, 1), st,
-                       in, out, twX.as<cx<T>>(), dlx_over_Nx, Nyh);
+      constexpr int LGNX = decltype(lgnx)::value, RPWMAX = row_rpw<T>(LGNX, 1);
+      if constexpr (RPWMAX > 0) {
+        dispatch_rpw<RPWMAX, LGNX>(slices, [&](auto rpw_) {
+          constexpr int RPW = decltype(rpw_)::value;
+          CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), row_nt(RPW), (k_x_fft<T, MODE, LGNX, RPW>), dim3((unsigned)row_groups(slices, RPW)),
+                         ldsX(RPW, 1), st,
+                         in, out, twX.as<cx<T>>(), dlx_over_Nx, Nyh);
+        });
       } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
     });
   }
@@ -1084,9 +1125,14 @@ struct Flow {
           x.Wx = a.Wx; x.Wy = a.Wy; x.Y0 = out + so; x.acc = Yacc.as<cx<T>>() + so; x.Hnext = H.as<cx<T>>() + som;
           x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.Nyh = c->Nyh; x.rk = rk;
           c->dispatch_row([&](auto lgnx) {
-            constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
-            if constexpr (RPW > 0) {
-              CMBL_LAUNCH_NT(c, K_ADJ_X, row_nt(RPW), (k_adj_x<T, LGNX, RPW>), dim3((unsigned)c->row_groups(gs, RPW)), c->lds_apart(c->ldsX(RPW, 2), c->row_groups(gs, RPW)), st, x);
+            constexpr int LGNX = decltype(lgnx)::value, RPWMAX = row_rpw<T>(LGNX, 2);
+            if constexpr (RPWMAX > 0) {
+              c->template dispatch_rpw<RPWMAX, LGNX>(gs, [&](auto rpw_) {
+                constexpr int RPW = decltype(rpw_)::value;
+                // (lds_apart keeps two FULL-height groups off one CU; shorter groups are meant to share)
+                const size_t lds = RPW == RPWMAX ? c->lds_apart(c->ldsX(RPW, 2), c->row_groups(gs, RPW)) : c->ldsX(RPW, 2);
+                CMBL_LAUNCH_NT(c, K_ADJ_X, row_nt(RPW), (k_adj_x<T, LGNX, RPW>), dim3((unsigned)c->row_groups(gs, RPW)), lds, st, x);
+              });
             } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
           });
         }
@@ -1142,6 +1188,17 @@ struct Flow {
           d.w1p = Wst.as<T>() + ((size_t)(2 * it) * slices + so) * np; d.w2p = d.w1p + (size_t)slices * np;
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
             constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
+            // one-workgroup-per-CU shapes (2048 rows in double precision) walk several tiles per workgroup with the next tile's loads
+            // under the current tile's last phase (delta_y_body_pipelined)
+#ifdef CMBL_EXPERIMENT_COL_PIPELINE      // measured and rejected (profiles/r05_ab_col_pipeline_rejected.txt); the kernel is kept for the record
+            if constexpr (col_pipelined<T>(LGM)) {
+              const int tiles = c->Nx / tile.C, tpw = c->col_tpw(tiles, gs);
+              if (tpw == 2) {
+                CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_cols_pl<T, R, NT, LGM, 2>), dim3(tiles / tpw, (unsigned)gs), c->ldsY(tile.C), st, d);
+                return;
+              }
+            }
+#endif
             CMBL_LAUNCH_NT(c, K_DELTA_Y, NT, (k_delta_cols<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)gs), c->ldsY(tile.C), st, d);
           });
           // delta-f row pass (RK update of df + next H) + d/dx of the next stage's f (a_nxt holds A_{s+1} after this column launch)
@@ -1150,10 +1207,13 @@ struct Flow {
           x.twX = c->twX.template as<cx<T>>(); x.lx_r = c->lx_r.template as<T>(); x.Nyh = c->Nyh; x.rk = rk;
           GradXArgs<T> gx{a_nxt + spm, Gx.as<cx<T>>() + spm, x.twX, c->dlx_over_Nx, c->Nyh};
           c->dispatch_row([&](auto lgnx) {
-            constexpr int LGNX = decltype(lgnx)::value, RPW = row_rpw<T>(LGNX, 2);
-            if constexpr (RPW > 0) {
-              const int nb_adj = (int)c->row_groups(gs, RPW);
-              CMBL_LAUNCH_NT(c, K_DELTA_ROWS, row_nt(RPW), (k_delta_rows<T, LGNX, RPW>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))), c->ldsX(RPW, 2), st, x, gx, nb_adj);
+            constexpr int LGNX = decltype(lgnx)::value, RPWMAX = row_rpw<T>(LGNX, 2);
+            if constexpr (RPWMAX > 0) {
+              c->template dispatch_rpw<RPWMAX, LGNX>(2 * gs, [&](auto rpw_) {              // adjoint part + d/dx part: twice the row groups
+                constexpr int RPW = decltype(rpw_)::value;
+                const int nb_adj = (int)c->row_groups(gs, RPW);
+                CMBL_LAUNCH_NT(c, K_DELTA_ROWS, row_nt(RPW), (k_delta_rows<T, LGNX, RPW>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))), c->ldsX(RPW, 2), st, x, gx, nb_adj);
+              });
             } else fail(ERR_SHAPE, "row tile does not fit LDS (Nx too large for this precision)");
           });
         }

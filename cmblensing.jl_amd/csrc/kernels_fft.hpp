@@ -389,6 +389,19 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
       }
     }
   }
+  // the two tiles alone (l = ly[k] depends on the entry index only: a workgroup that walks several tiles keeps it from its first issue)
+  __device__ __forceinline__ void issue_xy(const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY, int x0) {
+    const cx<T>* tX = tile_base(gX, x0, mixed_rows(M + 1));
+    const cx<T>* tY = tile_base(gY, x0, mixed_rows(M + 1));
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int e = threadIdx.x + i * NT;
+      if (e < TOT) {
+        const unsigned gi = tile_off<C>(e >> LGC, e & (C - 1), x0, mixed_rows(M + 1));
+        X[i] = at32(tX, gi); Y[i] = at32(tY, gi);
+      }
+    }
+  }
   template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
 #pragma unroll
     for (int i = 0; i < K; ++i) {
@@ -446,6 +459,11 @@ template <typename T> __host__ __device__ constexpr int row_rpw(int lgnx, int na
     if (((size_t)row_tw(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024) return rpw;
   return 0;
 }
+// Row-group heights compiled BESIDES the LDS-fit maximum.  Below Nx = 1024 a launch over groups of four rows has fewer workgroups than
+// the chip has CUs (512^2 QU: 2 x 65 = 130 on 256 CUs, 256^2: 66), and a launch lasts as long as one workgroup's chain whatever the
+// number of idle CUs: heights 2 and 1 are compiled as well and the launch site takes the tallest group that still fills the chip
+// (Ctx::pick_rpw; profiles/r05_ab_occupancy_tiles.txt).  From Nx = 1024 on the tallest group always fills it.
+__host__ __device__ constexpr bool row_rpw_variants(int lgnx) { return lgnx < 10; }
 // Block -> (slice, first row).  nblk = row groups of the launch (slices * ceil(Nyh / RPW)).  The full groups of all slices come
 // first and the short ones (Nyh = Ny/2 + 1 leaves one Nyquist row per slice) LAST: the launches are one residency wave, so the
 // blocks beyond the CU count share a CU with an earlier block -- a one-row group there costs its host little, a second full group

@@ -34,6 +34,9 @@ __device__ __forceinline__ void flow_pm(T t, T gx, T gy, T hxx, T hyx, T hyy, T&
 // tile is small enough (R <= 4 single precision) that the cap costs at most a handful of spilled registers.
 template <typename T> constexpr int col_min_waves(int R, int NT) { return (sizeof(T) == 4 && R <= 4 && NT >= 256) ? 4 : 1; }
 
+// shapes whose column workgroups are alone on their CU and walk several tiles with software-pipelined loads (delta_y_body_pipelined)
+template <typename T> constexpr bool col_pipelined(int lgm) { return sizeof(T) == 8 && lgm >= 10; }
+
 // pcx/pcy: p(t) of the current stage time from the per-phi cache (k_pcache), or nullptr -> formed from the five maps
 template <typename T> struct PhiMaps { const T *gx, *gy, *hxx, *hyx, *hyy; int Bphi; const T *pcx, *pcy; };
 
@@ -544,6 +547,111 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   CMBL_WSTAMP(15);
 }
 
+#ifdef CMBL_EXPERIMENT_COL_PIPELINE
+// EXPERIMENT, measured and rejected in round 5 (-DCMBL_EXPERIMENT_COL_PIPELINE; profiles/r05_ab_col_pipeline_rejected.txt).
+// The same stage with the workgroup walking TPW tiles and the next tile's pair tile requested under the current tile's last phase.  For
+// shapes whose register footprint leaves ONE workgroup per CU -- 2048 rows in double precision: 244 registers x 512 threads is the CU's
+// whole register file -- nothing overlaps a workgroup's exposed waits: in-kernel stamps at 2048^2 fp64
+// (profiles/r05_stamps_delta_cols_2048_f64.txt) show 18.9k of a workgroup's 45.8k cycles spent waiting for its pair tile.  What killed it is
+// the compiler, not the idea: as soon as one thread walks two tiles -- as a loop or unrolled, WITH or WITHOUT the prefetch -- hipcc keeps
+// the tile-independent address values of all load / store sites live across the tiles (loop-invariant code motion / common
+// subexpressions) and spills 228-596 bytes per lane, which the launch then moves through the vector memory path: (grad L)' 14.4 -> 17.0 ms.
+template <typename T, int R, int NT, int LGM, int TPW>
+__device__ __forceinline__ void delta_y_body_pipelined(const DeltaYArgs<T>& d, unsigned char* smem, size_t sl) {
+  constexpr int tpw = TPW;
+  using G = ColTile<R, NT, LGM>;
+  constexpr int M = G::M, LGN = G::LGN, LD = G::LDN, Nyh = G::Nyh, C = G::C, LGC = G::LGC;
+  const FlowYArgs<T>& a = d.f;
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* s = tw + M;
+  const int Nx = a.Nx, ntiles = (int)gridDim.x * tpw;
+  const int bphi = a.ph.Bphi == 1 ? 0 : (int)(sl / a.P);
+  const T invNy = T(1) / T(2 * M);
+  constexpr int NyhP = mixed_rows(Nyh);
+  const size_t moff = sl * (size_t)NyhP * Nx;
+  using PM = PairMap<R, NT, LGM>;
+  // tile k of this workgroup: the virtual block blockIdx.x + k * gridDim.x of a one-tile-per-block launch (same XCD for every k when
+  // gridDim.x is a multiple of 8; neighbouring workgroups of an XCD walk neighbouring tiles in step and share their 64-byte lines)
+  auto tile_x0 = [&](int k) { return xcd_tile((int)blockIdx.x + k * (int)gridDim.x, ntiles) * C; };
+  TwStage<T, NT, M> twr;
+  PairStage<T, NT, LGN, LGC> ps;
+  HalfStage<T, NT, LGM, LGC> th;
+  cx<T> px[R], py[R];
+  // CMBL_PL_HEAD = 1: the pair tile alone is prefetched (it alone gates the first transform); 2: p(t) and the delta-f tile as well (118
+  // registers carried across the loop: 596 bytes of scratch per lane in double precision)
+#ifndef CMBL_PL_HEAD
+#define CMBL_PL_HEAD 1
+#endif
+  auto issue_rest = [&](int x0) {
+    const size_t pbase = ((size_t)bphi * Nx + x0) * M;
+#pragma unroll
+    for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase, (unsigned)PM::e(i), a.rk.t, px[i], py[i]);
+    th.issue(d.H + moff, a.twY, x0);
+  };
+  auto issue_head = [&](int x0) {
+    ps.issue_xy(a.Gx + moff, a.A + moff, x0);
+    if (CMBL_PL_HEAD >= 2) issue_rest(x0);
+  };
+  twr.issue(a.twY);
+  ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, tile_x0(0));
+  if (CMBL_PL_HEAD >= 2) issue_rest(tile_x0(0));
+  twr.commit(tw);
+#pragma unroll
+  for (int k = 0; k < tpw; ++k) {
+    const int x0 = tile_x0(k);
+    const size_t mbase = (sl * Nx + x0) * (size_t)M;
+    if (CMBL_PL_HEAD == 0 && k > 0) ps.issue_xy(a.Gx + moff, a.A + moff, x0);          // timing aid: several tiles, nothing prefetched
+    ps.template commit<LD>(s);
+    if (CMBL_PL_HEAD < 2) issue_rest(x0);
+    __syncthreads();
+    cx<T> dx[R], dy[R];
+    npt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, dx, dy);
+    __syncthreads();
+    th.template commit<LD>(s);
+    cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
+    cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
+    cx<T> fn[R], ldf[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const unsigned e = PM::e(i);
+      fn[i] = at32(reinterpret_cast<const cx<T>*>(a.y0r) + mbase, e);
+      ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : at32(accp, e);
+    }
+    __syncthreads();
+    cx<T> lz[R];
+    mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, lz);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const unsigned e = PM::e(i);
+      cx<T> y0 = fn[i], acc = ldf[i];
+      ldf[i] = lz[i];
+      nt_store(&at32(reinterpret_cast<cx<T>*>(d.w1p) + mbase, e), pmul(ldf[i], dx[i]));
+      nt_store(&at32(reinterpret_cast<cx<T>*>(d.w2p) + mbase, e), pmul(ldf[i], dy[i]));
+      const cx<T> kv = pmul(px[i], dx[i]) + pmul(py[i], dy[i]);
+      fn[i] = rk_update(a.rk, kv, y0, acc);
+      if (a.rk.stage == 4) at32(y0p, e) = y0; else at32(accp, e) = acc;
+    }
+    __syncthreads();
+    npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], ldf[i]); y = pmul(py[i], ldf[i]); });
+    {
+      cx<T>* Wx = tile_base(d.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(d.Wy + moff, x0, NyhP);
+      pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int kk, int c, cx<T> A, cx<T> B) {
+        const unsigned gi = tile_off<C>(kk, c, x0, NyhP);
+        handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, ps.l[i]));
+      });
+    }
+    // the next tile's head: everything it waits for first, requested while this tile's last transform runs
+    if (CMBL_PL_HEAD > 0 && k + 1 < tpw) issue_head(tile_x0(k + 1));
+    if (!a.rk.last) {
+      __syncthreads();
+      mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
+      half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);
+    }
+    __syncthreads();                                          // the tile is rewritten by the next commit
+  }
+}
+
+#endif
 // ---------------------------------------------------------------------------------------------
 // delta-phi.  Its velocity (src/lenseflow.jl:198-206),
 //     d(dphi)/dt = i lx F(u1) + i ly F(u2) - lx^2 F(a) - lx ly F(b) - ly^2 F(c),   F = rfft2,
@@ -665,6 +773,13 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_cols(Delt
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   delta_y_body<T, R, NT, LGM>(d, smem, blockIdx.y);
 }
+#ifdef CMBL_EXPERIMENT_COL_PIPELINE
+template <typename T, int R, int NT, int LGM, int TPW>
+__global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_delta_cols_pl(DeltaYArgs<T> d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  delta_y_body_pipelined<T, R, NT, LGM, TPW>(d, smem, blockIdx.y);
+}
+#endif
 template <typename T, int LGNX, int RPW>
 __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_delta_rows(AdjXArgs<T> a, GradXArgs<T> g, int nblk_adj) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -57,3 +57,30 @@ def test_plain_python_bench_gpus_2_starts_two_ranks():
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-3000:]                     # both ranks ran main() and failed loudly
+
+
+def test_dry_run_of_the_eight_rank_launch():
+    """`python bench.py --dry-run-ranks 8`: the whole N-rank path except the kernels -- self-launch, eight processes, one (mocked) device
+    each, seeds base + 1000 rank, barriers, MAX over ranks, the gather and the collective report -- runs on the CPU over gloo."""
+    import json
+    r = subprocess.run([sys.executable, "bench.py", "--dry-run-ranks", "8", "--steps", "5", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                                         # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 8 and out["steps"] == 5 and out["scaling"] == "weak"
+    c = out["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 8
+    assert [m["rank"] for m in c["ranks"]] == list(range(8))
+    assert sorted(m["device"] for m in c["ranks"]) == list(range(8))                         # one device per rank, each used once
+    assert len({m["pid"] for m in c["ranks"]}) == 8                                          # eight processes
+    assert [m["seeds"] for m in c["ranks"]] == [[1 + 1000 * k, 2 + 1000 * k, 3 + 1000 * k] for k in range(8)]
+    assert out["logpdf"] == [1.0 + 1000 * k for k in range(8)]                               # the per-chain gather, in rank order
+    assert out["value"] > 0 and out["ms_per_step"] >= 1.0                                    # MAX over ranks of a >= 1 ms stand-in step
+
+
+def test_dry_run_refuses_fewer_devices_than_ranks():
+    # under a launcher with more ranks than (mocked) devices the one-GPU-per-rank rule still fires
+    env = dict(os.environ, WORLD_SIZE="4", RANK="3", LOCAL_RANK="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, "bench.py", "--dry-run-ranks", "2", "--gpus", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "only 2 GPU" in r.stderr, r.stderr[-2000:]

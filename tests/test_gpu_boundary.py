@@ -1,0 +1,91 @@
+"""Boundary promises of include/cmblens.h that had no test (VERDICT r04 "limits without tests"):
+
+  * "Independent contexts may be driven from different host threads" (cmblens.h:23): two host threads, each with its OWN context, flow and
+    dataset, run the hot path concurrently; every result equals the same computation run alone, bit for bit.  The error text is per thread.
+  * CMBL_ERR_ALLOC: a request the device cannot satisfy -- directly (cmbl_device_malloc) and inside an operation (the per-stage product
+    scratch of a delta flow with an absurd number of RK steps) -- returns the status code, and the context stays usable afterwards.
+
+Reference counterparts: one GPU worker per process / thread (src/util_parallel.jl:73-102); Julia's OutOfGPUMemoryError surfaces as an
+exception and leaves the session alive."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from bench import synthetic_cls
+
+
+def _workload(C, N, pol, seed):
+    s = C.load_sim(3.0, N, pol, synthetic_cls(), T=torch.float32, pixel_mask=dict(pad_deg=0.4, apod_deg=0.4), seeds=(seed, seed + 1, seed + 2))
+    ds = s["ds"]
+    fo, po = ds.mix(s["f"], s["phi"])
+    return s, ds, fo, po
+
+
+def test_two_host_threads_two_contexts():
+    import cmblensing_jl_amd as C
+    work = [_workload(C, 256, "P", 11), _workload(C, 128, "IP", 21)]              # different sizes, pols: different kernels, LDS limits, streams
+    def run(k, n):
+        s, ds, fo, po = work[k]
+        out = []
+        for _ in range(n):
+            lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
+            out.append((np.asarray(lp).copy(), gf.arr.clone(), gp.arr.clone()))
+        return out
+    alone = [run(0, 1)[0], run(1, 1)[0]]
+    res, errs = [None, None], []
+    def body(k):
+        try:
+            res[k] = run(k, 25)
+        except Exception as e:                                                  # noqa: BLE001
+            errs.append((k, repr(e)))
+    th = [threading.Thread(target=body, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for k in range(2):
+        for lp, gf, gp in res[k]:
+            assert np.array_equal(lp, alone[k][0]) and torch.equal(gf, alone[k][1]) and torch.equal(gp, alone[k][2]), f"thread {k}: result differs from the run alone"
+
+
+def test_error_text_is_per_thread():
+    import cmblensing_jl_amd as C
+    lib = C.load_library()
+    s, ds, fo, po = _workload(C, 64, "I", 5)
+    p = s["proj"]
+    seen = {}
+    def bad():
+        v = ctypes.c_int(0)
+        rc = lib.cmbl_ctx_get_option(p._h, b"no_such_option", ctypes.byref(v))
+        seen["rc"], seen["msg"] = rc, lib.cmbl_last_error().decode()
+    t = threading.Thread(target=bad); t.start(); t.join()
+    assert seen["rc"] == 1 and "no_such_option" in seen["msg"]                   # CMBL_ERR_ARG, text available in the thread that failed
+    assert "no_such_option" not in lib.cmbl_last_error().decode()                # ... and not in this one
+    ds.gradient_logpdf_mixed(fo, po)                                             # the context was not disturbed
+
+
+def test_err_alloc_is_reported_and_the_context_survives():
+    import cmblensing_jl_amd as C
+    from cmblensing_jl_amd.lib import CmblError
+    lib = C.load_library()
+    s, ds, fo, po = _workload(C, 256, "P", 7)
+    p = s["proj"]
+    before = ds.gradient_logpdf_mixed(fo, po)
+    # (1) directly: more than the device has (2^46 bytes = 64 TiB)
+    ptr = ctypes.c_void_p(1)
+    rc = lib.cmbl_device_malloc(p._h, ctypes.c_size_t(1 << 46), ctypes.byref(ptr))
+    assert rc == 6 and ptr.value is None and "hipMalloc" in lib.cmbl_last_error().decode()       # CMBL_ERR_ALLOC, *out = NULL
+    # (2) inside an operation: the delta flow keeps 4n x 2 product maps per slice; n = 10^6 RK steps at 256^2 QU asks for 4 TB
+    fm = s["f"].to(C.MAP)
+    Lbig = C.LenseFlow(p, 1_000_000)(s["phi"])
+    with pytest.raises(CmblError) as ei:
+        Lbig.gradient(C.FLOW_FWD, fm, fm.to(C.FOURIER))
+    assert ei.value.code == 6, ei.value
+    del Lbig
+    # the context, its flows and its dataset keep working, with the same results as before the failures
+    after = ds.gradient_logpdf_mixed(fo, po)
+    assert np.array_equal(np.asarray(before[0]), np.asarray(after[0])) and torch.equal(before[1].arr, after[1].arr) and torch.equal(before[2].arr, after[2].arr)

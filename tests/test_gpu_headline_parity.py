@@ -3,6 +3,8 @@
     ∇logpdf(Mixed)            1024² QU fp32   (bench.py's headline step; BASELINE `metric`)        vs float64 oracle on the rounded inputs
     ∇logpdf(Mixed)            1024² T+QU fp32 (BASELINE configs[2], the north_star target)          "
     L*f and its pullback      2048² QU fp64, n = 10 (BASELINE configs[4])                           vs float64 oracle, 1e-10 class
+    the same in fp32          2048² QU fp32, n = 10                                                vs the same oracle results
+    quadratic_estimate(:EB)   2048² QU fp64 (BASELINE configs[4])                                   vs float64 oracle, both drivers
 
 Large-size-only bugs (32-bit offsets, the 448 MB product scratch, tile caches, slice streams) are invisible to <= 512² parity.  The
 oracle takes 10-60 s per case on the GPU box's host cores.  Follows src/dataset.jl:84-117 (logpdf of Mixed), src/flowops.jl:40-53
@@ -45,8 +47,10 @@ def test_grad_logpdf_mixed_1024_fp32_vs_oracle(pol):
         close(f"∇ϕ° 1024² {pol} quirk={quirk}", gp.arr.cpu().numpy(), ogp, TOL_GP[pol])
 
 
-def test_lenseflow_and_pullback_2048_fp64_n10_vs_oracle():
-    import cmblensing_jl_amd as C
+@pytest.fixture(scope="module")
+def oracle_2048():
+    """the float64 oracle's L*f, L'g and pullback at 2048² QU, n = 10 -- computed once (about a minute on the GPU box's host cores) and
+    shared by the double- and the single-precision comparison"""
     N, n = 2048, 10
     oproj = O.Proj(N, N, 2.0, np.float64)
     cl = O.load_camb()["unlensed_total"]
@@ -56,16 +60,59 @@ def test_lenseflow_and_pullback_2048_fp64_n10_vs_oracle():
     g = O.from_harm(oproj, np.sqrt(Cf) * O.rfft2(O.white_noise(4, (1, 2, N, N), np.float64)))
     phi = O.irfft2(np.sqrt(Cphi) * O.rfft2(O.white_noise(2, (1, 1, N, N), np.float64)), N)
     OL = OLenseFlow(oproj, phi, n)
-    p = C.ProjLambert(N, N, 2.0, torch.float64)
-    F = lambda a, b: C.Field(p, p.tensor(a), b)
-    L = C.LenseFlow(p, n)(F(phi, C.MAP))
     want = OL.apply(f)
-    got = L * F(f, C.MAP)
-    close("L*f 2048² QU fp64 n=10", got.arr.cpu().numpy(), want, 1e-12)                       # measured 6.7e-14
     gl = O.rfft2(g)
-    close("L'g 2048² QU fp64 n=10", (L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy(), OL.adj(gl), 1.3e-12)   # 4.2e-13
+    adj = OL.adj(gl)
     f0, df, dp = OL.grad_apply(want, gl)
-    gdp, gdf, gf0 = L.gradient(C.FLOW_FWD, F(want, C.MAP), F(gl, C.FOURIER), alias_quirk=False)
-    close("pullback f 2048²", gf0.arr.cpu().numpy(), f0, 1e-12)                               # 6.7e-14
-    close("pullback δf 2048²", gdf.arr.cpu().numpy(), df, 1.3e-12)                            # 4.2e-13
-    close("pullback δϕ 2048²", gdp.arr.cpu().numpy(), dp, 2.3e-12)                            # 7.6e-13
+    return dict(N=N, n=n, f=f, phi=phi, gl=gl, Lf=want, adj=adj, f0=f0, df=df, dp=dp)
+
+
+def test_lenseflow_and_pullback_2048_fp64_n10_vs_oracle(oracle_2048):
+    import cmblensing_jl_amd as C
+    o = oracle_2048
+    p = C.ProjLambert(o["N"], o["N"], 2.0, torch.float64)
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    L = C.LenseFlow(p, o["n"])(F(o["phi"], C.MAP))
+    got = L * F(o["f"], C.MAP)
+    close("L*f 2048² QU fp64 n=10", got.arr.cpu().numpy(), o["Lf"], 1e-12)                       # measured 6.7e-14
+    close("L'g 2048² QU fp64 n=10", (L.adjoint * F(o["gl"], C.FOURIER)).arr.cpu().numpy(), o["adj"], 1.3e-12)   # 4.2e-13
+    gdp, gdf, gf0 = L.gradient(C.FLOW_FWD, F(o["Lf"], C.MAP), F(o["gl"], C.FOURIER), alias_quirk=False)
+    close("pullback f 2048²", gf0.arr.cpu().numpy(), o["f0"], 1e-12)                               # 6.7e-14
+    close("pullback δf 2048²", gdf.arr.cpu().numpy(), o["df"], 1.3e-12)                            # 4.2e-13
+    close("pullback δϕ 2048²", gdp.arr.cpu().numpy(), o["dp"], 2.3e-12)                            # 7.6e-13
+
+
+def test_lenseflow_and_pullback_2048_fp32_n10_vs_oracle(oracle_2048):
+    """The SINGLE-precision flows at 2048² (4096-sample column lines, plain hand-off stores, 16 KB rows) against the ORACLE -- they used to
+    be compared with the double-precision device operator only (tests/test_gpu_fullsize.py).  Inputs are the oracle's rounded to fp32; the
+    rounding of the inputs (6e-8) is far below the classes' tolerances (tests/_tol.py: forward-type 2e-5, adjoint-type 5e-5, δϕ 1.8e-4)."""
+    import cmblensing_jl_amd as C
+    o = oracle_2048
+    p = C.ProjLambert(o["N"], o["N"], 2.0, torch.float32)
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    L = C.LenseFlow(p, o["n"])(F(o["phi"], C.MAP))
+    close("L*f 2048² QU fp32 n=10 vs oracle", (L * F(o["f"], C.MAP)).arr.cpu().numpy(), o["Lf"], 2e-5)
+    close("L'g 2048² QU fp32 n=10 vs oracle", (L.adjoint * F(o["gl"], C.FOURIER)).arr.cpu().numpy(), o["adj"], 5e-5)
+    gdp, gdf, gf0 = L.gradient(C.FLOW_FWD, F(o["Lf"], C.MAP), F(o["gl"], C.FOURIER), alias_quirk=False)
+    close("pullback f 2048² fp32 vs oracle", gf0.arr.cpu().numpy(), o["f0"], 2e-5)
+    close("pullback δf 2048² fp32 vs oracle", gdf.arr.cpu().numpy(), o["df"], 5e-5)
+    close("pullback δϕ 2048² fp32 vs oracle", gdp.arr.cpu().numpy(), o["dp"], 1.8e-4)
+
+
+def test_quadratic_estimate_EB_2048_fp64_vs_oracle():
+    """BASELINE config 5's second half: quadratic_estimate(:EB) at 2048² QU fp64 (src/quadratic_estimate.jl:29-47,163-200) against the
+    oracle on the same simulated data -- it was compared with the oracle at 256² and through properties only at this size.  Both drivers:
+    the Python one and the library's own loop body (cmbl_quadratic_estimate)."""
+    from test_gpu_parity import _dataset_pair
+    C, so, sd = _dataset_pair("f64", "P", (2048, 2048), theta=2.0, mask=False, beam=1.0)
+    ods, ds, p = so["ds"], sd["ds"], sd["proj"]
+    ds.set_data(C.Field(p, p.tensor(so["d"]), C.HARMONIC))
+    planes = lambda op: {k: op.d[i] for i, k in enumerate(["E", "B"])}
+    TF = {k: planes(ods.Mf)[k] * planes(ods.B)[k] for k in ("E", "B")}
+    dd = {k: so["d"][:, i:i + 1] for i, k in enumerate(("E", "B"))}
+    pq, AL, Nphi = O.quadratic_estimate(so["proj"], "EB", dd, dd, planes(ods.Cf), planes(ods.Cftilde), planes(ods.Cn), ods.Cphi, TF)
+    m = ods.Cphi > 0
+    for name, fn in (("quadratic_estimate", C.quadratic_estimate), ("cmbl_quadratic_estimate", C.quadratic_estimate_native)):
+        got = fn(ds, "EB")
+        scalars_close(f"{name} 2048² fp64: AL", got["AL"][m], AL[m], rtol=1e-9)
+        close(f"{name} 2048² fp64: phiqe", got["phiqe"].arr.cpu().numpy(), pq, 1e-9)

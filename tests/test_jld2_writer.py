@@ -70,11 +70,15 @@ def test_chain_file_layout_append_and_checksums(tmp_path):
     # the reference's key names are what is stored (src/sampling.jl:388-464) ...
     raw = J.to_python(f["chunks_1"])
     assert len(raw) == 3 and len(raw[0]) == 2
-    assert set(raw[0][0]) == {"i", "lnP", "ΔH", "accept", "ncg", "ϕ", "f", "θ"} and raw[0][0]["θ"] == {"r": 0.21, "Aphi": 1.1}
-    # ... and load_chains hands back this package's
+    # `step` and `logpdf` are the reference's own names (src/sampling.jl:290 `setindex!.(states, step, :step)`, :446 `@pack! state = f̃, logpdf`):
+    # `@unpack step = states[1]` (:256) of a resuming Julia session and `chain[:logpdf]` need exactly these; `i` / `lnP` appear nowhere
+    assert set(raw[0][0]) == {"step", "logpdf", "ΔH", "accept", "ncg", "ϕ", "f", "θ"} and raw[0][0]["θ"] == {"r": 0.21, "Aphi": 1.1}
+    # the stored counter is the reference's: initial state = step 1, first Gibbs pass = step 2 (:263,288)
+    assert [s["step"] for s in raw[0]] == [2, 3] and raw[0][0]["logpdf"] == -13.5
+    # ... and load_chains hands back this package's key names with the file's (= the reference's) step numbers, like a Julia-written file
     ch = CF.load_chains(fn)
     assert len(ch) == 3 and len(ch[0]) == 4
-    np.testing.assert_array_equal(ch["step"], np.tile(np.arange(1, 5), (3, 1)))
+    np.testing.assert_array_equal(ch["step"], np.tile(np.arange(2, 6), (3, 1)))
     np.testing.assert_array_equal(ch[1, 2]["phi"], chunk2[1][0]["phi"])
     assert ch[0, 0]["theta_r"] == 0.21 and ch[2, -1]["logpdf"] == -16.5
     k, step, last = CF.last_state(fn)

@@ -1,0 +1,53 @@
+"""A/B of the occupancy-aware launch geometry on small maps: for every setting of (occupancy_tiles, fill_target)
+time L*f, L'g, (grad L)', grad lnP and a Wiener-CG iteration, and check that every result is BIT-IDENTICAL to the reference setting
+(tile width and rows per workgroup change which workgroup computes a column / row, never the arithmetic on it).
+   python tools/gpu_occ_ab.py 512 P [f32|f64]          (CMBL_LIB=... for a dev build)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import cmblensing_jl_amd as C
+from bench import synthetic_cls
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+pol = sys.argv[2] if len(sys.argv) > 2 else "P"
+T = torch.float64 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else torch.float32
+s = C.load_sim(2.0, N, pol, synthetic_cls(), T=T, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0))
+ds, p, f, phi = s["ds"], s["proj"], s["f"], s["phi"]
+fm = f.to(C.MAP); gl = fm.to(C.FOURIER)
+fo, po = ds.mix(f, phi)
+
+def timeit(fn, n=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+def run(occ, target):
+    p.set_option("occupancy_tiles", occ); p.set_option("row_fill_target", target)
+    L = ds.L(phi)
+    ft = L * fm
+    out = dict(Lf=ft.arr.clone(), Ltg=(L.adjoint * gl).arr.clone())
+    dphi, df, _ = L.gradient(C.FLOW_FWD, ft, gl)
+    out["dphi"], out["df"] = dphi.arr.clone(), df.arr.clone()
+    lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
+    out["gf"], out["gp"], out["lp"] = gf.arr.clone(), gp.arr.clone(), torch.tensor(np.asarray(lp))
+    t = [timeit(lambda: L * fm), timeit(lambda: L.adjoint * gl), timeit(lambda: L.gradient(C.FLOW_FWD, ft, gl)), timeit(lambda: ds.gradient_logpdf_mixed(fo, po))]
+    torch.cuda.synchronize(); t0 = time.perf_counter(); ds.argmaxf_logpdf(phi, tol=0.0, nsteps=40); torch.cuda.synchronize()
+    t.append((time.perf_counter() - t0) / 40 * 1e3)
+    return out, t
+
+print(f"N {N} pol {pol} {T}")
+ref = None
+rounds = int(os.environ.get("ROUNDS", 2))
+best = {}
+settings = [(0, 0), (3, 0), (3, 64), (3, 192), (3, 256)]        # (occupancy_tiles, row_fill_target); column target = default
+for r in range(rounds):
+    for occ, tg in settings:
+        out, t = run(occ, tg)
+        if ref is None: ref = out
+        same = all(torch.equal(out[k], ref[k]) for k in ref)
+        best[(occ, tg)] = t if (occ, tg) not in best else [min(a, b) for a, b in zip(best[(occ, tg)], t)]
+        print(f"round {r} occupancy_tiles={occ} row_fill_target={tg or 'default'}: L*f {t[0]:.3f}  L'g {t[1]:.3f}  gradL {t[2]:.3f}  gradlnP {t[3]:.3f}  CG it {t[4]:.3f} ms   bit-identical to first: {same}", flush=True)
+for k, t in best.items():
+    print(f"MIN occupancy_tiles={k[0]} row_fill_target={k[1] or 'default'}: L*f {t[0]:.3f}  L'g {t[1]:.3f}  gradL {t[2]:.3f}  gradlnP {t[3]:.3f}  CG it {t[4]:.3f} ms")

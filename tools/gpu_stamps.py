@@ -7,7 +7,9 @@ os.environ.setdefault("CMBL_SLICE_STREAMS", "1")
 import numpy as np, torch
 import cmblensing_jl_amd as C
 from bench import synthetic_cls
-s = C.load_sim(2.0, 1024, "P", synthetic_cls(), T=torch.float32, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), Nphi="flat")
+N = int(os.environ.get("N", 1024))                          # N=2048 DT=f64 NRK=10 NB=2048: BASELINE config 5
+T = torch.float64 if os.environ.get("DT", "f32") == "f64" else torch.float32
+s = C.load_sim(2.0, N, "P", synthetic_cls(), T=T, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), Nphi="flat", nsteps=int(os.environ.get("NRK", 7)))
 ds, f, phi = s["ds"], s["f"], s["phi"]
 fm = f.to(C.MAP); L = ds.L(phi); gl = fm.to(C.FOURIER); ft = L * fm
 for _ in range(3):
