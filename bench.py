@@ -583,7 +583,7 @@ def main():
                 del sim8, fo8, po8
             out["extras"] = ex
     dev_exact = None
-    if rank == 0 and world == 1 and B == 1 and not args.no_extras and not C.reference_exact():
+    if rank == 0 and world == 1 and B == 1 and not args.no_extras and not args.no_roofline and not C.reference_exact():
         # The same step with the REFERENCE's arithmetic as written: the aliased δϕ velocity (src/lenseflow.jl:198-200 + src/field_vectors.jl:48-49)
         # and plain sums in the working precision (src/util.jl:288-316).  The default line above times the consistent form with float64
         # accumulation; this is the mode a Julia caller of julia/CMBLensingHIPExt.jl gets by default.

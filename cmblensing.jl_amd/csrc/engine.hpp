@@ -384,8 +384,11 @@ struct Ctx : CtxBase {
   long fill_target() const { return opts.fill_target > 0 ? opts.fill_target : 2 * num_cus; }
   long row_fill_target() const { return opts.row_fill_target > 0 ? opts.row_fill_target : num_cus / 2; }
   TileY tileY(long slices, bool pair, int preferNT = 0) const {
-    // small maps: a launch of four-column tiles leaves CUs idle (512^2: 128 tiles per slice) -- take the two-column tile where compiled
-    const bool narrow = (opts.occupancy_tiles & 1) && (long)(Nx / 4) * slices < fill_target();
+    // small maps: a launch of four-column tiles leaves CUs idle (512^2: 128 tiles per slice) -- take the two-column tile where compiled.
+    // `slices` = all slices of the operation, not of one launch chain of it: the choice (and with it the rounding of the results) must not
+    // depend on how a flow is split over streams.  Up to 512 rows only: from 1024 rows on the narrowest tile with C >= 4 measured best
+    // (profiles/r02_variants.txt), and nothing narrower was measured there.
+    const bool narrow = (opts.occupancy_tiles & 1) && lgM <= 8 && (long)(Nx / 4) * slices < fill_target();
     if (preferNT == 0 && tile_cache[pair][narrow].C > 0) return tile_cache[pair][narrow];
     static const int list[][3] = {
 #define CMBL_X(lgm, r, nt) {lgm, r, nt},
@@ -515,14 +518,16 @@ struct Ctx : CtxBase {
                      (T)(1.0 / Ny));
     });
   }
-  template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices, hipStream_t st = nullptr) {
+  // all_slices: the slices of the whole operation when this call is one launch chain of several (the row-group height follows it)
+  template <int MODE> void x_pass(const cx<T>* in, cx<T>* out, long slices, hipStream_t st = nullptr, long all_slices = 0) {
     if (!st) st = stream;
+    if (all_slices <= 0) all_slices = slices;
     CMBL_REQUIRE(in != out, ERR_ARG, "x pass cannot run in place (tiled mixed layout on one side)");
     CMBL_REQUIRE(!generic, ERR_STATE, "fused row pass called on the any-size path");
     dispatch_row([&](auto lgnx) {
       constexpr int LGNX = decltype(lgnx)::value, RPWMAX = row_rpw<T>(LGNX, 1);
       if constexpr (RPWMAX > 0) {
-        dispatch_rpw<RPWMAX, LGNX>(slices, [&](auto rpw_) {
+        dispatch_rpw<RPWMAX, LGNX>(all_slices, [&](auto rpw_) {
           constexpr int RPW = decltype(rpw_)::value;
           CMBL_LAUNCH_NT(this, (MODE == 2 ? K_X_GRAD : K_X_FFT), row_nt(RPW), (k_x_fft<T, MODE, LGNX, RPW>), dim3((unsigned)row_groups(slices, RPW)),
                          ldsX(RPW, 1), st,
@@ -1065,7 +1070,7 @@ struct Flow {
     if (!a_ready) c->y_r2c(in, a_cur, slices);                             // the first RK step reads the state from `in` (y0r), the rest from `out`
     const int K = groups(P, B);
     const long gs = slices / K;                                            // slices per group
-    const auto tile = c->tileY(gs, true);
+    const auto tile = c->tileY(slices, true);
     const double t0 = inverse ? 1.0 : 0.0, h = (inverse ? -1.0 : 1.0) / n;
     fork(K);
     for (int step = 0; step < n; ++step)
@@ -1073,7 +1078,7 @@ struct Flow {
         for (int g = 0; g < K; ++g) {
           hipStream_t st = gstream(g);
           const long so = g * gs;
-          c->template x_pass<2>(a_cur + so * pl, Gx.as<cx<T>>() + so * pl, gs, st);
+          c->template x_pass<2>(a_cur + so * pl, Gx.as<cx<T>>() + so * pl, gs, st, slices);
           FlowYArgs<T> a{};
           a.A = a_cur + so * pl; a.Gx = Gx.as<cx<T>>() + so * pl; a.Anext = a_nxt + so * pl; a.y0 = y + so * np; a.acc = acc.as<T>() + so * np;
           a.y0r = (step == 0 ? in : y) + so * np;
@@ -1104,7 +1109,7 @@ struct Flow {
     if (!h_ready) c->template x_pass<1>(out, H.as<cx<T>>(), slices);
     const int K = groups(P, B);
     const long gs = slices / K;
-    const auto tile = c->tileY(gs, true);
+    const auto tile = c->tileY(slices, true);
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
     fork(K);
     for (int step = 0; step < n; ++step)
@@ -1127,7 +1132,7 @@ struct Flow {
           c->dispatch_row([&](auto lgnx) {
             constexpr int LGNX = decltype(lgnx)::value, RPWMAX = row_rpw<T>(LGNX, 2);
             if constexpr (RPWMAX > 0) {
-              c->template dispatch_rpw<RPWMAX, LGNX>(gs, [&](auto rpw_) {
+              c->template dispatch_rpw<RPWMAX, LGNX>(slices, [&](auto rpw_) {
                 constexpr int RPW = decltype(rpw_)::value;
                 // (lds_apart keeps two FULL-height groups off one CU; shorter groups are meant to share)
                 const size_t lds = RPW == RPWMAX ? c->lds_apart(c->ldsX(RPW, 2), c->row_groups(gs, RPW)) : c->ldsX(RPW, 2);
@@ -1164,7 +1169,7 @@ struct Flow {
     if (!h_ready) c->template x_pass<1>(df, H.as<cx<T>>(), slices);
     const int K = groups(P, B);
     const long gs = slices / K;
-    const auto tile = c->tileY_delta(gs);
+    const auto tile = c->tileY_delta(slices);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
     c->template x_pass<2>(a_cur, Gx.as<cx<T>>(), slices);                // later d/dx passes ride along with the previous stage's row launch
     tc_host.resize(2 * (size_t)nst);
@@ -1209,7 +1214,7 @@ struct Flow {
           c->dispatch_row([&](auto lgnx) {
             constexpr int LGNX = decltype(lgnx)::value, RPWMAX = row_rpw<T>(LGNX, 2);
             if constexpr (RPWMAX > 0) {
-              c->template dispatch_rpw<RPWMAX, LGNX>(2 * gs, [&](auto rpw_) {              // adjoint part + d/dx part: twice the row groups
+              c->template dispatch_rpw<RPWMAX, LGNX>(2 * slices, [&](auto rpw_) {          // adjoint part + d/dx part: twice the row groups
                 constexpr int RPW = decltype(rpw_)::value;
                 const int nb_adj = (int)c->row_groups(gs, RPW);
                 CMBL_LAUNCH_NT(c, K_DELTA_ROWS, row_nt(RPW), (k_delta_rows<T, LGNX, RPW>), dim3((unsigned)(nb_adj + (last ? 0 : nb_adj))), c->ldsX(RPW, 2), st, x, gx, nb_adj);

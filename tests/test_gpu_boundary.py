@@ -3,7 +3,7 @@
   * "Independent contexts may be driven from different host threads" (cmblens.h:23): two host threads, each with its OWN context, flow and
     dataset, run the hot path concurrently; every result equals the same computation run alone, bit for bit.  The error text is per thread.
   * CMBL_ERR_ALLOC: a request the device cannot satisfy -- directly (cmbl_device_malloc) and inside an operation (the per-stage product
-    scratch of a delta flow with an absurd number of RK steps) -- returns the status code, and the context stays usable afterwards.
+    scratch of a delta flow with 512 RK steps on 64 batch slots) -- returns the status code, and the context stays usable afterwards.
 
 Reference counterparts: one GPU worker per process / thread (src/util_parallel.jl:73-102); Julia's OutOfGPUMemoryError surfaces as an
 exception and leaves the session alive."""
@@ -79,13 +79,22 @@ def test_err_alloc_is_reported_and_the_context_survives():
     ptr = ctypes.c_void_p(1)
     rc = lib.cmbl_device_malloc(p._h, ctypes.c_size_t(1 << 46), ctypes.byref(ptr))
     assert rc == 6 and ptr.value is None and "hipMalloc" in lib.cmbl_last_error().decode()       # CMBL_ERR_ALLOC, *out = NULL
-    # (2) inside an operation: the delta flow keeps 4n x 2 product maps per slice; n = 10^6 RK steps at 256^2 QU asks for 4 TB
-    fm = s["f"].to(C.MAP)
-    Lbig = C.LenseFlow(p, 1_000_000)(s["phi"])
+    # (2) inside an operation: a delta flow keeps 4n x 2 product maps per slice -- n = 512 RK steps (the maximum) on 64 batch slots of 512^2 QU
+    #     asks for 2048 x 2 x 128 MiB = 512 GiB of scratch, more than the 288 GB of the part
+    p2 = C.ProjLambert(512, 512, 2.0, torch.float32)
+    rng = np.random.default_rng(3)
+    F = lambda a, b: C.Field(p2, p2.tensor(a), b)
+    phi = F(1e-6 * rng.standard_normal((1, 1, 512, 512)), C.MAP)
+    fs = F(rng.standard_normal((1, 2, 512, 512)), C.MAP)
+    L7 = C.LenseFlow(p2, 7)(phi)
+    ref = (L7 * fs).arr.clone()
+    fbig = F(rng.standard_normal((64, 2, 512, 512)), C.MAP)
+    Lbig = C.LenseFlow(p2, 512)(phi)
     with pytest.raises(CmblError) as ei:
-        Lbig.gradient(C.FLOW_FWD, fm, fm.to(C.FOURIER))
-    assert ei.value.code == 6, ei.value
-    del Lbig
-    # the context, its flows and its dataset keep working, with the same results as before the failures
+        Lbig.gradient(C.FLOW_FWD, fbig, fbig.to(C.FOURIER))
+    assert ei.value.code == 6 and "hipMalloc" in str(ei.value), ei.value
+    del Lbig, fbig
+    # the contexts, their flows and the dataset keep working, with the same results as before the failures
+    assert torch.equal((L7 * fs).arr, ref)
     after = ds.gradient_logpdf_mixed(fo, po)
     assert np.array_equal(np.asarray(before[0]), np.asarray(after[0])) and torch.equal(before[1].arr, after[1].arr) and torch.equal(before[2].arr, after[2].arr)

@@ -47,6 +47,11 @@ def test_grad_logpdf_mixed_1024_fp32_vs_oracle(pol):
         close(f"∇ϕ° 1024² {pol} quirk={quirk}", gp.arr.cpu().numpy(), ogp, TOL_GP[pol])
 
 
+# 3 x measured (L*f 2.95e-5, L'g 1.77e-4 against the oracle; the pullback as against the double-precision device operator at this size,
+# tests/test_gpu_fullsize.py DFLOW32: f 4.2e-5, δf 2.5e-4, δϕ 3.8e-4)
+TOL32_2048 = dict(Lf=9e-5, adj=5.4e-4, f0=1.3e-4, df=7.5e-4, dp=1.2e-3)
+
+
 @pytest.fixture(scope="module")
 def oracle_2048():
     """the float64 oracle's L*f, L'g and pullback at 2048² QU, n = 10 -- computed once (about a minute on the GPU box's host cores) and
@@ -91,12 +96,15 @@ def test_lenseflow_and_pullback_2048_fp32_n10_vs_oracle(oracle_2048):
     p = C.ProjLambert(o["N"], o["N"], 2.0, torch.float32)
     F = lambda a, b: C.Field(p, p.tensor(a), b)
     L = C.LenseFlow(p, o["n"])(F(o["phi"], C.MAP))
-    close("L*f 2048² QU fp32 n=10 vs oracle", (L * F(o["f"], C.MAP)).arr.cpu().numpy(), o["Lf"], 2e-5)
-    close("L'g 2048² QU fp32 n=10 vs oracle", (L.adjoint * F(o["gl"], C.FOURIER)).arr.cpu().numpy(), o["adj"], 5e-5)
+    # bounds = 3 x the errors measured on MI355X at THIS size (2048-point rows and columns, 40 stages: the 64²-1024² classes of tests/_tol.py
+    # -- forward-type 2e-5, adjoint-type 5e-5, δϕ 1.8e-4 -- are 1.5-2 x tighter than what n = 10 at 2048² reaches); the per-comparison record in
+    # tests/golden/parity_measured.json then holds each to 3 x its own
+    close("L*f 2048² QU fp32 n=10 vs oracle", (L * F(o["f"], C.MAP)).arr.cpu().numpy(), o["Lf"], TOL32_2048["Lf"])
+    close("L'g 2048² QU fp32 n=10 vs oracle", (L.adjoint * F(o["gl"], C.FOURIER)).arr.cpu().numpy(), o["adj"], TOL32_2048["adj"])
     gdp, gdf, gf0 = L.gradient(C.FLOW_FWD, F(o["Lf"], C.MAP), F(o["gl"], C.FOURIER), alias_quirk=False)
-    close("pullback f 2048² fp32 vs oracle", gf0.arr.cpu().numpy(), o["f0"], 2e-5)
-    close("pullback δf 2048² fp32 vs oracle", gdf.arr.cpu().numpy(), o["df"], 5e-5)
-    close("pullback δϕ 2048² fp32 vs oracle", gdp.arr.cpu().numpy(), o["dp"], 1.8e-4)
+    close("pullback f 2048² fp32 vs oracle", gf0.arr.cpu().numpy(), o["f0"], TOL32_2048["f0"])
+    close("pullback δf 2048² fp32 vs oracle", gdf.arr.cpu().numpy(), o["df"], TOL32_2048["df"])
+    close("pullback δϕ 2048² fp32 vs oracle", gdp.arr.cpu().numpy(), o["dp"], TOL32_2048["dp"])
 
 
 def test_quadratic_estimate_EB_2048_fp64_vs_oracle():
@@ -111,7 +119,10 @@ def test_quadratic_estimate_EB_2048_fp64_vs_oracle():
     TF = {k: planes(ods.Mf)[k] * planes(ods.B)[k] for k in ("E", "B")}
     dd = {k: so["d"][:, i:i + 1] for i, k in enumerate(("E", "B"))}
     pq, AL, Nphi = O.quadratic_estimate(so["proj"], "EB", dd, dd, planes(ods.Cf), planes(ods.Cftilde), planes(ods.Cn), ods.Cphi, TF)
-    m = ods.Cphi > 0
+    # The normalisation is an integral over pairs of filtered modes: with the LowPass(3000) of load_sim it has no support beyond |l| = 6000, and
+    # between 5000 and the band limit of the map (7600) its reciprocal AL is the reciprocal of rounding noise (measured: identical to 1.4e-11 up
+    # to 5000, factors of 6 apart at 6700 -- in BOTH implementations' own noise).  The estimate itself (weighted by Cϕ/(Cϕ+Nϕ)) is compared everywhere.
+    m = (ods.Cphi > 0) & (so["proj"].lmag < 5000)
     for name, fn in (("quadratic_estimate", C.quadratic_estimate), ("cmbl_quadratic_estimate", C.quadratic_estimate_native)):
         got = fn(ds, "EB")
         scalars_close(f"{name} 2048² fp64: AL", got["AL"][m], AL[m], rtol=1e-9)
