@@ -15,6 +15,18 @@ struct cmbl_dataset {
   std::vector<std::unique_ptr<DevBuf>> qe_pool;                        // legs and products of cmbl_quadratic_estimate, reused between calls
 };
 
+// Driver scratch lives in the dataset, keyed by the flow it was built for (it holds a Flow<T>&): a flow that goes away must take its
+// entries with it -- the buffers would otherwise leak until the dataset is destroyed, and a NEW flow allocated at the same address would
+// silently inherit scratch built around the old one.  Datasets register here so that cmbl_lenseflow_destroy can find them.
+static std::mutex g_ds_mtx;
+static std::vector<cmbl_dataset*> g_datasets;
+static void registry_add(cmbl_dataset* d) { std::lock_guard<std::mutex> l(g_ds_mtx); g_datasets.push_back(d); }
+static void registry_remove(cmbl_dataset* d) { std::lock_guard<std::mutex> l(g_ds_mtx); g_datasets.erase(std::remove(g_datasets.begin(), g_datasets.end(), d), g_datasets.end()); }
+static void registry_drop_flow(const void* f32, const void* f64) {
+  std::lock_guard<std::mutex> l(g_ds_mtx);
+  for (cmbl_dataset* d : g_datasets) { if (f32) d->drv32.erase(f32); if (f64) d->drv64.erase(f64); }
+}
+
 template <typename F>
 static int guard(F&& f) {
   try { f(); return CMBL_OK; }
@@ -176,9 +188,11 @@ static void do_map_step(Drivers<T>& dr, const void* phi, const void* fstart, con
   std::vector<T> h1(pl, T(1));
   CMBL_HIP(hipMemcpyAsync(ones, h1.data(), sizeof(T) * pl, hipMemcpyHostToDevice, c->stream));
   CMBL_HIP(hipStreamSynchronize(c->stream));
-  struct Swap { const T*& slot; const T* old; ~Swap() { slot = old; } } sw{ds.ops[OP_G_INV].d[0], ds.ops[OP_G_INV].d[0]};
-  CMBL_REQUIRE(ds.ops[OP_G_INV].nplanes > 0, ERR_STATE, "a required dataset operator has not been set");
-  ds.ops[OP_G_INV].d[0] = ones;
+  // (a dataset that never set G works as well: the slot is a one-plane diagonal for the duration of the call and is put back as it was)
+  auto& g = ds.ops[OP_G_INV];
+  struct Swap { decltype(g)& o; const T* d0; int np, kind; ~Swap() { o.d[0] = d0; o.nplanes = np; o.kind = kind; } } sw{g, g.d[0], g.nplanes, g.kind};
+  if (g.nplanes == 0) { g.nplanes = 1; g.kind = 1; }
+  g.d[0] = ones;
   std::vector<double> hist((size_t)cg_maxit * B);
   dr.map_joint_step(pF, fs, hF, amax, atol, cg_tol, cg_maxit, quirk != 0, B, fF, oF, logpdf, alpha, ncg, nls, hist.data());
   c->F2ref(fF, (cx<T>*)f_out, (long)ds.P * B);
@@ -205,10 +219,11 @@ static void do_qe(Dataset<T>& ds, std::vector<std::unique_ptr<DevBuf>>& pool, in
   const cx<T>* drc[2] = {dr[0], dr[1]};
   quadratic_estimate<T>(c, pool, which, B, drc, Cf, Cft, Cn, TF, Cphi, wiener != 0, AL_in, (cx<T>*)phiqe_out, AL_out);
   // the legs and products stay allocated for the next call (a one-off estimator otherwise spends half its time in hipMalloc), unless
-  // they are large: ~100 maps, 3 GB at 2048^2 in double precision
-  size_t held = 0;
+  // they are large relative to the device: ~100 maps, 3 GB at 2048^2 in double precision
+  size_t held = 0, free_b = 0, total_b = 0;
   for (const auto& b : pool) held += b->bytes;
-  if (held > ((size_t)1 << 30)) pool.clear();
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)16 << 30; }
+  if (held > total_b / 16) pool.clear();                                 // 18 GB on a 288 GB part (round 4 dropped the pool above 1 GB: re-allocated on every call at 2048^2)
 }
 
 extern "C" {
@@ -385,7 +400,7 @@ int cmbl_lenseflow_create(cmbl_ctx* ctx, int nsteps, cmbl_flow** out) {
     *out = h.release();
   });
 }
-int cmbl_lenseflow_destroy(cmbl_flow* L) { return guard([&] { delete L; }); }
+int cmbl_lenseflow_destroy(cmbl_flow* L) { return guard([&] { if (L) registry_drop_flow(L->f32.get(), L->f64.get()); delete L; }); }
 int cmbl_lenseflow_set_phi(cmbl_flow* L, int basis, const void* phi, int nb) {
   return guard([&] {
     NOTNULL(L); NOTNULL(phi); BASIS_OK(basis); CMBL_REQUIRE(nb >= 1, ERR_SHAPE, "nbatch_phi >= 1");
@@ -465,10 +480,11 @@ int cmbl_dataset_create(cmbl_ctx* ctx, int npol, cmbl_dataset** out) {
     auto h = std::make_unique<cmbl_dataset>();
     h->ctx = ctx;
     BY_DTYPE(ctx, h->f32 = std::make_unique<Dataset<float>>(C<float>(ctx), npol), h->f64 = std::make_unique<Dataset<double>>(C<double>(ctx), npol));
+    registry_add(h.get());
     *out = h.release();
   });
 }
-int cmbl_dataset_destroy(cmbl_dataset* ds) { return guard([&] { delete ds; }); }
+int cmbl_dataset_destroy(cmbl_dataset* ds) { return guard([&] { if (ds) registry_remove(ds); delete ds; }); }
 int cmbl_dataset_set_op(cmbl_dataset* ds, int which, const void* planes, int nplanes) {
   return guard([&] { NOTNULL(ds); NOTNULL(planes); BY_DTYPE(ds->ctx, ds->f32->set_op(which, planes, nplanes), ds->f64->set_op(which, planes, nplanes)); });
 }

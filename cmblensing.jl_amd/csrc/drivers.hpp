@@ -220,13 +220,14 @@ struct QuadEst {
   cx<T>* new_fourier(int nb) { return (cx<T>*)take(sizeof(cx<T>) * nb * c->plane()); }
   T* new_map(int nb) { return (T*)take(sizeof(T) * nb * c->npix()); }
 
-  // a real (Nyh x Nx, reference layout) host plane as a complex S0 Fourier field of one batch slot
-  cx<T>* upload_plane(const std::vector<double>& p) {
-    std::vector<cx<T>> h(p.size());
-    for (size_t i = 0; i < p.size(); ++i) h[i] = mk<T>((T)p[i], T(0));
-    cx<T>* d = new_fourier(1);
-    CMBL_HIP(hipMemcpyAsync(d, h.data(), sizeof(cx<T>) * h.size(), hipMemcpyHostToDevice, c->stream));
-    CMBL_HIP(hipStreamSynchronize(c->stream));
+  // a real (Nyh x Nx, reference layout) double plane on the device: the caller's pointer itself when it is device memory, else a copy
+  const double* dev_plane(const double* p, long n) {
+    if (!p) return nullptr;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) == hipSuccess) { if (a.type == hipMemoryTypeDevice) return p; }
+    else (void)hipGetLastError();                                  // plain host memory is "invalid value" to the runtime: not an error here
+    double* d = (double*)take(sizeof(double) * n);
+    CMBL_HIP(hipMemcpyAsync(d, p, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     return d;
   }
   const T* leg(const cx<T>* C, int nb, std::initializer_list<QEInd> inds) {
@@ -259,27 +260,22 @@ void quadratic_estimate(Ctx<T>* c, std::vector<std::unique_ptr<DevBuf>>& pool, i
   const long pl = c->plane();
   const int ncomp = which == 2 ? 2 : 1;
   QuadEst<T> q{c, B, pool};
-  auto finite0 = [](double v) { return std::isfinite(v) ? v : 0.0; };
-  // inverse-variance filtered data legs  extra * (Sigma_tot \ (TF d))  and the weight planes of orders 0, 1, 2 in Cf  (:52-62, 100-110)
-  std::vector<std::vector<double>> w0(ncomp), w1(ncomp), w2(ncomp), fil(ncomp), filC(ncomp);
+  const unsigned gpl = (unsigned)std::min<long>((pl + NTP - 1) / NTP, 4096);
+  // inverse-variance filter and the weight planes of orders 0, 1, 2 in Cf (:52-62, 100-110): one pointwise launch per component on the
+  // device (round 4 formed them on the host: 15 planes of 2 M doubles, each uploaded behind a blocking synchronisation -- 227 ms at 2048^2
+  // fp64, three times the Python driver)
+  const double* dCf = q.dev_plane(Cf, ncomp * pl); const double* dCft = q.dev_plane(Cft, ncomp * pl);
+  const double* dCn = q.dev_plane(Cn, ncomp * pl); const double* dTF = q.dev_plane(TF, ncomp * pl);
+  const cx<T>*W0[2] = {nullptr, nullptr}, *W1[2] = {nullptr, nullptr}, *W2[2] = {nullptr, nullptr}, *fil[2] = {nullptr, nullptr}, *filC[2] = {nullptr, nullptr};
   for (int k = 0; k < ncomp; ++k) {
-    w0[k].resize(pl); w1[k].resize(pl); w2[k].resize(pl); fil[k].resize(pl); filC[k].resize(pl);
-    for (long i = 0; i < pl; ++i) {
-      const double tf = TF[k * pl + i], S = tf * tf * Cft[k * pl + i] + Cn[k * pl + i], iS = finite0(1.0 / S), C = Cf[k * pl + i];
-      w0[k][i] = tf * tf * iS; w1[k][i] = tf * tf * C * iS; w2[k][i] = tf * tf * C * C * iS;
-      fil[k][i] = finite0(tf / S); filC[k][i] = finite0(tf / S * C);
-    }
+    cx<T>*w0 = q.new_fourier(1), *w1 = q.new_fourier(1), *w2 = q.new_fourier(1), *f = q.new_fourier(1), *fc = q.new_fourier(1);
+    CMBL_LAUNCH(c, K_HARM, (k_qe_weights<T>), dim3(gpl), 0, c->stream, dCf + k * pl, dCft + k * pl, dCn + k * pl, dTF + k * pl, w0, w1, w2, f, fc, pl);
+    W0[k] = w0; W1[k] = w1; W2[k] = w2; fil[k] = f; filC[k] = fc;
   }
-  // filt: plane .* data component, in the reference layout (both operands are in it): through a tiny pointwise pass on (re, im) pairs
-  auto filt = [&](int k, const std::vector<double>& w) {
-    cx<T>* wd = q.upload_plane(w);
+  // filt: plane .* data component, in the reference layout (both operands are in it): the elementwise product of the interleaved reals
+  auto filt = [&](int k, const cx<T>* w) {
     cx<T>* out = q.new_fourier(B);
-    // real-plane x complex field, reference layout: the complex "map_fma" on interleaved (re, im) = multiply by (w, w)
-    std::vector<cx<T>> h(pl);
-    for (long i = 0; i < pl; ++i) h[i] = mk<T>((T)w[i], (T)w[i]);
-    CMBL_HIP(hipMemcpyAsync(wd, h.data(), sizeof(cx<T>) * pl, hipMemcpyHostToDevice, c->stream));
-    CMBL_HIP(hipStreamSynchronize(c->stream));
-    for (int b = 0; b < B; ++b) c->map_fma((T*)(out + (long)b * pl), (const T*)wd, (const T*)(dref[k] + (long)b * pl), 1.0, false, 2 * pl);
+    for (int b = 0; b < B; ++b) c->map_fma((T*)(out + (long)b * pl), (const T*)w, (const T*)(dref[k] + (long)b * pl), 1.0, false, 2 * pl);
     return (const cx<T>*)out;
   };
   cx<T>* un = q.new_fourier(B);
@@ -290,8 +286,6 @@ void quadratic_estimate(Ctx<T>* c, std::vector<std::unique_ptr<DevBuf>>& pool, i
     c->lincomb((T*)acc, (const T*)(first ? t : acc), (const T*)t, a.data(), b.data(), 2 * pl, nb);
   };
   std::function<T*(int, int)> A;
-  const cx<T>*W0[2] = {nullptr, nullptr}, *W1[2] = {nullptr, nullptr}, *W2[2] = {nullptr, nullptr};
-  for (int k = 0; k < ncomp; ++k) { W0[k] = q.upload_plane(w0[k]); W1[k] = q.upload_plane(w1[k]); W2[k] = q.upload_plane(w2[k]); }
   const int idx[2] = {1, 2};
   if (which == 0) {                                                                       // TT (:95-112)
     const cx<T>* a = filt(0, fil[0]); const cx<T>* b = filt(0, filC[0]);
@@ -346,30 +340,25 @@ void quadratic_estimate(Ctx<T>* c, std::vector<std::unique_ptr<DevBuf>>& pool, i
       return acc;
     };
   }
-  std::vector<double> AL(pl);
-  if (AL_in) std::copy(AL_in, AL_in + pl, AL.begin());
-  else {                                                                                  // normalisation (:177-187)
-    cx<T>* tot = q.new_fourier(1);
+  // normalisation (:177-187), the Wiener weight (:44-46) and the estimate, on the device; AL comes back once, if asked for
+  const cx<T>* tot = nullptr;
+  const double* dAL_in = q.dev_plane(AL_in, pl);
+  if (!AL_in) {
+    cx<T>* t = q.new_fourier(1);
     bool first = true;
     for (int i : idx) for (int j : idx) {
-      add_to(tot, 1.0, lmul(A(i, j), (i == 1) + (j == 1), (i == 2) + (j == 2), true, 1), 1.0, first, 1);
+      add_to(t, 1.0, lmul(A(i, j), (i == 1) + (j == 1), (i == 2) + (j == 2), true, 1), 1.0, first, 1);
       first = false;
     }
-    std::vector<cx<T>> h(pl);
-    CMBL_HIP(hipMemcpyAsync(h.data(), tot, sizeof(cx<T>) * pl, hipMemcpyDeviceToHost, c->stream));
-    CMBL_HIP(hipStreamSynchronize(c->stream));
-    for (long i = 0; i < pl; ++i) AL[i] = finite0(1.0 / (double)h[i].x);
+    tot = t;
   }
-  std::vector<double> wf(AL);
-  if (wiener) for (long i = 0; i < pl; ++i) wf[i] = finite0(Cphi[i] / (Cphi[i] + AL[i])) * AL[i];        // :44-46
-  std::vector<cx<T>> h(pl);
-  for (long i = 0; i < pl; ++i) h[i] = mk<T>((T)wf[i], (T)wf[i]);
+  const double* dCphi = q.dev_plane(Cphi, pl);
+  double* dAL = (double*)q.take(sizeof(double) * pl);
   cx<T>* wd = q.new_fourier(1);
-  CMBL_HIP(hipMemcpyAsync(wd, h.data(), sizeof(cx<T>) * pl, hipMemcpyHostToDevice, c->stream));
-  CMBL_HIP(hipStreamSynchronize(c->stream));
+  CMBL_LAUNCH(c, K_HARM, (k_qe_norm<T>), dim3(gpl), 0, c->stream, tot, dAL_in, dCphi, wiener ? 1 : 0, dAL, wd, pl);
   for (int b = 0; b < B; ++b) c->map_fma((T*)(phiqe_ref + (long)b * pl), (const T*)wd, (const T*)(un + (long)b * pl), 1.0, false, 2 * pl);
+  if (AL_out) CMBL_HIP(hipMemcpyAsync(AL_out, dAL, sizeof(double) * pl, hipMemcpyDefault, c->stream));     // host or device destination
   CMBL_HIP(hipStreamSynchronize(c->stream));
-  if (AL_out) std::copy(AL.begin(), AL.end(), AL_out);
 }
 
 }  // namespace cmbl

@@ -326,6 +326,33 @@ __global__ __launch_bounds__(NTP) void k_qe_leg(const cx<T>* __restrict__ in, cx
   }
 }
 
+// quadratic_estimate weight planes (src/quadratic_estimate.jl:52-62,100-110), all of one component in one pass, evaluated in double like
+// the reference's host algebra and rounded once:  S = TF^2 Cf~ + Cn;  W0 = TF^2 / S, W1 = W0 Cf, W2 = W0 Cf^2 as S0 Fourier planes (w, 0);
+// fil = TF / S and filC = fil Cf as (w, w) pairs (a real plane times a complex field = an elementwise product of the interleaved reals).
+__device__ __forceinline__ double finite0(double v) { return isfinite(v) ? v : 0.0; }
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_qe_weights(const double* __restrict__ Cf, const double* __restrict__ Cft, const double* __restrict__ Cn,
+                                                    const double* __restrict__ TF, cx<T>* __restrict__ W0, cx<T>* __restrict__ W1, cx<T>* __restrict__ W2,
+                                                    cx<T>* __restrict__ fil, cx<T>* __restrict__ filC, long plane) {
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < plane; i += (long)gridDim.x * NTP) {
+    const double tf = TF[i], S = tf * tf * Cft[i] + Cn[i], iS = finite0(1.0 / S), C = Cf[i];
+    W0[i] = mk<T>((T)(tf * tf * iS), T(0)); W1[i] = mk<T>((T)(tf * tf * C * iS), T(0)); W2[i] = mk<T>((T)(tf * tf * C * C * iS), T(0));
+    const T f = (T)finite0(tf / S), fc = (T)finite0(tf / S * C);
+    fil[i] = mk<T>(f, f); filC[i] = mk<T>(fc, fc);
+  }
+}
+// normalisation and the Wiener weight (src/quadratic_estimate.jl:44-46,177-187):  AL = pinv(tot) (or the caller's plane);
+// wf = (wiener ? Cphi / (Cphi + AL) : 1) AL as a (w, w) pair
+template <typename T>
+__global__ __launch_bounds__(NTP) void k_qe_norm(const cx<T>* __restrict__ tot, const double* __restrict__ AL_in, const double* __restrict__ Cphi, int wiener,
+                                                 double* __restrict__ AL, cx<T>* __restrict__ wf, long plane) {
+  for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < plane; i += (long)gridDim.x * NTP) {
+    const double al = AL_in ? AL_in[i] : finite0(1.0 / (double)tot[i].x);
+    AL[i] = al;
+    const T w = (T)(wiener ? finite0(Cphi[i] / (Cphi[i] + al)) * al : al);
+    wf[i] = mk<T>(w, w);
+  }
+}
 // out = (accumulate ? out : 0) + scale * a * b   (maps)
 template <typename T>
 __global__ __launch_bounds__(NTP) void k_map_fma(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b, T scale, int accumulate, long n) {

@@ -203,26 +203,36 @@ def quadratic_estimate(ds, which=None, wiener_filtered=True, AL=None):
 
 
 def quadratic_estimate_native(ds, which=None, wiener_filtered=True, AL=None):
-    """`quadratic_estimate` as ONE library call (`cmbl_quadratic_estimate`): the same legs and sums inside the library.  Returns the same dict."""
+    """`quadratic_estimate` as ONE library call (`cmbl_quadratic_estimate`): the same legs and sums inside the library.  Returns the same dict.
+    The double-precision planes the call takes (Cf, Cf~, Cn, TF = Mf .* B, Cϕ) are kept on the device between calls -- they change only when
+    the dataset's operators do (`theta.set_theta` replaces the host arrays, which drops the cached copies) -- so a call moves no plane over PCIe
+    but the normalisation it returns."""
     import ctypes
     from .lib import check
     proj, h = ds.proj, ds.host
     which = which or ("TT" if ds.P == 1 else "EB")
     off = {1: {"T": 0}, 2: {"E": 0, "B": 1}, 3: {"T": 0, "E": 3, "B": 4}}[ds.P]
     comps = {"TT": ["T"], "EE": ["E"], "EB": ["E", "B"]}[which]
-    plane = lambda op, k: np.ascontiguousarray(np.asarray(op.p[off[k]], np.float64))
-    pack = lambda f: np.ascontiguousarray(np.stack([f(k) for k in comps]))
-    Cf, Cft, Cn = pack(lambda k: plane(h["Cf"], k)), pack(lambda k: plane(h["Cftilde"], k)), pack(lambda k: plane(h["Cn"], k))
-    TF = pack(lambda k: plane(h["Mf"], k) * plane(h["B"], k))
-    Cphi = np.ascontiguousarray(np.asarray(h["Cphi"], np.float64))
+    key = (which,) + tuple(id(h[k]) for k in ("Cf", "Cftilde", "Cn", "Mf", "B", "Cphi"))
+    cache = ds.__dict__.setdefault("_qe_planes", {})
+    if key not in cache:
+        cache.clear()
+        plane = lambda op, k: np.ascontiguousarray(np.asarray(op.p[off[k]], np.float64))
+        pack = lambda f: torch.as_tensor(np.ascontiguousarray(np.stack([f(k) for k in comps])), device=proj.device)
+        cache[key] = dict(Cf=pack(lambda k: plane(h["Cf"], k)), Cft=pack(lambda k: plane(h["Cftilde"], k)), Cn=pack(lambda k: plane(h["Cn"], k)),
+                          TF=pack(lambda k: plane(h["Mf"], k) * plane(h["B"], k)),
+                          Cphi=torch.as_tensor(np.ascontiguousarray(np.asarray(h["Cphi"], np.float64)), device=proj.device),
+                          keep=[h[k] for k in ("Cf", "Cftilde", "Cn", "Mf", "B", "Cphi")])       # the ids stay unique while these live
+    pl = cache[key]
     B = ds.d.arr.shape[0]
     out = proj.empty(FOURIER, 1, B)
-    ALo = np.zeros_like(Cphi)
-    pd = lambda a: None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    ALi = None if AL is None else np.ascontiguousarray(np.asarray(AL, np.float64))
-    check(ds.lib.cmbl_quadratic_estimate(ds._h, {"TT": 0, "EE": 1, "EB": 2}[which], pd(Cf), pd(Cft), pd(Cn), pd(TF), pd(Cphi), 1 if wiener_filtered else 0,
-                                         pd(ALi), ctypes.c_void_p(out.data_ptr()), pd(ALo), B))
-    return dict(phiqe=Field(proj, out, FOURIER), AL=ALo, Nphi=ALo.copy())
+    ALo = torch.empty_like(pl["Cphi"])
+    dp = lambda t: None if t is None else ctypes.cast(ctypes.c_void_p(t.data_ptr()), ctypes.POINTER(ctypes.c_double))
+    ALi = None if AL is None else torch.as_tensor(np.ascontiguousarray(np.asarray(AL, np.float64)), device=proj.device)
+    check(ds.lib.cmbl_quadratic_estimate(ds._h, {"TT": 0, "EE": 1, "EB": 2}[which], dp(pl["Cf"]), dp(pl["Cft"]), dp(pl["Cn"]), dp(pl["TF"]), dp(pl["Cphi"]),
+                                         1 if wiener_filtered else 0, dp(ALi), ctypes.c_void_p(out.data_ptr()), dp(ALo), B))
+    ALh = ALo.cpu().numpy()
+    return dict(phiqe=Field(proj, out, FOURIER), AL=ALh, Nphi=ALh.copy())
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -92,10 +92,17 @@ class JLD2File:
     def __init__(self, path, verify=True):
         """verify: check the lookup3 checksums of the superblock and of every object header / continuation block that is read"""
         self.verify = verify
+        # memory-mapped: only the pages that are decoded are read.  The chain-file writer opens the file it appends to through this class
+        # on every chunk (root links, committed datatypes): with `fh.read()` that was O(file size) of I/O and RAM per flush, quadratic over
+        # a long run (a 1024² sample is 25 MB)
+        import mmap
         with open(path, "rb") as fh:
-            self.buf = fh.read()
+            try:
+                self.buf = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            except (ValueError, OSError):                                     # empty file, or a file system without mmap
+                self.buf = fh.read()
         b = self.buf
-        if not b.startswith(b"HDF5-based Julia Data Format"):
+        if b[:28] != b"HDF5-based Julia Data Format":
             raise JLD2Error(f"{path}: not a JLD2 file")
         self.base = 512
         if b[512:520] != b"\x89HDF\r\n\x1a\n":

@@ -252,7 +252,10 @@ int cmbl_map_joint_step(cmbl_dataset* ds, cmbl_flow* L, const void* phi, const v
  *   estimator uses (TT: T; EE: E; EB: E then B): Cf (unlensed), Cftilde (lensed), Cn, and TF = Mf .* B, the Fourier-diagonal
  *   approximations of mask x beam and noise the reference uses (`ds.M̂`, `ds.B̂`, `ds.Cn̂`), plus Cphi.  AL_in_host != NULL skips the
  *   normalisation sums and uses that plane (:38).  Outputs: phiqe_out FOURIER (Ny/2+1, Nx, 1, nbatch) = (wiener_filtered ?
- *   Cphi/(Cphi+AL) : 1) .* AL .* unnormalised estimate; AL_out_host (may be NULL) the normalisation = N0 bias plane. */
+ *   Cphi/(Cphi+AL) : 1) .* AL .* unnormalised estimate; AL_out_host (may be NULL) the normalisation = N0 bias plane.
+ *   Every plane argument (inputs and AL_out_host) may be a HOST or a DEVICE pointer (detected with hipPointerGetAttributes): a caller that
+ *   keeps the planes of a dataset on the device -- they change only with theta -- pays no transfer per call.  All plane algebra runs on
+ *   the device in double precision, rounded once to the working precision, exactly as the host algebra of the reference does. */
 int cmbl_quadratic_estimate(cmbl_dataset* ds, int which, const double* Cf_host, const double* Cftilde_host, const double* Cn_host,
                             const double* TF_host, const double* Cphi_host, int wiener_filtered, const double* AL_in_host,
                             void* phiqe_out, double* AL_out_host, int nbatch);

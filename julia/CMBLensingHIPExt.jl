@@ -33,8 +33,12 @@ import Base: *, \, adjoint
 
 const lib = get(ENV, "CMBL_LIB", joinpath(@__DIR__, "..", "cmblensing.jl_amd", "libcmblens_hip.so"))
 
-# CMBL_REFERENCE_EXACT=1 (read by the library too): δϕ velocity exactly as written upstream and plain working-precision sums
-reference_exact() = !(get(ENV, "CMBL_REFERENCE_EXACT", "0") in ("", "0"))
+# DEFAULT ARITHMETIC OF THIS GLUE = THE REFERENCE'S, AS WRITTEN: the δϕ velocity with the in-place aliasing of src/lenseflow.jl:198-200 and
+# plain sums in the working precision (`sum_accuracy_mode = nothing`, src/util.jl:288-316) -- a user who swaps `LenseFlow` for
+# `HIPLenseFlow` gets the reference's numbers, not the library's "consistent" variant (DESIGN.md §3 Q1: that one matches finite differences
+# to 2e-8 and differs from the reference by ~3e-4 in the ϕ gradient).  The consistent form stays a keyword (`alias_quirk=false`), Float64 /
+# Kahan accumulation a call (`set_sum_accuracy_mode!`); CMBL_CONSISTENT=1 makes both the default of a session.
+reference_exact() = get(ENV, "CMBL_CONSISTENT", "0") in ("", "0")
 
 # ---- status codes -> exceptions (include/cmblens.h: nothing throws across the ABI) ---------------------------------------
 chk(rc::Integer) = rc == 0 ? nothing : error("libcmblens_hip error $rc: ", unsafe_string(ccall((:cmbl_last_error, lib), Cstring, ())))
@@ -89,6 +93,8 @@ mutable struct HIPContext
         chk(ccall((:cmbl_ctx_create, lib), Cint, (Cint, Cint, Cdouble, Cint, Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
                   proj.Ny, proj.Nx, proj.θpix, dtype(real(T)), AMDGPU.device_id(AMDGPU.device()) - 1,
                   Ptr{Cvoid}(UInt(Base.unsafe_convert(Ptr{Cvoid}, AMDGPU.stream().stream))), h))
+        # the library's own default accumulates in Float64; the reference's is the working precision (src/util.jl:288-316)
+        reference_exact() && chk(ccall((:cmbl_set_sum_accuracy_mode, lib), Cint, (Ptr{Cvoid}, Cint), h[], 0))
         finalizer(c -> ccall((:cmbl_ctx_destroy, lib), Cint, (Ptr{Cvoid},), c.h), new(h[], Any[]))
     end
 end

@@ -25,7 +25,9 @@ rel(a, b) = norm(Array(a.arr) .- Array(b.arr)) / norm(Array(b.arr))
             Lcpu = LenseFlow(ϕ, 7)
             # the same fields in device storage (ext/CMBLensingCUDAExt.jl:42-43's twin `gpu`)
             fg, ϕg = gpu(f), gpu(ϕ)
-            L = HIPLenseFlow(ϕg, 7; alias_quirk=true)                  # reference-exact arithmetic (src/lenseflow.jl:198-200)
+            L = HIPLenseFlow(ϕg, 7)                                     # the DEFAULT is the reference's arithmetic (src/lenseflow.jl:198-200)
+            @test L.alias_quirk === true && CMBLensingHIPExt.reference_exact()
+            @test HIPLenseFlow(ϕg, 7; alias_quirk=false).alias_quirk === false    # the consistent form stays a keyword
 
             # operator surface (src/flowops.jl:11-14)
             @test rel(L * Map(fg), Lcpu * Map(f)) < flowtol
@@ -38,7 +40,7 @@ rel(a, b) = norm(Array(a.arr) .- Array(b.arr)) / norm(Array(b.arr))
 
             # Zygote pullbacks (src/flowops.jl:40-68) against the reference's own
             ∇cpu = gradient((f, ϕ) -> norm(LenseFlow(ϕ, 7) * f), Map(f), ϕ)
-            ∇hip = gradient((f, ϕ) -> norm(HIPLenseFlow(ϕ, 7; alias_quirk=true) * f), Map(fg), ϕg)
+            ∇hip = gradient((f, ϕ) -> norm(HIPLenseFlow(ϕ, 7) * f), Map(fg), ϕg)          # default arguments: must reproduce the reference's gradient
             @test rel(∇hip[1], ∇cpu[1]) < flowtol
             @test rel(∇hip[2], ∇cpu[2]) < gradtol
 

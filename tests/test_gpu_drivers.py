@@ -39,6 +39,16 @@ def test_quadratic_estimate(prec, pol, which):
     nat = C.quadratic_estimate_native(ds, which)                        # cmbl_quadratic_estimate, directly against the oracle
     scalars_close("cmbl_quadratic_estimate vs oracle: AL", nat["AL"][m], AL[m], rtol=2e-3 if prec == "f32" else 1e-9)
     close("cmbl_quadratic_estimate vs oracle: phiqe", nat["phiqe"].arr.cpu().numpy(), pq, (2e-3 if prec == "f32" else 1e-9))
+    # the plane arguments of cmbl_quadratic_estimate may be host or device pointers (include/cmblens.h): the wrapper above passes the
+    # dataset's device-resident copies, here the same planes go in as plain host arrays -- identical results
+    import ctypes
+    pl = next(iter(ds._qe_planes.values()))
+    hostp = {k: np.ascontiguousarray(pl[k].cpu().numpy()) for k in ("Cf", "Cft", "Cn", "TF", "Cphi")}
+    pd = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    out_h, AL_h = p.empty(C.FOURIER, 1, 1), np.zeros_like(hostp["Cphi"])
+    rc = ds.lib.cmbl_quadratic_estimate(ds._h, {"TT": 0, "EE": 1, "EB": 2}[which], pd(hostp["Cf"]), pd(hostp["Cft"]), pd(hostp["Cn"]), pd(hostp["TF"]),
+                                        pd(hostp["Cphi"]), 1, None, ctypes.c_void_p(out_h.data_ptr()), pd(AL_h), 1)
+    assert rc == 0 and np.array_equal(AL_h, nat["AL"]) and torch.equal(out_h, nat["phiqe"].arr)
     # it is an estimate of ϕ: correlates with the truth
     phi = so["phi"]
     r = O.dot_fourier(so["proj"], pq, phi) / np.sqrt(O.dot_fourier(so["proj"], pq, pq) * O.dot_fourier(so["proj"], phi, phi))
@@ -491,8 +501,12 @@ def test_native_driver_exports_equal_the_python_drivers(prec, pol):
     assert acc_n2.tolist() == acc_p2.tolist()
     # MAP_joint step
     p0 = C.Field(proj, torch.zeros_like(po.arr), C.FOURIER)
+    # a G that is NOT the identity the step runs with (load_sim's default mixing matrix is 1): the restore below then proves something
+    ds.set_op("G_inv", (0.5 + np.random.default_rng(9).random(np.asarray(ds.host["Cphi"]).shape))[None])
     st_p = C.MAP_joint_step(ds, p0, alpha_tol=1e-4, cg_tol=0.0, cg_nsteps=8)
     Ginv_before = ds.ops["G_inv"].clone()
+    assert float((Ginv_before - 1).abs().max()) > 1e-3
+    lp_G_before = np.asarray(ds.logpdf_mixed(fo, po)).copy()                # evaluated through the LIBRARY's G slot (a mixed-variable logpdf)
     st_n = C.MAP_joint_step_native(ds, p0, alpha_tol=1e-4, cg_tol=0.0, cg_nsteps=8)
     assert st_n["ncg"] == len(st_p["cg_hist"]) == 8
     close("native MAP_joint step: f", st_n["f"].arr.cpu().numpy(), st_p["f"].arr.cpu().numpy(), tight)
@@ -500,7 +514,8 @@ def test_native_driver_exports_equal_the_python_drivers(prec, pol):
     close("native MAP_joint step: phi", st_n["phi"].arr.cpu().numpy(), st_p["phi"].arr.cpu().numpy(), 5e-3 if prec == "f32" else 1e-6)
     scalars_close("native MAP_joint step: logpdf", st_n["logpdf"], st_p["logpdf"], rtol=2e-6 if prec == "f32" else 1e-10)
     assert st_n["linesearch_evals"] == st_p["linesearch_evals"] or prec == "f32"
-    assert torch.equal(ds.ops["G_inv"], Ginv_before)                        # the dataset's G is back in place
+    assert torch.equal(ds.ops["G_inv"], Ginv_before)                        # the host-side copy was never touched ...
+    assert np.array_equal(np.asarray(ds.logpdf_mixed(fo, po)), lp_G_before)    # ... and the library's own G slot is back: same logpdf, bit for bit
     lp_chk = ds.logpdf_mixed(*ds.mix(st_n["f"], st_n["phi"]))               # and the library still evaluates with it
     assert np.all(np.isfinite(lp_chk))
 

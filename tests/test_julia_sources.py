@@ -87,3 +87,16 @@ def test_ccalls_match_the_header():
     must = {"cmbl_ctx_create", "cmbl_lenseflow_apply", "cmbl_lenseflow_grad", "cmbl_wiener_cg", "cmbl_gradientf_logpdf", "cmbl_logpdf_mixed",
             "cmbl_grad_logpdf_mixed", "cmbl_dataset_set_op", "cmbl_dot", "cmbl_randn"}
     assert must <= seen, must - seen
+
+
+def test_the_glue_defaults_to_the_reference_arithmetic():
+    """A Julia user who loads the glue unmodified must get the reference's results: `HIPLenseFlow` defaults to the aliased
+    δϕ velocity of src/lenseflow.jl:198-200, a context starts with working-precision sums (src/util.jl:288-316), the consistent form is a
+    keyword, and julia/test_hipext.jl compares DEFAULT-constructed operators with the reference and asserts the default."""
+    ext = strip(open(FILES[0], encoding="utf-8").read())
+    assert re.search(r"reference_exact\(\)\s*=\s*get\(ENV,\s*\"\",\s*\"\"\)\s*in\s*\(\"\",\s*\"\"\)", ext)             # default true; CMBL_CONSISTENT=1 flips it
+    assert len(re.findall(r"HIPLenseFlow\([^)]*;\s*alias_quirk=reference_exact\(\)\)", ext)) == 2                  # both constructors
+    assert re.search(r"reference_exact\(\)\s*&&\s*chk\(ccall\(\(:cmbl_set_sum_accuracy_mode,\s*lib\)[^\n]*h\[\],\s*0\)\)", ext)
+    tst = strip(open(FILES[2], encoding="utf-8").read())
+    assert "L = HIPLenseFlow(ϕg, 7)" in tst and "L.alias_quirk === true" in tst
+    assert "alias_quirk=true" not in tst                                                    # no test forces the mode: the default is what is compared
