@@ -446,7 +446,7 @@ struct Ctx : CtxBase {
   // keeps them apart; the few workgroups beyond the CU count are the short ones (row_group) and run in a second, short round.
   const size_t lds_one_per_cu = env_int("CMBL_ONE_PER_CU", 1) ? (size_t)82 * 1024 : 0;
   size_t lds_apart(size_t lds, long nblk) const { return (lds_one_per_cu && nblk <= num_cus + num_cus / 8) ? std::max(lds, lds_one_per_cu) : lds; }
-  size_t ldsX(int rpw, int nbuf) const { return ((size_t)row_tw(Nx) + (size_t)nbuf * rpw * row_ld(Nx)) * sizeof(cx<T>); }
+  size_t ldsX(int rpw, int nbuf) const { return ((size_t)row_tw<T>(Nx) + (size_t)nbuf * rpw * row_ld(Nx)) * sizeof(cx<T>); }
   long row_groups(long slices, int rpw) const { return slices * ((Nyh + rpw - 1) / rpw); }
   // rows per row workgroup of a launch over `slices` slices: the LDS-fit maximum unless the launch would then leave CUs idle
   int pick_rpw(int rpw_max, int lgnx, long slices) const {

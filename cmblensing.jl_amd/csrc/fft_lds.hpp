@@ -58,6 +58,7 @@ constexpr int levels_after(int lgN, int idx, int maxlg = 4) { int tot = 0; for (
 // WorkCoop: the NT threads of the workgroup share S sequences (column tiles); stages are separated by workgroup barriers.
 template <int NT> struct WorkCoop {
   int S;
+  static constexpr bool twq = false;
   template <int LGNB, typename F> __device__ __forceinline__ void each(F&& f) const {
     for (int q = threadIdx.x; q < (S << LGNB); q += NT) f(q >> LGNB, q & ((1 << LGNB) - 1));
   }
@@ -69,8 +70,11 @@ template <int NT> struct WorkCoop {
 // [w*I/2, (w+1)*I/2) of the I items of a stage are exactly those that touch half w), with RT = 64 one wave has the whole row: either
 // way a wave only ever reads LDS slots it wrote itself, LDS operations of a wave execute in order, and no barrier is needed
 // between stages.  Other RT fall back to workgroup barriers.
-template <int RT, int RPW> struct WorkRows {
+// TWQ: the twiddle table in LDS holds a QUARTER of the circle (row kernels of 2048-point double-precision rows: row_tw_quarter), the second
+// quarter is -i times the first (stage_twiddles)
+template <int RT, int RPW, bool TWQ = false> struct WorkRows {
   int NA, nr;
+  static constexpr bool twq = TWQ;
   static constexpr bool wave_private = RT <= 128;
   template <int LGNB, typename F> __device__ __forceinline__ void each(F&& f) const {
     const int row = threadIdx.x / RT, t = threadIdx.x % RT;
@@ -101,8 +105,9 @@ template <int RT, int RPW> struct WorkRows {
 
 // WorkSeqs: like WorkRows with every row set on its own threads -- RT consecutive threads own sequence `threadIdx.x / RT` of NA * RPW
 // sequences (sequence a*RPW + row; rows >= nr absent).  Used by the row carriers that hold all pol slices of a batch slot.
-template <int RT, int RPW> struct WorkSeqs {
+template <int RT, int RPW, bool TWQ = false> struct WorkSeqs {
   int nr;
+  static constexpr bool twq = TWQ;
   static constexpr bool wave_private = RT <= 128;
   template <int LGNB, typename F> __device__ __forceinline__ void each(F&& f) const {
     static_assert(RT == 128, "WorkSeqs: two wavefronts per sequence");
@@ -128,9 +133,22 @@ template <int RT, int RPW> struct WorkSeqs {
 #ifndef CMBL_TW_REC
 #define CMBL_TW_REC 2
 #endif
-template <typename T, int r, typename V>
+// table entry i < 2^(QLG+1) of a table that keeps the first 2^QLG entries (a quarter of the circle): W^(i + N/4) = -i W^i.  QLG = 0: plain read
+template <typename T, int QLG> __device__ __forceinline__ typename vreg<T>::type tw_read(const cx<T>* __restrict__ tw, int i) {
+  if constexpr (QLG == 0) return vload(tw + i);
+  else {
+    const typename vreg<T>::type w = vload(tw + (i & ((1 << QLG) - 1)));
+    return (i >> QLG) ? vmul_mi(w) : w;
+  }
+}
+template <typename T, int r, int QLG = 0, typename V>
 __device__ __forceinline__ void stage_twiddles(const cx<T>* __restrict__ tw, int j, int sh, V (&w)[r]) {
-  if constexpr ((CMBL_TW_REC == 2 || (CMBL_TW_REC == 1 && sizeof(T) == 4)) && r >= 4) {
+  if constexpr (QLG != 0) {
+    static_assert(CMBL_TW_REC == 2, "quarter-circle tables need the one-read stage twiddles");
+    w[1] = tw_read<T, QLG>(tw, j << sh);
+#pragma unroll
+    for (int k = 2; k < r; ++k) w[k] = vmul(w[k >> 1], w[k - (k >> 1)]);
+  } else if constexpr ((CMBL_TW_REC == 2 || (CMBL_TW_REC == 1 && sizeof(T) == 4)) && r >= 4) {
     w[1] = vload(tw + (j << sh));
 #pragma unroll
     for (int k = 2; k < r; ++k) w[k] = vmul(w[k >> 1], w[k - (k >> 1)]);
@@ -155,7 +173,7 @@ __device__ __forceinline__ void dif_stage(cx<T>* __restrict__ s, const W& wk, co
 #pragma unroll
     for (int m = 0; m < r; ++m) v[m] = vload(p + pad(m << lghmin));     // pad(base + m*hmin) == pad(base) + pad(m*hmin) here
     V w[r];
-    if constexpr (hmin > 1) stage_twiddles<T, r>(tw, j, sh, w);
+    if constexpr (hmin > 1) stage_twiddles<T, r, (W::twq ? LGNTW - 2 : 0)>(tw, j, sh, w);
     dft<T, LG, false>(v);
 #pragma unroll
     for (int k = 0; k < r; ++k) {
@@ -180,7 +198,7 @@ __device__ __forceinline__ void dit_stage(cx<T>* __restrict__ s, const W& wk, co
     const int b0 = (blk << (LGH + LG)) + j;                          // logical (unpadded) index of element m = 0
     cx<T>* p = s + seq * LD + pad(b0);
     V v[r], w[r];
-    if constexpr (hmin > 1) stage_twiddles<T, r>(tw, j, sh, w);
+    if constexpr (hmin > 1) stage_twiddles<T, r, (W::twq ? LGNTW - 2 : 0)>(tw, j, sh, w);
 #pragma unroll
     for (int k = 0; k < r; ++k) {                                    // frequency k of the group sits at position brev(k)
       const int m = brevc<LG>(k);

@@ -27,6 +27,8 @@
 
 namespace cmbl {
 
+__host__ __device__ constexpr int ilog2c(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+
 // debug builds (-DCMBL_STAMPS): per-workgroup phase timestamps, read back with cmbl_debug_stamps (tools/gpu_stamps.py)
 #ifdef CMBL_STAMPS
 __device__ unsigned long long g_stamps[8192 * 16];
@@ -173,7 +175,6 @@ __global__ __launch_bounds__(NTP) void k_F2ref(const V* __restrict__ in, V* __re
 
 // ---------------------------------------------------------------------------------------------
 // Column-tile geometry, all compile time: C columns per workgroup of NT threads, M = Ny/2, R = C*M/NT packed pairs/thread.
-constexpr int ilog2c(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 template <int R, int NT, int LGM> struct ColTile {
   static constexpr int M = 1 << LGM, N = 2 * M, LGN = LGM + 1, Nyh = M + 1;
   static constexpr int C = (R * NT) >> LGM, LGC = ilog2c(C);
@@ -451,12 +452,24 @@ __host__ __device__ constexpr int row_ld(int n) { return pad(n) + ((4 - pad(n) %
 // (stage_twiddles: index j * 2^sh < Nx / 2) and the fused top level (index < Nx / 2) nothing beyond it is read; the 4 KB saved at
 // Nx = 1024 are 4 KB less to load per workgroup.
 static_assert(CMBL_TW_REC == 2, "row kernels load half of the twiddle circle: needs the one-read stage twiddles in both precisions");
-__host__ __device__ constexpr int row_tw(int nx) { return nx >> 1; }
+// 2048-point rows in double precision keep a QUARTER (8 KB instead of 16; the second quarter is -i times the first: tw_read, fft_lds.hpp).
+// It was built so that two row groups of two rows (2 x 78 KB) could share a CU where one group of four rows (156 KB) is alone -- two
+// out-of-phase workgroups per CU.  Measured (profiles/r05_ab_fp64_rows_2wg_rejected.txt): the d/dx pass does not change, the adjoint row
+// pass on one-row groups is 7-9 % SLOWER, so the group heights stay (CMBL_F64_ROWS_2WG = 0); the smaller table stays as well (8 KB less to
+// load per workgroup, results identical).
+template <typename T> __host__ __device__ constexpr bool row_tw_quarter(int lgnx) { return sizeof(T) == 8 && lgnx == 11; }
+template <typename T> __host__ __device__ constexpr int row_tw(int nx) { return row_tw_quarter<T>(ilog2c(nx)) ? nx >> 2 : nx >> 1; }
+template <typename T, int LGNX> constexpr int row_qlg() { return row_tw_quarter<T>(LGNX) ? LGNX - 2 : 0; }
 // fused radix-2 levels per stage of a row transform
 __host__ __device__ constexpr int row_xlg(int lgnx) { return lgnx >= 10 ? CMBL_XLG : CMBL_XLG_SMALL; }
+#ifndef CMBL_F64_ROWS_2WG
+#define CMBL_F64_ROWS_2WG 0   // 1: quarter-table shapes take the tallest row group of which TWO fit a CU -- measured slower (profiles/r05_ab_fp64_rows_2wg_rejected.txt)
+#endif
 template <typename T> __host__ __device__ constexpr int row_rpw(int lgnx, int na) {
-  for (int rpw = (lgnx >= 10 ? CMBL_RPW_BIG : CMBL_RPW_SMALL); rpw >= 1; rpw >>= 1)
-    if (((size_t)row_tw(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024) return rpw;
+  const size_t budget = (CMBL_F64_ROWS_2WG && row_tw_quarter<T>(lgnx)) ? 80 * 1024 : 160 * 1024;
+  for (int pass = 0; pass < 2; ++pass)                                   // second pass: nothing fits twice -> whatever fits once
+    for (int rpw = (lgnx >= 10 ? CMBL_RPW_BIG : CMBL_RPW_SMALL); rpw >= 1; rpw >>= 1)
+      if (((size_t)row_tw<T>(1 << lgnx) + (size_t)na * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= (pass == 0 ? budget : (size_t)160 * 1024)) return rpw;
   return 0;
 }
 // Row-group heights compiled BESIDES the LDS-fit maximum.  Below Nx = 1024 a launch over groups of four rows has fewer workgroups than
@@ -561,7 +574,7 @@ __device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
         const cx<T>* p = s + r * LD + pad(xt * MIXW + c) + e;
-        const V uu = vload(p), t = vmulc(vload(p + pad(NH)), vload(tw + xt * MIXW + c + e));
+        const V uu = vload(p), t = vmulc(vload(p + pad(NH)), tw_read<T, row_qlg<T, LGNX>()>(tw, xt * MIXW + c + e));
         oa.v[e] = vcx(vscale(vadd(uu, t), scale)); ob.v[e] = vcx(vscale(vsub(uu, t), scale));
         if (nyq >= 0 && (ky0 + r == 0 || ky0 + r == nyq)) { oa.v[e].y = T(0); ob.v[e].y = T(0); }
       }
@@ -727,13 +740,13 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + row_tw(Nx);
+  cx<T>* s = tw + row_tw<T>(Nx);
   const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh, gridDim.x);
   const int NyhP = mixed_rows(Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx, fo = ((size_t)rg.sl * Nyh + rg.ky0) * Nx;
   CMBL_XWSTAMP(14);
   CMBL_XSTAMP(0);
-  TwStage<T, NT, row_tw(Nx)> twr;
+  TwStage<T, NT, row_tw<T>(Nx)> twr;
   twr.issue(twX);
   if (MODE == 1) rows_load_F<T, LGNX, RPW>(s, in + fo, rg.nr);
   else {
@@ -746,7 +759,7 @@ __global__ __launch_bounds__(row_nt(RPW), row_min_waves<T>()) void k_x_fft(const
   __syncthreads();
   CMBL_XSTAMP(1);
   CMBL_WVSTAMP(0);
-  const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
+  const WorkRows<ROW_RT, RPW, row_tw_quarter<T>(LGNX)> wk{1, rg.nr};
   if (MODE == 0) fft_dif_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw);
   CMBL_XSTAMP(2);
   if (MODE == 2) {

@@ -318,12 +318,12 @@ template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* smem, unsigned blk, unsigned nblk) {
   constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), NT = row_nt(RPW), PF = NH >= 64 ? NH / 64 : 1;
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + row_tw(Nx);
+  cx<T>* s = tw + row_tw<T>(Nx);
   cx<T>* s2 = s + RPW * LD;                                   // second row set: sequence RPW + row, owned by the same threads
   const RowGroup rg = row_group<RPW>(blk, a.Nyh, nblk);
   const int NyhP = mixed_rows(a.Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx;
-  TwStage<T, NT, row_tw(Nx)> twr;
+  TwStage<T, NT, row_tw<T>(Nx)> twr;
   twr.issue(a.twX);
   {
     cx<T>* const sa[2] = {s, s2};
@@ -338,7 +338,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   using V = typename vreg<T>::type;
   constexpr int XLG = row_xlg(LGNX), NS = num_stages(LGNX - 1, XLG), LG = stage_lg(LGNX - 1, NS - 1, XLG), r = 1 << LG;
   constexpr int VE = 16 / (int)sizeof(cx<T>), NV = r / VE;
-  const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
+  const WorkRows<ROW_RT, RPW, row_tw_quarter<T>(LGNX)> wk{1, rg.nr};
   const T inv = T(1) / T(Nx);
   const bool last = a.rk.last;
   // The Fourier state of the thread's butterflies (Y0, acc: 64 contiguous bytes each per butterfly) and lx do not depend on the
@@ -364,7 +364,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
     });
   };
   prefetch();
-  fft_dif_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW>, 0, 1>(s, WorkRows<ROW_RT, RPW>{2, rg.nr}, tw);
+  fft_dif_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW, row_tw_quarter<T>(LGNX)>, 0, 1>(s, WorkRows<ROW_RT, RPW, row_tw_quarter<T>(LGNX)>{2, rg.nr}, tw);
   int item = 0;
   wk.template each<LGNX - LG>([&](int row, int rr) {
     const int b0 = rr << LG;
@@ -405,7 +405,7 @@ __device__ __forceinline__ void adj_x_body(const AdjXArgs<T>& a, unsigned char* 
   });
   if (last) return;
   wk.sync();
-  fft_dit_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW>, NoPre, NS - 2>(s, wk, tw);
+  fft_dit_w<T, LD, LGNX, LGNX, XLG, 1, WorkRows<ROW_RT, RPW, row_tw_quarter<T>(LGNX)>, NoPre, NS - 2>(s, wk, tw);
   __syncthreads();
   rows_store_mixed_dit<T, LGNX, RPW>(s, a.Hnext + mo, tw, NyhP, rg.ky0, rg.nr, T(1));
 }
@@ -422,11 +422,11 @@ template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char* smem, unsigned blk, unsigned nblk) {
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + row_tw(Nx);
+  cx<T>* s = tw + row_tw<T>(Nx);
   const RowGroup rg = row_group<RPW>(blk, g.Nyh, nblk);
   const int NyhP = mixed_rows(g.Nyh);
   const size_t mo = (size_t)rg.sl * NyhP * Nx;
-  TwStage<T, NT, row_tw(Nx)> twr;
+  TwStage<T, NT, row_tw<T>(Nx)> twr;
   twr.issue(g.twX);
   {
     cx<T>* const sa[1] = {s};
@@ -435,7 +435,7 @@ __device__ __forceinline__ void grad_x_body(const GradXArgs<T>& g, unsigned char
   }
   twr.commit(tw);
   __syncthreads();
-  const WorkRows<ROW_RT, RPW> wk{1, rg.nr};
+  const WorkRows<ROW_RT, RPW, row_tw_quarter<T>(LGNX)> wk{1, rg.nr};
   // i*lx/Nx multiply between the last forward and the first inverse butterfly, in registers: slot i holds kx = bitrev(i), lx = dlx * signed(kx)
   const T dl = g.dlx_over_Nx;
   fft_dif_mid_dit_w<T, LD, LGNX, LGNX, row_xlg(LGNX), 1>(s, wk, tw, [dl](int, int b0, int j, typename vreg<T>::type v) {

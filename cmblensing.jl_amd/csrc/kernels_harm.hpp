@@ -405,7 +405,7 @@ __host__ __device__ constexpr int xpw_nt(int P, int rpw) { return P * rpw * ROW_
 // rows per workgroup: four sequences where possible (P = 1: 4 rows, P = 2: 2 rows; P = 3: 2 rows = six sequences), fewer when LDS is short
 template <typename T> __host__ __device__ constexpr int xpw_rpw(int lgnx, int P) {
   for (int rpw = (P == 1 ? 4 : 2); rpw >= 1; rpw >>= 1)
-    if (((size_t)row_tw(1 << lgnx) + (size_t)P * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024 && xpw_nt(P, rpw) <= 1024) return rpw;
+    if (((size_t)row_tw<T>(1 << lgnx) + (size_t)P * rpw * row_ld(1 << lgnx)) * sizeof(cx<T>) <= 160 * 1024 && xpw_nt(P, rpw) <= 1024) return rpw;
   return 0;
 }
 template <typename T, int LGNX, int RPW, int P, bool IN_F, typename PW>
@@ -414,13 +414,13 @@ __global__ __launch_bounds__(xpw_nt(P, RPW)) void k_x_pw(const cx<T>* __restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = xpw_nt(P, RPW), NT1 = row_nt(RPW), XLG = row_xlg(LGNX);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + row_tw(Nx);
+  cx<T>* s = tw + row_tw<T>(Nx);
   const int Nyh = io.Nyh, NyhP = mixed_rows(Nyh);
   const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh, gridDim.x);             // rg.sl = batch slot
   const int b = rg.sl;
   const int set = threadIdx.x / NT1, tid = threadIdx.x % NT1;               // this thread's pol slice during loads / stores
   const size_t mpl = (size_t)NyhP * Nx, fpl = (size_t)Nyh * Nx;
-  TwStage<T, NT, row_tw(Nx)> twr;
+  TwStage<T, NT, row_tw<T>(Nx)> twr;
   twr.issue(twX);
   if constexpr (IN_F) rows_load_F<T, LGNX, RPW>(s + set * RPW * LD, in + ((size_t)b * P + set) * fpl + (size_t)rg.ky0 * Nx, rg.nr, tid);
   else {
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(xpw_nt(P, RPW)) void k_x_pw(const cx<T>* __restrict
   }
   twr.commit(tw);
   __syncthreads();
-  const WorkSeqs<ROW_RT, RPW> wk{rg.nr};
+  const WorkSeqs<ROW_RT, RPW, row_tw_quarter<T>(LGNX)> wk{rg.nr};
   if constexpr (!IN_F) { fft_dif_w<T, LD, LGNX, LGNX, XLG, 1>(s, wk, tw); __syncthreads(); }
   const typename PW::Local loc = pw.prologue(b, B, reinterpret_cast<double*>(smem));
   SumAccRt<T> acc[PW::NACC > 0 ? PW::NACC : 1];
@@ -467,12 +467,12 @@ __global__ __launch_bounds__(row_nt(RPW)) void k_x_dphi(const cx<T>* __restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Nx = 1 << LGNX, LD = row_ld(Nx), NT = row_nt(RPW), XLG = row_xlg(LGNX);
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
-  cx<T>* s = tw + row_tw(Nx);
+  cx<T>* s = tw + row_tw<T>(Nx);
   const int NyhP = mixed_rows(Nyh);
   const RowGroup rg = row_group<RPW>(blockIdx.x, Nyh, gridDim.x);
   const int b = rg.sl;
   const size_t mpl = (size_t)NyhP * Nx, fpl = (size_t)Nyh * Nx;
-  TwStage<T, NT, row_tw(Nx)> twr;
+  TwStage<T, NT, row_tw<T>(Nx)> twr;
   twr.issue(twX);
   {
     cx<T>* sa[5]; const cx<T>* ga[5];
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(row_nt(RPW)) void k_x_dphi(const cx<T>* __restrict_
   }
   twr.commit(tw);
   __syncthreads();
-  fft_dif_w<T, LD, LGNX, LGNX, XLG, 1>(s, WorkRows<ROW_RT, RPW>{5, rg.nr}, tw);
+  fft_dif_w<T, LD, LGNX, LGNX, XLG, 1>(s, WorkRows<ROW_RT, RPW, row_tw_quarter<T>(LGNX)>{5, rg.nr}, tw);
   __syncthreads();
   for (int u = threadIdx.x; u < RPW * Nx; u += NT) {
     const int r = u >> LGNX, x = u & (Nx - 1);
