@@ -47,9 +47,8 @@ def test_grad_logpdf_mixed_1024_fp32_vs_oracle(pol):
         close(f"∇ϕ° 1024² {pol} quirk={quirk}", gp.arr.cpu().numpy(), ogp, TOL_GP[pol])
 
 
-# 3 x measured (L*f 2.95e-5, L'g 1.77e-4 against the oracle; the pullback as against the double-precision device operator at this size,
-# tests/test_gpu_fullsize.py DFLOW32: f 4.2e-5, δf 2.5e-4, δϕ 3.8e-4)
-TOL32_2048 = dict(Lf=9e-5, adj=5.4e-4, f0=1.3e-4, df=7.5e-4, dp=1.2e-3)
+# 3 x measured against the oracle on MI355X (profiles/r05_parity_measured.txt): L*f 2.95e-5, L'g 1.77e-4, pullback f 2.97e-5, δf 1.77e-4, δϕ 3.26e-4
+TOL32_2048 = dict(Lf=9e-5, adj=5.4e-4, f0=9e-5, df=5.4e-4, dp=9.8e-4)
 
 
 @pytest.fixture(scope="module")
