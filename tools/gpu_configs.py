@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import cmblensing_jl_amd as C
-from bench import synthetic_cls, algorithmic_bytes
+from bench import synthetic_cls, survey_bytes as algorithmic_bytes      # SURVEY §8(d) pass structure of the REFERENCE: a speed-up figure, not a bandwidth
 
 cls = synthetic_cls()
 
