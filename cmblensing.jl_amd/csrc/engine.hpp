@@ -376,7 +376,7 @@ struct Ctx : CtxBase {
   // ---- launch geometry -----------------------------------------------------------------------
   // Column kernels are compiled for the tile shapes of CMBL_COL_LIST: (lgM, R, NT) with C = R*NT/M columns per workgroup of
   // NT threads and R packed pairs per thread.
-  // CMBL_TUNE_C forces a width, CMBL_TUNE_RX the rows per workgroup of the row kernels (tuning aids).
+  // CMBL_TUNE_C / CMBL_TUNE_NT force a tile width / workgroup size (tuning aids); the rows per row workgroup follow row_rpw / pick_rpw.
   struct TileY { int C, NT, R; };
   mutable TileY tile_cache[2][2] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};   // [pair][narrow]: made once per kind (host launch path)
   const int tuneC = env_int("CMBL_TUNE_C", 0), tuneNT = env_int("CMBL_TUNE_NT", 0);
