@@ -98,3 +98,35 @@ def test_err_alloc_is_reported_and_the_context_survives():
     assert torch.equal((L7 * fs).arr, ref)
     after = ds.gradient_logpdf_mixed(fo, po)
     assert np.array_equal(np.asarray(before[0]), np.asarray(after[0])) and torch.equal(before[1].arr, after[1].arr) and torch.equal(before[2].arr, after[2].arr)
+
+
+@pytest.mark.parametrize("N,pol", [(128, "P"), (256, "IP")])
+def test_small_map_launch_geometry_changes_no_result(N, pol):
+    """Round 5's occupancy-aware launch geometry (options `occupancy_tiles`, `fill_target`, `row_fill_target`) decides WHICH
+    workgroup computes a column / row, never the arithmetic on it: every setting gives bit-identical results -- also when the flow is split
+    into one launch chain per pol slice (the tile choice follows the slices of the whole operation, not of one chain: a regression caught by
+    test_slice_streams_give_identical_results at 1024² while this was being built)."""
+    import cmblensing_jl_amd as C
+    s, ds, fo, po = _workload(C, N, pol, 31)
+    p = s["proj"]
+    fm = s["f"].to(C.MAP)
+    gl = fm.to(C.FOURIER)
+    def run():
+        L = ds.L(s["phi"])
+        ft = L * fm
+        dphi, df, _ = L.gradient(C.FLOW_FWD, ft, gl)
+        lp, gf, gp = ds.gradient_logpdf_mixed(fo, po)
+        return [ft.arr.clone(), (L.adjoint * gl).arr.clone(), dphi.arr.clone(), df.arr.clone(), gf.arr.clone(), gp.arr.clone(), torch.tensor(np.asarray(lp))]
+    saved = {k: p.get_option(k) for k in ("occupancy_tiles", "fill_target", "row_fill_target", "slice_streams", "slice_streams_min_pix")}
+    try:
+        p.set_option("occupancy_tiles", 0)
+        ref = run()
+        for occ, ft_, rt_, ss, mp in [(3, 0, 0, saved["slice_streams"], saved["slice_streams_min_pix"]), (1, 0, 0, 4, 0), (2, 0, 0, 4, 0), (3, 0, 0, 4, 0),
+                                      (3, 4096, 4096, 1, 0), (3, 64, 64, 4, 0)]:
+            for k, v in (("occupancy_tiles", occ), ("fill_target", ft_), ("row_fill_target", rt_), ("slice_streams", ss), ("slice_streams_min_pix", mp)):
+                p.set_option(k, v)
+            got = run()
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), (occ, ft_, rt_, ss, mp)
+    finally:
+        for k, v in saved.items():
+            p.set_option(k, v)
