@@ -114,4 +114,22 @@ for (pol, F, F̂) in ((:P, QUMap, EBFourier), (:IP, IQUMap, IEBFourier))
     out(tag * "map1_f", F̂(h.f)); out(tag * "map1_phi", Fourier(h.ϕ))
     npy_write(tag * "map1_alpha_logpdf_ncg", Float64[h.α, h.logpdf, length(h.argmaxf_logpdf_history)])
 end
+# ---- a chain file as JLD2.jl itself writes it (src/sampling.jl:311-320): `rundat` + `chunks_1 :: Vector{Vector{Any}}` of `Dict{Symbol,Any}` states ----
+# tests/test_jld2_writer.py compares the file cmblensing.jl_amd/jld2_writer.py produces for the SAME content with this one, message by message
+# (ADVICE r04: that writer's `Dict{Symbol,Any}` layout was inferred by analogy and has never been opened by JLD2.jl).  Plain values only (no Field
+# structs), the keys and the step numbering of the reference's state (`:step` = 2 for the first Gibbs pass, `:logpdf`, `:ΔH`, `:accept`, `:ϕ`, `:f`, `:θ`).
+using CMBLensing: jldopen
+let fn = joinpath(outdir, "chain_fixture.jld2")
+    state(step, c) = Dict{Symbol,Any}(:step => step, :logpdf => -100.0 - step - c, :ΔH => 0.25 * step, :accept => isodd(step), :ncg => 17.0,
+                                      :ϕ => ComplexF64[x + 10y + im * c for x in 1:3, y in 1:4], :f => ComplexF64[x - y + im * step for x in 1:3, y in 1:4, p in 1:2],
+                                      :θ => Dict{Symbol,Any}(:r => 0.21, :Aphi => 1.1))
+    chunks = [Any[state(step, c) for step in 2:3] for c in 0:1]
+    jldopen(fn, "w") do io
+        write(io, "rundat", Dict{Symbol,Any}(:nchains => 2, :eps => 0.01, :rng => "device"))
+        write(io, "chunks_1", chunks)
+    end
+    jldopen(fn, "a+") do io                                                # the append path (:313-316)
+        write(io, "chunks_2", [Any[state(4, c)] for c in 0:1])
+    end
+end
 println("wrote ", length(readdir(outdir)), " files to ", outdir)

@@ -185,3 +185,49 @@ def test_files_of_the_julia_package_are_read_only_here(tmp_path):
     from_writer = None
     with pytest.raises(ValueError, match="this package only"):
         W.JLD2Writer(fn, "a")
+
+
+JULIA_CHAIN = os.environ.get("CMBL_JULIA_CHAIN_FIXTURE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_outputs", "chain_fixture.jld2")
+
+
+@pytest.mark.skipif(not os.path.isfile(JULIA_CHAIN), reason="parity unpinned: tests/golden/ref_outputs/chain_fixture.jld2 (a chain file written by JLD2.jl itself, "
+                    "julia/make_reference_fixtures.jl) is absent -- no Julia in the build image; the `.jld2` output of jld2_writer.py stays experimental")
+def test_same_messages_as_a_chain_file_jld2_jl_wrote(tmp_path):
+    """The file JLD2.jl writes for a `Vector{Vector{Any}}` of `Dict{Symbol,Any}` states against the file jld2_writer.py writes for the SAME content:
+    same values through the reader, and for every object class (root links, the `Dict` datasets, their committed datatypes, the `Vector{Any}` of object
+    references) the same header messages -- kinds, flags and the layout-defining leading bytes -- in the same order."""
+    ref = J.JLD2File(JULIA_CHAIN, verify=True)
+    def state(step, c):
+        return {"step": step - 1, "logpdf": -100.0 - step - c, "dH": 0.25 * step, "accept": bool(step % 2), "ncg": 17.0,
+                "phi": np.array([[x + 10 * y + 1j * c for x in range(1, 4)] for y in range(1, 5)], np.complex128),               # NumPy (Nx, Ny) == Julia (Ny, Nx)
+                "f": np.array([[[x - y + 1j * step for x in range(1, 4)] for y in range(1, 5)] for p in range(2)], np.complex128),
+                "theta_r": 0.21, "theta_Aphi": 1.1}
+    fn = str(tmp_path / "mine.jld2")
+    CF.write_chunk(fn, 1, [[state(step, c) for step in (2, 3)] for c in (0, 1)], rundat=dict(nchains=2, eps=0.01, rng="device"), clobber=True)
+    CF.write_chunk(fn, 2, [[state(4, c)] for c in (0, 1)])
+    mine = J.JLD2File(fn, verify=True)
+    assert sorted(mine.keys()) == sorted(ref.keys()) == ["chunks_1", "chunks_2", "rundat"]
+    # the same values, read through the same reader
+    for key in ("chunks_1", "chunks_2"):
+        a, b = J.to_python(mine[key]), J.to_python(ref[key])
+        assert len(a) == len(b) and all(len(x) == len(y) for x, y in zip(a, b))
+        for ca, cb in zip(a, b):
+            for sa, sb in zip(ca, cb):
+                assert set(sa) == set(sb), (set(sa), set(sb))
+                for k in sa:
+                    va, vb = CF._jld2_value(sa[k]), CF._jld2_value(sb[k])
+                    if isinstance(va, dict):
+                        assert va == vb
+                    else:
+                        np.testing.assert_array_equal(np.asarray(va), np.asarray(vb))
+    # the same object structure: message kinds and flags of the dataset headers and of the committed datatypes they point to
+    kinds = lambda f, addr: [(t, fl) for t, fl, _ in f._messages(addr) if t != 0x00]
+    for key in ("rundat", "chunks_1"):
+        assert kinds(mine, mine._root_links[key]) == kinds(ref, ref._root_links[key]), key
+    tm = {mine._committed_type(a).julia_type: a for a in mine._links(mine._messages(mine._root_links["_types"])).values()}
+    tr = {ref._committed_type(a).julia_type: a for a in ref._links(ref._messages(ref._root_links["_types"])).values()}
+    assert set(tr) <= set(tm) | {t for t in tr if t.startswith("Core.")}, (set(tr) - set(tm))
+    for name in set(tm) & set(tr):
+        assert kinds(mine, tm[name]) == kinds(ref, tr[name]), name
+        cm, cr = mine._committed_type(tm[name]), ref._committed_type(tr[name])
+        assert (cm.cls, cm.written_type) == (cr.cls, cr.written_type), name
