@@ -100,7 +100,7 @@ def test_err_alloc_is_reported_and_the_context_survives():
     assert np.array_equal(np.asarray(before[0]), np.asarray(after[0])) and torch.equal(before[1].arr, after[1].arr) and torch.equal(before[2].arr, after[2].arr)
 
 
-@pytest.mark.parametrize("N,pol", [(128, "P"), (256, "IP")])
+@pytest.mark.parametrize("N,pol", [(128, "P"), (256, "IP"), ((512, 64), "I"), ((64, 512), "P")])
 def test_small_map_launch_geometry_changes_no_result(N, pol):
     """Round 5's occupancy-aware launch geometry (options `occupancy_tiles`, `fill_target`, `row_fill_target`) decides WHICH
     workgroup computes a column / row, never the arithmetic on it: every setting gives bit-identical results -- also when the flow is split
