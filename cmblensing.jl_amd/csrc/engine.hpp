@@ -92,7 +92,7 @@ struct CtxBase {
     int gen_prologue = env_int("CMBL_GEN_PROLOGUE", 1) != 0;              //   pointwise work in the fetch of the consuming transform
     int gen_xderiv_fused = env_int("CMBL_GEN_XDERIV_FUSED", 1) != 0;      //   d/dx pass as one launch
     // launch geometry that fills the chip on small maps (profiles/r05_ab_occupancy_tiles.txt): narrower column tiles while a launch has
-    // fewer workgroups than `fill_target` (0: twice the number of CUs), shorter row groups while it has fewer than `row_fill_target`
+    // fewer workgroups than `fill_target` (0: the rule in Ctx::tileY), shorter row groups while it has fewer than `row_fill_target`
     // (0: half the number of CUs -- 130 -> 258 row workgroups at 512^2 QU measured slower, 34 -> 130 at 128^2 17 % faster)
     int col_pipeline = env_int("CMBL_COL_PIPELINE", 1);                   // only in -DCMBL_EXPERIMENT_COL_PIPELINE builds: two tiles per column workgroup
     int occupancy_tiles = env_int("CMBL_OCCUPANCY_TILES", 3);             // bit 0: narrower column tiles, bit 1: shorter row groups
@@ -381,14 +381,19 @@ struct Ctx : CtxBase {
   mutable TileY tile_cache[2][2] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};   // [pair][narrow]: made once per kind (host launch path)
   const int tuneC = env_int("CMBL_TUNE_C", 0), tuneNT = env_int("CMBL_TUNE_NT", 0);
   // workgroups a launch needs before the tallest row group / the four-column tile is taken (see row_rpw_variants)
-  long fill_target() const { return opts.fill_target > 0 ? opts.fill_target : 2 * num_cus; }
   long row_fill_target() const { return opts.row_fill_target > 0 ? opts.row_fill_target : num_cus / 2; }
   TileY tileY(long slices, bool pair, int preferNT = 0) const {
     // small maps: a launch of four-column tiles leaves CUs idle (512^2: 128 tiles per slice) -- take the two-column tile where compiled.
     // `slices` = all slices of the operation, not of one launch chain of it: the choice (and with it the rounding of the results) must not
     // depend on how a flow is split over streams.  Up to 512 rows only: from 1024 rows on the narrowest tile with C >= 4 measured best
     // (profiles/r02_variants.txt), and nothing narrower was measured there.
-    const bool narrow = (opts.occupancy_tiles & 1) && lgM <= 8 && (long)(Nx / 4) * slices < fill_target();
+    // Default rule (fill_target = 0): narrow when four-column tiles leave CUs idle (fewer tiles than CUs) or load them unevenly (between one and
+    // two tiles per CU, not a whole number: 512^2 T+QU, 384 tiles, -4 %).  Exactly one tile per CU (512^2 QU) stays on four columns: two-column
+    // tiles measured within 1 % there while the L2 <-> fabric counters read 1.26 x the compulsory bytes of delta_cols instead of 1.01 (each 128-byte
+    // line is then requested by two workgroups).
+    const long wtiles = (long)(Nx / 4) * slices;
+    const bool narrow = (opts.occupancy_tiles & 1) && lgM <= 8 &&
+                        (opts.fill_target > 0 ? wtiles < opts.fill_target : (wtiles < num_cus || (wtiles < 2 * num_cus && wtiles % num_cus != 0)));
     if (preferNT == 0 && tile_cache[pair][narrow].C > 0) return tile_cache[pair][narrow];
     static const int list[][3] = {
 #define CMBL_X(lgm, r, nt) {lgm, r, nt},

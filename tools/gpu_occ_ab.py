@@ -41,7 +41,7 @@ print(f"N {N} pol {pol} {T}")
 ref = None
 rounds = int(os.environ.get("ROUNDS", 2))
 best = {}
-settings = [(0, 0), (3, 0), (3, 64), (3, 192), (3, 256)]        # (occupancy_tiles, row_fill_target); column target = default
+settings = [(0, 0), (3, 0), (2, 0), (1, 0)]        # (occupancy_tiles, row_fill_target); column rule = default
 for r in range(rounds):
     for occ, tg in settings:
         out, t = run(occ, tg)
