@@ -94,6 +94,7 @@ struct CtxBase {
     // launch geometry that fills the chip on small maps (profiles/r05_ab_occupancy_tiles.txt): narrower column tiles while a launch has
     // fewer workgroups than `fill_target` (0: the rule in Ctx::tileY), shorter row groups while it has fewer than `row_fill_target`
     // (0: half the number of CUs -- 130 -> 258 row workgroups at 512^2 QU measured slower, 34 -> 130 at 128^2 17 % faster)
+    int col_prefetch = env_int("CMBL_COL_PREFETCH", -1);                  // touch prefetch of multi-round column launches: -1 = Ctx::col_prefetch's rule, 0 = off, > 0 = that distance (blocks)
     int col_pipeline = env_int("CMBL_COL_PIPELINE", 1);                   // only in -DCMBL_EXPERIMENT_COL_PIPELINE builds: two tiles per column workgroup
     int occupancy_tiles = env_int("CMBL_OCCUPANCY_TILES", 3);             // bit 0: narrower column tiles, bit 1: shorter row groups
     int fill_target = env_int("CMBL_FILL_TARGET", 0);
@@ -109,6 +110,7 @@ struct CtxBase {
     if (k == "gen_prologue") return &opts.gen_prologue;
     if (k == "gen_xderiv_fused") return &opts.gen_xderiv_fused;
     if (k == "col_pipeline") return &opts.col_pipeline;
+    if (k == "col_prefetch") return &opts.col_prefetch;
     if (k == "occupancy_tiles") return &opts.occupancy_tiles;
     if (k == "fill_target") return &opts.fill_target;
     if (k == "row_fill_target") return &opts.row_fill_target;
@@ -443,6 +445,16 @@ struct Ctx : CtxBase {
     int tpw = 2;
     while (tpw > 1 && (tiles % (8 * tpw) != 0 || (long)(tiles / tpw) * slices < num_cus)) tpw >>= 1;
     return tpw;
+  }
+  // Touch-prefetch distance of a column launch (kernels_flow.hpp TouchTiles): three quarters of the workgroups of this launch that are resident at
+  // once -- the CUs, shared by the K launch chains that run side by side -- as a multiple of 8 (XCDs): measured best at 80-96 for two chains and
+  // 192 for one (profiles/r05_ab_touch_prefetch.txt).  Only for the shapes that run one workgroup per CU over many residency rounds (double
+  // precision, 2048 rows); launches of fewer than three rounds have nobody to prefetch for.
+  int col_prefetch(long tiles, long slices, int K) const {
+    if (opts.col_prefetch >= 0) return opts.col_prefetch;
+    if (!col_touch<T>(lgM)) return 0;
+    const long resident = num_cus / std::max(K, 1);
+    return tiles * slices >= 3 * resident ? (int)std::max<long>(8, (3 * resident / 4) & ~7L) : 0;
   }
   size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
   // Row launches: one workgroup per group of RPW adjacent ky rows of a slice (RPW = row_rpw<T>(lgNx, row sets), kernels_fft.hpp)
@@ -1091,6 +1103,7 @@ struct Flow {
           a.Nx = c->Nx; a.P = P; a.emit_last = emit_last ? 1 : 0;
           a.rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
           a.ph = ph(a.rk.t, phi_off(g, K, B));
+          a.pf = c->col_prefetch(c->Nx / tile.C, gs, K);
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
             constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
             CMBL_LAUNCH_NT(c, K_FLOW_Y, NT, (k_flow_y_fwd<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)gs), c->ldsY(tile.C), st, a);
@@ -1127,6 +1140,7 @@ struct Flow {
           a.H = H.as<cx<T>>() + som; a.Wx = Wx.as<cx<T>>() + som; a.Wy = Wy.as<cx<T>>() + som; a.ph = ph(rk.t, phi_off(g, K, B));
           a.twY = c->twY.template as<cx<T>>(); a.ly = c->ly.template as<T>();
           a.Nx = c->Nx; a.P = P; a.t = rk.t;
+          a.pf = c->col_prefetch(c->Nx / tile.C, gs, K);
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
             constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
             CMBL_LAUNCH_NT(c, K_ADJ_Y, NT, (k_adj_y<T, R, NT, LGM>), dim3(c->Nx / tile.C, (unsigned)gs), c->ldsY(tile.C), st, a);
@@ -1196,6 +1210,7 @@ struct Flow {
           a.Nx = c->Nx; a.P = P; a.rk = rk;
           d.H = H.as<cx<T>>() + spm; d.Wx = Wx.as<cx<T>>() + spm; d.Wy = Wy.as<cx<T>>() + spm;
           d.w1p = Wst.as<T>() + ((size_t)(2 * it) * slices + so) * np; d.w2p = d.w1p + (size_t)slices * np;
+          d.pf = c->col_prefetch(c->Nx / tile.C, gs, K);
           c->dispatch_col(tile, [&](auto lgm, auto r, auto nt) {
             constexpr int LGM = decltype(lgm)::value, R = decltype(r)::value, NT = decltype(nt)::value;
             // one-workgroup-per-CU shapes (2048 rows in double precision) walk several tiles per workgroup with the next tile's loads

@@ -187,6 +187,50 @@ __device__ __forceinline__ void npt_write_forward(cx<T>* s, const cx<T>* tw, XY&
   }
 }
 
+// Touch prefetch (round 5).  A column launch of several residency rounds with ONE workgroup per CU (2048 rows in double precision: 244 registers x
+// 512 threads is the CU's register file) has nobody to fill the ~9 us a workgroup waits for its first tile (profiles/r05_stamps_delta_cols_2048_f64.txt).
+// The workgroup that will REPLACE this one is, to dispatch-order accuracy, `dist` blocks ahead in the grid, and -- block b is observed on XCD b % 8
+// (speed only) -- on this XCD when dist is a multiple of 8.  So this workgroup reads ONE dword of every 128-byte line of that block's head tiles
+// into the shared L2, as soon as its own last global load has been consumed: NL lines per tile = one or two loads per thread and array.
+// The loads are inline asm, so the compiler tracks neither them nor their destination registers' contents: nothing ever waits for them (they return
+// during the two transforms that follow; s_endpgm waits for stragglers), and `keep()` at the end of the kernel only keeps the destination
+// registers from being handed to another value while a load may still land in them.
+template <typename T, int NT, int LGM, int C, int NARR> struct TouchTiles {
+  static constexpr int M = 1 << LGM, NyhP = mixed_rows(M + 1), RPL = 128 / (MIXW * (int)sizeof(cx<T>)), NL = (M + 1 + RPL - 1) / RPL;
+  static constexpr int NB = (C + MIXW - 1) / MIXW, K = (NL * NB + NT - 1) / NT;
+  unsigned r[NARR > 0 ? NARR : 1][K];                                       // NARR = 0: the shape does not prefetch (nothing is issued or kept)
+  __device__ __forceinline__ void issue(const cx<T>* const (&g)[NARR > 0 ? NARR : 1] /*slice bases*/, int x0) {
+#pragma unroll
+    for (int a = 0; a < NARR; ++a) {
+      const cx<T>* tg = tile_base(g[a], x0, NyhP);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        int i = threadIdx.x + k * NT;
+        if (i >= NL * NB) i = NL * NB - 1;                                  // the spare lanes of the last round re-touch the last line
+        const int blk = i / NL, ln = i - blk * NL;
+        const void* q = tg + ((size_t)blk * NyhP + (size_t)ln * RPL) * MIXW;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r[a][k]) : "v"(q) : "memory");
+      }
+    }
+  }
+  __device__ __forceinline__ void keep() const {
+#pragma unroll
+    for (int a = 0; a < NARR; ++a)
+#pragma unroll
+      for (int k = 0; k < K; ++k) asm volatile("" :: "v"(r[a][k]));
+  }
+};
+
+// compiled into the one-workgroup-per-CU shapes only (every other instantiation is byte for byte what it was)
+template <typename T> constexpr bool col_touch(int lgm) { return sizeof(T) == 8 && lgm >= 10; }
+// block -> (slice offset in the mixed layout, first column) of the workgroup `pf` blocks ahead of this one in a (tiles, slices) column grid
+template <int C> __device__ __forceinline__ bool touch_target(int pf, size_t sl, int NyhP, int Nx, size_t& mo2, int& x02) {
+  const unsigned t = blockIdx.y * gridDim.x + blockIdx.x + (unsigned)pf;
+  if (pf <= 0 || t >= gridDim.x * gridDim.y) return false;
+  mo2 = (sl - blockIdx.y + t / gridDim.x) * (size_t)NyhP * Nx;
+  x02 = xcd_tile((int)(t % gridDim.x), gridDim.x) * C;
+  return true;
+}
 // ---------------------------------------------------------------------------------------------
 // Forward / inverse flow, column kernel.  grid (Nx/C, P*B).  LDS: twY[M] + C*tile_ld(2M).
 //   in : A  = rfft_y(f_s)  (mixed), Gx = d/dx f_s y-transformed (mixed; from k_x_fft<MODE 2>)
@@ -201,6 +245,7 @@ template <typename T> struct FlowYArgs {
   int Nx, P;
   RKCoef<T> rk;
   int emit_last;            // the last stage also writes Anext = rfft_y(final state): the caller continues in Fourier space without a y pass
+  int pf;                   // > 0: touch prefetch distance in blocks (TouchTiles)
 };
 
 template <typename T, int R, int NT, int LGM>
@@ -250,9 +295,17 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
     if (a.rk.stage == 4) at32(y0p, e) = y0[i]; else at32(accp, e) = acc[i];
   }
   if (a.rk.last && !a.emit_last) return;
+  TouchTiles<T, NT, LGM, C, col_touch<T>(LGM) ? 2 : 0> touch;
+  size_t mo2 = 0; int x02 = 0;
+  bool do_touch = false;
+  if constexpr (col_touch<T>(LGM)) {
+    do_touch = touch_target<C>(a.pf, sl, NyhP, Nx, mo2, x02);
+    if (do_touch) { const cx<T>* const heads[2] = {a.Gx + mo2, a.A + mo2}; touch.issue(heads, x02); }
+  }
   __syncthreads();
   mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
   half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);
+  if constexpr (col_touch<T>(LGM)) { if (do_touch) touch.keep(); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -264,6 +317,7 @@ template <typename T> struct AdjYArgs {
   const cx<T>* twY; const T* ly;
   int Nx, P;
   T t;
+  int pf;                   // > 0: touch prefetch distance in blocks (TouchTiles)
 };
 
 template <typename T, int R, int NT, int LGM>
@@ -296,13 +350,26 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   __syncthreads();
   cx<T> yv[R];
   mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, yv);
+  TouchTiles<T, NT, LGM, C, col_touch<T>(LGM) ? 1 : 0> touch;
+  size_t mo2 = 0; int x02 = 0;
+  bool do_touch = false;
+  if constexpr (col_touch<T>(LGM)) {
+    // every global load of this thread must have been consumed before the untracked touch loads are issued (a compiler wait for an OLDER load would
+    // otherwise also wait for them): form the products now (the same arithmetic the transform's writer does)
+#pragma unroll
+    for (int i = 0; i < R; ++i) { px[i] = pmul(px[i], yv[i]); py[i] = pmul(py[i], yv[i]); }
+    do_touch = touch_target<C>(a.pf, sl, NyhP, Nx, mo2, x02);
+    if (do_touch) { const cx<T>* const heads[1] = {a.H + mo2}; touch.issue(heads, x02); }
+  }
   __syncthreads();
-  npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], yv[i]); y = pmul(py[i], yv[i]); });
+  if constexpr (col_touch<T>(LGM)) npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = px[i]; y = py[i]; });
+  else npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], yv[i]); y = pmul(py[i], yv[i]); });
   cx<T>* Wx = tile_base(a.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(a.Wy + moff, x0, NyhP);
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
     const unsigned gi = tile_off<C>(k, c, x0, NyhP);
     handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, lyr[i]));
   });
+  if constexpr (col_touch<T>(LGM)) { if (do_touch) touch.keep(); }
 }
 
 // Adjoint flow, row kernel:  k = i*lx*fft_x(Wx) + fft_x(Wy')  -> RK update of the Fourier state (F layout)
@@ -454,6 +521,7 @@ template <typename T> struct DeltaYArgs {
   FlowYArgs<T> f;           // f part
   const cx<T>* H; cx<T>* Wx; cx<T>* Wy;   // delta-f part
   T* w1p; T* w2p;           // (P*B, Nx, Ny)
+  int pf;                   // > 0: touch prefetch distance in blocks (TouchTiles)
 };
 
 template <typename T, int R, int NT, int LGM>
@@ -523,6 +591,13 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
     fn[i] = rk_update(a.rk, kv, y0, acc);
     if (a.rk.stage == 4) at32(y0p, e) = y0; else at32(accp, e) = acc;
   }
+  TouchTiles<T, NT, LGM, C, col_touch<T>(LGM) ? 3 : 0> touch;
+  size_t mo2 = 0; int x02 = 0;
+  bool do_touch = false;
+  if constexpr (col_touch<T>(LGM)) {
+    do_touch = touch_target<C>(d.pf, sl, NyhP, Nx, mo2, x02);
+    if (do_touch) { const cx<T>* const heads[3] = {a.Gx + mo2, a.A + mo2, d.H + mo2}; touch.issue(heads, x02); }
+  }
   __syncthreads();
   CMBL_STAMP(6);
   // (Wx, Wy') from one N-point forward transform of px*Ldf + i*py*Ldf
@@ -537,7 +612,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
     });
   }
   CMBL_STAMP(9);
-  if (a.rk.last) { CMBL_WSTAMP(15); return; }
+  if (a.rk.last) { if constexpr (col_touch<T>(LGM)) { if (do_touch) touch.keep(); } CMBL_WSTAMP(15); return; }
   __syncthreads();
   // next-stage f : rfft_y
   mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
@@ -545,6 +620,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);
   CMBL_STAMP(12);
   CMBL_WSTAMP(15);
+  if constexpr (col_touch<T>(LGM)) { if (do_touch) touch.keep(); }
 }
 
 #ifdef CMBL_EXPERIMENT_COL_PIPELINE

@@ -171,3 +171,31 @@ def test_p_cache_matches_on_the_fly_p():
     r1 = run()
     for x, y in zip(r0, r1):
         assert float((x - y).abs().max() / y.abs().max()) < 2e-6
+
+
+def test_touch_prefetch_changes_no_result():
+    """The double-precision column kernels at >= 2048 rows read one dword per line of the head tiles of the workgroup that will replace them (option
+    `col_prefetch`, kernels_flow.hpp TouchTiles: untracked inline-asm loads whose values are never used).  Speed only: with the prefetch off, at the
+    built-in distance and at an odd one the flows and the pullback are bit-identical -- also across the last blocks of the grid, which have nobody to
+    prefetch for, and with one launch over all slices instead of one chain per pol slice."""
+    import cmblensing_jl_amd as C
+    proj = C.ProjLambert(2048, 2048, 2.0, torch.float64, 0)
+    f, g, phi, _ = _fields(C, proj, 2)
+    L = C.LenseFlow(proj, 3)(phi)                                       # 12 stages are as good as 40 for this purpose
+    gl = g.to(C.FOURIER)
+    def run():
+        a = L * f
+        c = L.adjoint * gl
+        dphi, df, fs = L.gradient(C.FLOW_FWD, a, gl)
+        torch.cuda.synchronize()
+        return [x.arr.clone() for x in (a, c, dphi, df, fs)]
+    saved = {k: proj.get_option(k) for k in ("col_prefetch", "slice_streams")}
+    try:
+        proj.set_option("col_prefetch", 0)
+        ref = run()
+        for pf, ss in ((-1, saved["slice_streams"]), (40, saved["slice_streams"]), (-1, 1), (1000, 1)):
+            proj.set_option("col_prefetch", pf); proj.set_option("slice_streams", ss)
+            assert all(torch.equal(x, y) for x, y in zip(run(), ref)), (pf, ss)
+    finally:
+        for k, v in saved.items():
+            proj.set_option(k, v)
