@@ -83,6 +83,11 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *        "pcache_max_mb"         CMBL_PCACHE_MAX_MB (16384)
  *        "fused_harm"            !CMBL_NO_FUSED_HARM (1)           harmonic-space operator chains inside one row pass
  *        "gen_separable", "gen_prologue", "gen_xderiv_fused"       any-size path stage fusions (CMBL_GEN_SEPARABLE / _PROLOGUE / _XDERIV_FUSED, all 1)
+ *        "occupancy_tiles"       CMBL_OCCUPANCY_TILES (3)          small maps: bit 0 = two-column tiles when four-column tiles leave CUs idle or unevenly loaded, bit 1 = shorter row groups
+ *        "fill_target"           CMBL_FILL_TARGET (0)              > 0: narrow the column tiles below that many tiles per launch instead of the built-in rule
+ *        "row_fill_target"       CMBL_ROW_FILL_TARGET (0 = CUs/2)  shorten the row groups below that many groups per launch
+ *        "col_prefetch"          CMBL_COL_PREFETCH (-1)            touch prefetch of the double-precision >= 2048-row column kernels: -1 = built-in distance, 0 = off, > 0 = blocks ahead
+ *      (the launch-geometry and prefetch switches change no result at all: tests/test_gpu_boundary.py, tests/test_gpu_fullsize.py)
  *      Unknown names return CMBL_ERR_ARG.  The reference has no counterpart (its switches are Julia keyword arguments). */
 int cmbl_ctx_set_option(cmbl_ctx* ctx, const char* name, int value);
 int cmbl_ctx_get_option(cmbl_ctx* ctx, const char* name, int* value_host);
