@@ -221,8 +221,11 @@ template <typename T, int NT, int LGM, int C, int NARR> struct TouchTiles {
   }
 };
 
+#ifndef CMBL_TOUCH_ALL
+#define CMBL_TOUCH_ALL 0            // 1: compile the touch prefetch into every column kernel (experiment builds)
+#endif
 // compiled into the one-workgroup-per-CU shapes only (every other instantiation is byte for byte what it was)
-template <typename T> constexpr bool col_touch(int lgm) { return sizeof(T) == 8 && lgm >= 10; }
+template <typename T> constexpr bool col_touch(int lgm) { return CMBL_TOUCH_ALL || (sizeof(T) == 8 && lgm >= 10); }
 // block -> (slice offset in the mixed layout, first column) of the workgroup `pf` blocks ahead of this one in a (tiles, slices) column grid
 template <int C> __device__ __forceinline__ bool touch_target(int pf, size_t sl, int NyhP, int Nx, size_t& mo2, int& x02) {
   const unsigned t = blockIdx.y * gridDim.x + blockIdx.x + (unsigned)pf;
