@@ -456,7 +456,8 @@ struct Ctx : CtxBase {
     const long resident = num_cus / std::max(K, 1);
     return tiles * slices >= 3 * resident ? (int)std::max<long>(8, (3 * resident / 4) & ~7L) : 0;
   }
-  size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>); }
+  // (+ the 256-byte pad of the touch prefetch behind the tile for the shapes that prefetch: kernels_flow.hpp TouchTiles)
+  size_t ldsY(int C, bool pair = true) const { return ((size_t)M + (size_t)C * tile_ld(pair ? 2 * M : M)) * sizeof(cx<T>) + (pair && col_touch<T>(lgM) ? TOUCH_PAD : 0); }
   // Row launches: one workgroup per group of RPW adjacent ky rows of a slice (RPW = row_rpw<T>(lgNx, row sets), kernels_fft.hpp)
   // Row launches of about one workgroup per CU (258 row groups at 1024^2 QU) run faster when no CU hosts two of them: two co-resident
   // row workgroups are VALU-issue bound and the launch ends with its slowest workgroup.  Asking for more than half of the CU's LDS

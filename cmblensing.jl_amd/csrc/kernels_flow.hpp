@@ -192,14 +192,19 @@ __device__ __forceinline__ void npt_write_forward(cx<T>* s, const cx<T>* tw, XY&
 // The workgroup that will REPLACE this one is, to dispatch-order accuracy, `dist` blocks ahead in the grid, and -- block b is observed on XCD b % 8
 // (speed only) -- on this XCD when dist is a multiple of 8.  So this workgroup reads ONE dword of every 128-byte line of that block's head tiles
 // into the shared L2, as soon as its own last global load has been consumed: NL lines per tile = one or two loads per thread and array.
-// The loads are inline asm, so the compiler tracks neither them nor their destination registers' contents: nothing ever waits for them (they return
-// during the two transforms that follow; s_endpgm waits for stragglers), and `keep()` at the end of the kernel only keeps the destination
-// registers from being handed to another value while a load may still land in them.
+// The loads are LDS-DMA (`global_load_lds_dword`) into a 256-byte pad behind the tile that nothing ever reads: they have NO destination register.
+// (A first version loaded into registers the compiler did not know were written asynchronously; in the register-starved double-precision row kernel
+// the compiler moved such a "value" to an AGPR and reused the VGPR, the late load landed on an address register, and the run died with a memory
+// fault -- the column kernels happened to survive the same construction, which is not a guarantee.)  Being inline asm they are also invisible to the
+// compiler's s_waitcnt bookkeeping: nothing waits for them; they return during the transforms that follow, and `drain()` -- one s_waitcnt before the
+// workgroup's last stores -- makes sure that none can land in LDS that already belongs to another workgroup.
 template <typename T, int NT, int LGM, int C, int NARR> struct TouchTiles {
   static constexpr int M = 1 << LGM, NyhP = mixed_rows(M + 1), RPL = 128 / (MIXW * (int)sizeof(cx<T>)), NL = (M + 1 + RPL - 1) / RPL;
   static constexpr int NB = (C + MIXW - 1) / MIXW, K = (NL * NB + NT - 1) / NT;
-  unsigned r[NARR > 0 ? NARR : 1][K];                                       // NARR = 0: the shape does not prefetch (nothing is issued or kept)
-  __device__ __forceinline__ void issue(const cx<T>* const (&g)[NARR > 0 ? NARR : 1] /*slice bases*/, int x0) {
+  static constexpr int PAD_BYTES = 256;                                   // one wave-instruction of 64 lanes x 4 bytes; every wave uses the same pad
+  // pad: LDS byte address of the pad (wave-uniform)
+  __device__ __forceinline__ static void issue(const cx<T>* const (&g)[NARR > 0 ? NARR : 1] /*slice bases*/, int x0, unsigned pad) {
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)pad);
 #pragma unroll
     for (int a = 0; a < NARR; ++a) {
       const cx<T>* tg = tile_base(g[a], x0, NyhP);
@@ -209,16 +214,13 @@ template <typename T, int NT, int LGM, int C, int NARR> struct TouchTiles {
         if (i >= NL * NB) i = NL * NB - 1;                                  // the spare lanes of the last round re-touch the last line
         const int blk = i / NL, ln = i - blk * NL;
         const void* q = tg + ((size_t)blk * NyhP + (size_t)ln * RPL) * MIXW;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r[a][k]) : "v"(q) : "memory");
+        unsigned keep;
+        // M0 (the LDS-DMA destination base) is compiler-reserved: set and restored inside the statement (cdna_hip_programming.md, LDS-DMA recipe)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(q), "s"(m0v) : "memory");
       }
     }
   }
-  __device__ __forceinline__ void keep() const {
-#pragma unroll
-    for (int a = 0; a < NARR; ++a)
-#pragma unroll
-      for (int k = 0; k < K; ++k) asm volatile("" :: "v"(r[a][k]));
-  }
+  __device__ __forceinline__ static void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
 #ifndef CMBL_TOUCH_ALL
@@ -226,6 +228,9 @@ template <typename T, int NT, int LGM, int C, int NARR> struct TouchTiles {
 #endif
 // compiled into the one-workgroup-per-CU shapes only (every other instantiation is byte for byte what it was)
 template <typename T> constexpr bool col_touch(int lgm) { return CMBL_TOUCH_ALL || (sizeof(T) == 8 && lgm >= 10); }
+// LDS byte address of the touch pad: right behind the column tile (twiddles M + C columns of LD slots); the launch asks for TOUCH_PAD bytes more
+constexpr int TOUCH_PAD = 256;
+template <typename T, int C, int LD> __device__ __forceinline__ unsigned touch_pad(int M) { return (unsigned)(((size_t)M + (size_t)C * LD) * sizeof(cx<T>)); }
 // block -> (slice offset in the mixed layout, first column) of the workgroup `pf` blocks ahead of this one in a (tiles, slices) column grid
 template <int C> __device__ __forceinline__ bool touch_target(int pf, size_t sl, int NyhP, int Nx, size_t& mo2, int& x02) {
   const unsigned t = blockIdx.y * gridDim.x + blockIdx.x + (unsigned)pf;
@@ -298,17 +303,17 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_flow_y_fwd(Flow
     if (a.rk.stage == 4) at32(y0p, e) = y0[i]; else at32(accp, e) = acc[i];
   }
   if (a.rk.last && !a.emit_last) return;
-  TouchTiles<T, NT, LGM, C, col_touch<T>(LGM) ? 2 : 0> touch;
+  using Touch = TouchTiles<T, NT, LGM, C, 2>;
   size_t mo2 = 0; int x02 = 0;
   bool do_touch = false;
   if constexpr (col_touch<T>(LGM)) {
     do_touch = touch_target<C>(a.pf, sl, NyhP, Nx, mo2, x02);
-    if (do_touch) { const cx<T>* const heads[2] = {a.Gx + mo2, a.A + mo2}; touch.issue(heads, x02); }
+    if (do_touch) { const cx<T>* const heads[2] = {a.Gx + mo2, a.A + mo2}; Touch::issue(heads, x02, touch_pad<T, C, LD>(M)); }
   }
   __syncthreads();
   mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
+  if constexpr (col_touch<T>(LGM)) { if (do_touch) Touch::drain(); }
   half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);
-  if constexpr (col_touch<T>(LGM)) { if (do_touch) touch.keep(); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   __syncthreads();
   cx<T> yv[R];
   mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, yv);
-  TouchTiles<T, NT, LGM, C, col_touch<T>(LGM) ? 1 : 0> touch;
+  using Touch = TouchTiles<T, NT, LGM, C, 1>;
   size_t mo2 = 0; int x02 = 0;
   bool do_touch = false;
   if constexpr (col_touch<T>(LGM)) {
@@ -362,17 +367,17 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
 #pragma unroll
     for (int i = 0; i < R; ++i) { px[i] = pmul(px[i], yv[i]); py[i] = pmul(py[i], yv[i]); }
     do_touch = touch_target<C>(a.pf, sl, NyhP, Nx, mo2, x02);
-    if (do_touch) { const cx<T>* const heads[1] = {a.H + mo2}; touch.issue(heads, x02); }
+    if (do_touch) { const cx<T>* const heads[1] = {a.H + mo2}; Touch::issue(heads, x02, touch_pad<T, C, LD>(M)); }
   }
   __syncthreads();
   if constexpr (col_touch<T>(LGM)) npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = px[i]; y = py[i]; });
   else npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], yv[i]); y = pmul(py[i], yv[i]); });
+  if constexpr (col_touch<T>(LGM)) { if (do_touch) Touch::drain(); }
   cx<T>* Wx = tile_base(a.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(a.Wy + moff, x0, NyhP);
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
     const unsigned gi = tile_off<C>(k, c, x0, NyhP);
     handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, lyr[i]));
   });
-  if constexpr (col_touch<T>(LGM)) { if (do_touch) touch.keep(); }
 }
 
 // Adjoint flow, row kernel:  k = i*lx*fft_x(Wx) + fft_x(Wy')  -> RK update of the Fourier state (F layout)
@@ -594,12 +599,12 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
     fn[i] = rk_update(a.rk, kv, y0, acc);
     if (a.rk.stage == 4) at32(y0p, e) = y0; else at32(accp, e) = acc;
   }
-  TouchTiles<T, NT, LGM, C, col_touch<T>(LGM) ? 3 : 0> touch;
+  using Touch = TouchTiles<T, NT, LGM, C, 3>;
   size_t mo2 = 0; int x02 = 0;
   bool do_touch = false;
   if constexpr (col_touch<T>(LGM)) {
     do_touch = touch_target<C>(d.pf, sl, NyhP, Nx, mo2, x02);
-    if (do_touch) { const cx<T>* const heads[3] = {a.Gx + mo2, a.A + mo2, d.H + mo2}; touch.issue(heads, x02); }
+    if (do_touch) { const cx<T>* const heads[3] = {a.Gx + mo2, a.A + mo2, d.H + mo2}; Touch::issue(heads, x02, touch_pad<T, C, LD>(M)); }
   }
   __syncthreads();
   CMBL_STAMP(6);
@@ -607,6 +612,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   CMBL_STAMP(7);
   npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], ldf[i]); y = pmul(py[i], ldf[i]); });
   CMBL_STAMP(8);
+  if constexpr (col_touch<T>(LGM)) { if (do_touch && a.rk.last) Touch::drain(); }       // the last launch of a flow ends after the stores below
   {
     cx<T>* Wx = tile_base(d.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(d.Wy + moff, x0, NyhP);
     pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
@@ -615,15 +621,15 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
     });
   }
   CMBL_STAMP(9);
-  if (a.rk.last) { if constexpr (col_touch<T>(LGM)) { if (do_touch) touch.keep(); } CMBL_WSTAMP(15); return; }
+  if (a.rk.last) { CMBL_WSTAMP(15); return; }
   __syncthreads();
   // next-stage f : rfft_y
   mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
   CMBL_STAMP(11);
+  if constexpr (col_touch<T>(LGM)) { if (do_touch) Touch::drain(); }
   half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);
   CMBL_STAMP(12);
   CMBL_WSTAMP(15);
-  if constexpr (col_touch<T>(LGM)) { if (do_touch) touch.keep(); }
 }
 
 #ifdef CMBL_EXPERIMENT_COL_PIPELINE
