@@ -15,6 +15,7 @@
 #include "kernels_flow.hpp"
 #include "kernels_harm.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_ct.hpp"
 
 namespace cmbl {
 
@@ -91,6 +92,7 @@ struct CtxBase {
     int gen_separable = env_int("CMBL_GEN_SEPARABLE", 1) != 0;            // any-size path: separable stages
     int gen_prologue = env_int("CMBL_GEN_PROLOGUE", 1) != 0;              //   pointwise work in the fetch of the consuming transform
     int gen_xderiv_fused = env_int("CMBL_GEN_XDERIV_FUSED", 1) != 0;      //   d/dx pass as one launch
+    int gen_ct = env_int("CMBL_GEN_CT", 1) != 0;                          //   compile-time plans for the lengths of CMBL_CT_LIST (kernels_ct.hpp)
     // launch geometry that fills the chip on small maps (profiles/r05_ab_occupancy_tiles.txt): narrower column tiles while a launch has
     // fewer workgroups than `fill_target` (0: the rule in Ctx::tileY), shorter row groups while it has fewer than `row_fill_target`
     // (0: half the number of CUs -- 130 -> 258 row workgroups at 512^2 QU measured slower, 34 -> 130 at 128^2 17 % faster)
@@ -109,6 +111,7 @@ struct CtxBase {
     if (k == "gen_separable") return &opts.gen_separable;
     if (k == "gen_prologue") return &opts.gen_prologue;
     if (k == "gen_xderiv_fused") return &opts.gen_xderiv_fused;
+    if (k == "gen_ct") return &opts.gen_ct;
     if (k == "col_pipeline") return &opts.col_pipeline;
     if (k == "col_prefetch") return &opts.col_prefetch;
     if (k == "occupancy_tiles") return &opts.occupancy_tiles;
@@ -274,7 +277,24 @@ struct Ctx : CtxBase {
     for (int k = 0; k < L; ++k) { const double a = -2.0 * M_PI * k / L; tw[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
     upload(ax.chirp, wc); upload(ax.bhat, bh); upload(ax.tw, tw);
   }
+  // lengths with a compile-time plan (kernels_ct.hpp): one wavefront per sequence, S = 64 bytes of sequences per workgroup
+  bool gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
+    a.N = ax.N; a.tw = ax.twN.template as<cx<T>>(); a.S = ct_S<T>();
+    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
+    int kind = ct_kind(a);
+#ifdef CMBL_STAMPS_CT
+    static const int stamp_kind = env_int("CMBL_CT_STAMP_KIND", -1);
+    if (kind + (a.lmul_mid ? 8 : 0) == stamp_kind) kind |= 256;
+#endif
+    switch (ax.N) {
+#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft<T, n>), grid, ct_lds<T>(n), stream, a, kind); return true;
+      CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+      default: return false;
+    }
+  }
   void gen_dft(const GenAxis& ax, GenDft<T> a, long slices) {
+    if (ax.plan.nf > 0 && opts.gen_ct && gen_dft_ct(ax, a, slices)) return;
     if (ax.plan.nf > 0) {
       a.N = ax.N; a.tw = ax.twN.template as<cx<T>>();
       // sequences per workgroup: enough of them for coalesced strided access, but not so many that the launch has fewer than a few

@@ -1,0 +1,398 @@
+// Any-size path, compile-time plans: batched 1-D DFTs of the lengths N = 2^a 3^b 5^c listed in CMBL_CT_LIST (the common survey patch
+// sides 3 * 2^k and 5 * 2^k, and the sizes of the reference-style tables: 360, 1000), as a drop-in for k_gen_dft_mr (kernels_generic.hpp)
+// behind the same GenDft argument block -- same element order in and out (natural), same fetch / store options, same results to rounding.
+//
+// What is different from the run-time-planned kernel (whose launches are ~1 TB/s: a fetch loop that exposes one memory latency per
+// element, five barrier-separated stages with run-time divisions, 45 % LDS bank conflicts; profiles/r04_anysize_stamps_and_ilp_rejected.txt):
+//   * the plan is a template parameter: power-of-two radices up to 16 first (register butterflies of fft_core.hpp, one-read stage
+//     twiddles), then the 3s and 5s, as a Stockham autosort network IN PLACE -- every index is a shift, a mask or a constant division;
+//   * ONE WAVEFRONT owns a sequence: a lane pulls all of its butterflies of a stage into registers and writes them back; LDS operations
+//     of a wave execute in order, so every read of a stage precedes every write of it and no workgroup barrier separates the stages
+//     (the WorkRows idea of the fused row kernels).  S = 64 bytes / sizeof(element) sequences per workgroup = as many wavefronts;
+//   * every thread issues ALL of its global loads (up to 12 elements with all their operands) before the first LDS store: one exposed
+//     memory latency per workgroup instead of one per element.  The fetch variants are separate straight-line instantiations (KIND)
+//     selected by one uniform switch at the top of the kernel;
+//   * padded LDS rows (fft_lds.hpp pad()), row stride = 8 (mod 32) slots so that the transposed side of a y pass spreads over the banks;
+//   * workgroups that are neighbours in the strided direction share 128-byte lines: they are mapped to the same XCD (xcd_tile).
+#pragma once
+#include "kernels_generic.hpp"
+
+#ifndef CMBL_CT_LIST
+#define CMBL_CT_LIST(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(640) X(720) X(768) X(960) X(1000) X(1280) X(1536)
+#endif
+
+namespace cmbl {
+
+constexpr int ct_count(int N, int p) { int c = 0; while (N % p == 0) { N /= p; ++c; } return c; }
+constexpr int ct_np2(int N) { return num_stages(ct_count(N, 2)); }                                   // power-of-two stages
+constexpr int ct_nstages(int N) { return ct_np2(N) + ct_count(N, 3) + ct_count(N, 5); }
+constexpr int ct_radix(int N, int i) {
+  if (i < ct_np2(N)) return 1 << stage_lg(ct_count(N, 2), i);
+  return i - ct_np2(N) < ct_count(N, 3) ? 3 : 5;
+}
+constexpr int ct_ns(int N, int i) { int ns = 1; for (int k = 0; k < i; ++k) ns *= ct_radix(N, k); return ns; }   // product of the earlier radices
+constexpr int ct_ld(int N) { return pad(N) + ((8 - pad(N) % 32) + 32) % 32; }                        // row stride, 8 (mod 32) slots
+template <typename T> constexpr int ct_S() { return 64 / (int)sizeof(cx<T>); }                       // sequences (= wavefronts) per workgroup
+template <typename T> constexpr size_t ct_lds(int N) { return ((size_t)(N / 2) + (size_t)ct_S<T>() * ct_ld(N)) * sizeof(cx<T>); }
+
+// fetch variants
+enum { CT_C = 0, CT_R1, CT_R2, CT_H1, CT_H2, CT_P1, CT_P2, CT_P3 };
+template <typename T> inline int ct_kind(const GenDft<T>& a) {
+  if (a.in_real) return a.pro.mode == 1 ? CT_P1 : a.pro.mode == 2 ? CT_P2 : a.pro.mode == 3 ? CT_P3 : (a.in2 ? CT_R2 : CT_R1);
+  if (a.herm) return a.in2 ? CT_H2 : CT_H1;
+  return CT_C;
+}
+
+// r-point butterflies on register values; output X_m is left at v[ct_loc<R>(m)]
+template <int R> constexpr int ct_loc(int m) { return R == 16 ? dft_loc<4>(m) : R == 8 ? dft_loc<3>(m) : m; }
+template <typename T, int R, typename V> __device__ __forceinline__ void ct_bfly(V (&v)[R]) {
+  if constexpr (R == 16) dft<T, 4, false>(v);
+  else if constexpr (R == 8) dft<T, 3, false>(v);
+  else if constexpr (R == 4) dft<T, 2, false>(v);
+  else if constexpr (R == 2) dft<T, 1, false>(v);
+  else if constexpr (R == 3) {
+    const V t = vadd(v[1], v[2]), m = vsub(v[0], vscale(t, T(0.5))), sd = vscale(vsub(v[1], v[2]), T(0.86602540378443864676));
+    v[0] = vadd(v[0], t); v[1] = vsubi(m, sd); v[2] = vaddi(m, sd);
+  } else {
+    static_assert(R == 5, "radices 2, 4, 8, 16, 3, 5");
+    constexpr T c1 = T(0.30901699437494742410), c2 = T(-0.80901699437494742410), s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);
+    const V t1 = vadd(v[1], v[4]), t2 = vadd(v[2], v[3]), t3 = vsub(v[1], v[4]), t4 = vsub(v[2], v[3]);
+    const V a1 = vadd(v[0], vadd(vscale(t1, c1), vscale(t2, c2))), a2 = vadd(v[0], vadd(vscale(t1, c2), vscale(t2, c1)));
+    const V b1 = vadd(vscale(t3, s1), vscale(t4, s2)), b2 = vsub(vscale(t3, s2), vscale(t4, s1));
+    v[0] = vadd(v[0], vadd(t1, t2));
+    v[1] = vsubi(a1, b1); v[4] = vaddi(a1, b1); v[2] = vsubi(a2, b2); v[3] = vaddi(a2, b2);
+  }
+}
+
+// W_N^i, i < N, from the table of the first half of the circle (N even): W^(i + N/2) = -W^i
+template <typename T, int N> __device__ __forceinline__ typename vreg<T>::type ct_tw(const cx<T>* __restrict__ tw, int i) {
+  const bool hi = i >= N / 2;
+  return vscale(vload(tw + (hi ? i - N / 2 : i)), hi ? T(-1) : T(1));
+}
+
+// Stage I of the plan of N on the sequence at s (one wavefront; lane = its lane id), in place:
+//   v[m] = X[j + m N/R] W_{Ns R}^{m k},  v <- DFT_R(v),  X[(j div Ns) Ns R + k + m Ns] = v[m]      (j < N/R, k = j mod Ns)
+template <typename T, int N, int I>
+__device__ __forceinline__ void ct_stage(cx<T>* __restrict__ s, const cx<T>* __restrict__ tw, int lane) {
+  using V = typename vreg<T>::type;
+  constexpr int R = ct_radix(N, I), Ns = ct_ns(N, I), nb = N / R, tstep = N / (Ns * R), B = (nb + 63) / 64;
+  V v[B][R];
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const int j0 = lane + 64 * b, j = (nb % 64 == 0 || j0 < nb) ? j0 : nb - 1;       // spare lanes re-read the last butterfly (and write nothing)
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[b][m] = vload(s + pad(j + m * nb));
+  }
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const int j = lane + 64 * b;
+    const int blk = j / Ns, k = j - blk * Ns;
+    if constexpr (Ns > 1) {
+      // External twiddles W^(m k tstep).  Radices 3 and 5: every one a table read.  Powers of two: W^1 and W^(4q) are table reads, the
+      // rest ONE product each (W^2 = W^1 W^1, W^3 = W^1 W^2, W^(4q+r) = W^(4q) W^r) -- the angle error of a power grows with the exponent
+      // when everything is derived from W^1 alone (15 roundings of W^1 in W^15: single-precision transforms 2-4 x less accurate than
+      // with table twiddles, measured at 768^2), and R/4 + 1 reads per butterfly are still far from R - 1.
+      V w[R];
+      const int kt = k * tstep;
+      if constexpr (R == 3 || R == 5) {
+#pragma unroll
+        for (int m = 1; m < R; ++m) w[m] = ct_tw<T, N>(tw, m * kt);
+      } else {
+        w[1] = vload(tw + kt);                                                        // kt < N / R
+        if constexpr (R >= 4) { w[2] = vmul(w[1], w[1]); w[3] = vmul(w[1], w[2]); }
+#pragma unroll
+        for (int q = 1; q < R / 4; ++q) {
+          w[4 * q] = ct_tw<T, N>(tw, 4 * q * kt);
+#pragma unroll
+          for (int r = 1; r < 4; ++r) w[4 * q + r] = vmul(w[4 * q], w[r]);
+        }
+      }
+#pragma unroll
+      for (int m = 1; m < R; ++m) v[b][m] = vmul(v[b][m], w[m]);
+    }
+    ct_bfly<T, R>(v[b]);
+    if (nb % 64 == 0 || j < nb) {
+#pragma unroll
+      for (int m = 0; m < R; ++m) vstore(s + pad(blk * (Ns * R) + k + m * Ns), v[b][ct_loc<R>(m)]);
+    }
+    // many values in flight: keep the compiler from interleaving the butterflies of a lane (their twiddles and temporaries would all
+    // be live at once: spills at 720 / 1000 / 1280 under the two-workgroups-per-CU register cap)
+    if constexpr (B * R > 24) __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+template <typename T, int N, int I = 0>
+__device__ __forceinline__ void ct_transform(cx<T>* __restrict__ s, const cx<T>* __restrict__ tw, int lane) {
+  if constexpr (I < ct_nstages(N)) {
+    ct_stage<T, N, I>(s, tw, lane);
+    ct_transform<T, N, I + 1>(s, tw, lane);
+  }
+}
+
+// ---- fetch: operands of CH elements into registers (load), then their values (value) ------------------------------------------------
+template <typename T, int CH> struct CtRegs { cx<T> u[CH], w[CH]; T r[7][CH]; };
+
+// element i of the chunk: sequence seq (clamped to a valid one by the caller), entry n < N.  Addresses are a wave-uniform base (the
+// slice) + ONE 32-bit element offset shared by all arrays of the element (at32, kernels_fft.hpp): no 64-bit vector arithmetic, one
+// address register per element in flight.
+template <typename T, int KIND, bool FLAG /*H: lmul_in given; P: p(t) from the cache*/, int CH>
+__device__ __forceinline__ void ct_load(CtRegs<T, CH>& g, int i, const GenDft<T>& a, size_t sl, int seq, int n) {
+  const size_t sb = sl * a.in_slice;
+  if constexpr (KIND == CT_C) g.u[i] = at32(reinterpret_cast<const cx<T>*>(a.in) + sb, (unsigned)seq * (unsigned)a.in_seq + (unsigned)n * (unsigned)a.in_elem);
+  else if constexpr (KIND == CT_R1 || KIND == CT_R2) {
+    const unsigned o = (unsigned)seq * (unsigned)a.in_seq + (unsigned)n * (unsigned)a.in_elem;
+    g.r[0][i] = at32(reinterpret_cast<const T*>(a.in) + sb, o);
+    if constexpr (KIND == CT_R2) g.r[1][i] = at32(reinterpret_cast<const T*>(a.in2) + sb, o);
+  } else if constexpr (KIND == CT_H1 || KIND == CT_H2) {
+    const int m = n < a.nin ? n : a.N - n;
+    const unsigned o = (unsigned)seq * (unsigned)a.in_seq + (unsigned)m * (unsigned)a.in_elem;
+    g.u[i] = at32(reinterpret_cast<const cx<T>*>(a.in) + sb, o);
+    if constexpr (KIND == CT_H2) g.w[i] = at32(reinterpret_cast<const cx<T>*>(a.in2) + sb, o);
+    if constexpr (FLAG) g.r[0][i] = at32(a.lmul_in, (unsigned)m);
+  } else {
+    const GenPro<T>& e = a.pro;                                          // real maps [slice][npix]: in_slice == npix
+    const unsigned o = (unsigned)seq * (unsigned)a.in_seq + (unsigned)n * (unsigned)a.in_elem;
+    const size_t pb = (size_t)(e.ph.Bphi == 1 ? 0 : sl / e.P) * e.npix;
+    if constexpr (FLAG) { g.r[0][i] = at32(e.ph.pcx + pb, o); g.r[1][i] = at32(e.ph.pcy + pb, o); }
+    else {
+      g.r[0][i] = at32(e.ph.gx + pb, o); g.r[1][i] = at32(e.ph.gy + pb, o);
+      g.u[i] = mk<T>(at32(e.ph.hxx + pb, o), at32(e.ph.hyx + pb, o)); g.w[i].x = at32(e.ph.hyy + pb, o);
+    }
+    if constexpr (KIND == CT_P2 || KIND == CT_P3) g.r[2][i] = at32(e.Ldf + sb, o);
+    if constexpr (KIND != CT_P3) {
+      g.r[3][i] = at32(e.gx + sb, o); g.r[4][i] = at32(e.gy + sb, o); g.r[5][i] = at32(e.y0 + sb, o);
+      g.r[6][i] = at32(e.acc + sb, o);                                   // (not read by stage 1: whatever the buffer holds)
+    }
+  }
+}
+// Hermitian extension with FFTW's c2r rule (gen_herm)
+template <typename T> __device__ __forceinline__ cx<T> ct_herm(cx<T> v, int n, int nin, int N) {
+  if (n == 0 || 2 * n == N) v.y = T(0);
+  return n < nin ? v : conj(v);
+}
+// The pointwise kinds also produce what the stage writes back to memory (so[0..1]: the delta-phi products, so[2]: the new y0 / acc); the
+// caller stores them AFTER its last load has returned -- loads and stores share one in-order counter (vmcnt), so a store between two
+// chunks of loads makes the second chunk wait for the store's acknowledgement (measured: 14k cycles of fetch instead of 4k).
+template <typename T, int KIND, bool FLAG, int CH>
+__device__ __forceinline__ cx<T> ct_value(const CtRegs<T, CH>& g, int i, const GenDft<T>& a, int n, T (&so)[3]) {
+  cx<T> v;
+  if constexpr (KIND == CT_C) v = g.u[i];
+  else if constexpr (KIND == CT_R1) v = mk<T>(g.r[0][i], T(0));
+  else if constexpr (KIND == CT_R2) v = mk<T>(g.r[0][i], g.r[1][i]);
+  else if constexpr (KIND == CT_H1) {
+    v = g.u[i];
+    if constexpr (FLAG) v = mul_il(v, g.r[0][i]);
+    v = ct_herm(v, n, a.nin, a.N);
+  } else if constexpr (KIND == CT_H2) {
+    cx<T> w = g.w[i];
+    if constexpr (FLAG) w = mul_il(w, g.r[0][i]);
+    const cx<T> u = ct_herm(g.u[i], n, a.nin, a.N);
+    w = ct_herm(w, n, a.nin, a.N);
+    v = mk<T>(u.x - w.y, u.y + w.x);
+  } else {
+    const GenPro<T>& e = a.pro;
+    T px, py;
+    if constexpr (FLAG) { px = g.r[0][i]; py = g.r[1][i]; }
+    else { T m11, m12, m22; flow_pm(e.rk.t, g.r[0][i], g.r[1][i], g.u[i].x, g.u[i].y, g.w[i].x, px, py, m11, m12, m22); }
+    if constexpr (KIND == CT_P3) v = mk<T>(px * g.r[2][i], py * g.r[2][i]);
+    else {
+      const T ax = g.r[3][i], ay = g.r[4][i];
+      if constexpr (KIND == CT_P2) { so[0] = g.r[2][i] * ax; so[1] = g.r[2][i] * ay; }
+      const T k = px * ax + py * ay;
+      T y = g.r[5][i], ac = e.rk.stage == 1 ? T(0) : g.r[6][i];
+      const T nxt = rk_update(e.rk, k, y, ac);
+      so[2] = e.rk.stage == 4 ? y : ac;
+      v = mk<T>(nxt, T(0));
+    }
+  }
+  return a.inverse ? conj(v) : v;
+}
+
+// elements a thread requests before it consumes the first: as many as fit a budget of operand registers (in units of T)
+#ifndef CMBL_CT_FETCH_WORDS
+#define CMBL_CT_FETCH_WORDS 64
+#endif
+constexpr int ct_words(int kind, bool flag) {
+  return kind == CT_C ? 2 : kind == CT_R1 ? 1 : kind == CT_R2 ? 2 : kind == CT_H1 ? 2 + flag : kind == CT_H2 ? 4 + flag
+       : (flag ? 2 : 5) + (kind == CT_P1 ? 4 : kind == CT_P2 ? 5 : 1);
+}
+constexpr int ct_chunk(int E, int kind, bool flag) {
+  int ch = CMBL_CT_FETCH_WORDS / ct_words(kind, flag);
+  ch = ch < 2 ? 2 : ch;
+  ch = ch > E ? E : ch;
+  const int nch = (E + ch - 1) / ch;
+  return (E + nch - 1) / nch;
+}
+template <typename T, int N, int KIND, bool FLAG>
+__device__ __forceinline__ void ct_fetch(const GenDft<T>& a, cx<T>* __restrict__ s, size_t sl, int seq0, bool by_seq) {
+  constexpr int S = ct_S<T>(), LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), E = (N + 63) / 64, CH = ct_chunk(E, KIND, FLAG), NCH = (E + CH - 1) / CH;
+  const int tid = threadIdx.x;
+  constexpr bool WB = KIND == CT_P1 || KIND == CT_P2;                    // kinds that write back to memory
+  constexpr int WBN = E <= 16 ? NCH : 1;                                 // chunks whose write-backs are held back (all of them up to 16 elements per thread)
+  T so[WB ? WBN * CH : 1][3];
+  auto write_back = [&](int j0, int cnt_base) {                          // elements j0 .. j0 + WBN * CH - 1 of the thread
+    if constexpr (WB) {
+      const GenPro<T>& e = a.pro;
+      const size_t sb = sl * a.in_slice;
+      T* const dst = (e.rk.stage == 4 ? e.y0 : e.acc) + sb;
+#pragma unroll
+      for (int jj = 0; jj < WBN * CH; ++jj) {
+        const int j = j0 + jj, q = tid + j * NT, sq = by_seq ? (q & (S - 1)) : (tid >> 6), n0 = by_seq ? (q >> LGS) : ((tid & 63) + 64 * j);
+        if (n0 < N && j < E && seq0 + sq < a.nseq) {                     // the element exists: only then anything is written
+          const unsigned o = (unsigned)(seq0 + sq) * (unsigned)a.in_seq + (unsigned)n0 * (unsigned)a.in_elem;
+          if constexpr (KIND == CT_P2) { at32(e.w1p + sb, o) = so[jj][0]; at32(e.w2p + sb, o) = so[jj][1]; }
+          at32(dst, o) = so[jj][2];
+        }
+      }
+    }
+    (void)cnt_base;
+  };
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    CtRegs<T, CH> g;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      // transposed side: consecutive threads walk the S sequences at one n (S elements = 64 contiguous bytes); else a wavefront walks its own sequence
+      const int q = tid + (c * CH + i) * NT, sq = by_seq ? (q & (S - 1)) : (tid >> 6), n0 = by_seq ? (q >> LGS) : ((tid & 63) + 64 * (c * CH + i));
+      const int n = n0 < N ? n0 : N - 1, seq = min(seq0 + sq, a.nseq - 1);
+      ct_load<T, KIND, FLAG, CH>(g, i, a, sl, seq, n);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int q = tid + (c * CH + i) * NT, sq = by_seq ? (q & (S - 1)) : (tid >> 6), n0 = by_seq ? (q >> LGS) : ((tid & 63) + 64 * (c * CH + i));
+      const int n = n0 < N ? n0 : N - 1;
+      const cx<T> v = ct_value<T, KIND, FLAG, CH>(g, i, a, n, so[WB ? (WBN > 1 ? c * CH + i : i) : 0]);
+      if (n0 < N && (c * CH + i) < E) s[sq * LD + pad(n0)] = v;
+    }
+    if constexpr (WB && WBN == 1) write_back(c * CH, 0);
+  }
+  if constexpr (WB && WBN > 1) write_back(0, 0);
+}
+
+// gen_put (kernels_generic.hpp) with the addressing of the fetch: wave-uniform slice base in scalar registers + one 32-bit element
+// offset (the 64-bit multiplies of a general index cost the store phase 4.4k cycles per launch: 12 elements per thread)
+template <int BYTES> __device__ __forceinline__ void ct_store(void* sbase, unsigned byte_off, const void* v, bool wt) {
+#if CMBL_WT_GEN
+  if (wt) {
+    if constexpr (BYTES == 16) { const wt_f4 d = *reinterpret_cast<const wt_f4*>(v); asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(byte_off), "v"(d), "s"(sbase) : "memory"); }
+    else if constexpr (BYTES == 8) { const wt_f2 d = *reinterpret_cast<const wt_f2*>(v); asm volatile("global_store_dwordx2 %0, %1, %2 sc1" : : "v"(byte_off), "v"(d), "s"(sbase) : "memory"); }
+    else { const float d = *reinterpret_cast<const float*>(v); asm volatile("global_store_dword %0, %1, %2 sc1" : : "v"(byte_off), "v"(d), "s"(sbase) : "memory"); }
+    return;
+  }
+#endif
+  char* q = reinterpret_cast<char*>(sbase) + byte_off;
+  if constexpr (BYTES == 16) *reinterpret_cast<wt_f4*>(q) = *reinterpret_cast<const wt_f4*>(v);
+  else if constexpr (BYTES == 8) *reinterpret_cast<wt_f2*>(q) = *reinterpret_cast<const wt_f2*>(v);
+  else *reinterpret_cast<float*>(q) = *reinterpret_cast<const float*>(v);
+}
+template <typename T>
+__device__ __forceinline__ void ct_put(const GenDft<T>& a, size_t sl, int seq, int k, cx<T> y, cx<T> yr) {
+  if (a.inverse) y = conj(y);
+  const size_t sb = sl * a.out_slice;
+  const unsigned o = (unsigned)seq * (unsigned)a.out_seq + (unsigned)k * (unsigned)a.out_elem;
+  const bool wt = wt_line<T>(a.N);
+  if (a.out_real) {
+    const T v1 = a.scale * y.x;
+    ct_store<(int)sizeof(T)>(reinterpret_cast<T*>(a.out) + sb, o * (unsigned)sizeof(T), &v1, wt);
+    if (a.out2) { const T v2 = a.scale2 * y.y; ct_store<(int)sizeof(T)>(reinterpret_cast<T*>(a.out2) + sb, o * (unsigned)sizeof(T), &v2, wt); }
+    return;
+  }
+  if (a.in_real && a.in2) {                                             // split the transform of in + i in2
+    const cx<T> c = conj(yr);
+    const cx<T> x1 = mk<T>(T(0.5) * (y.x + c.x), T(0.5) * (y.y + c.y)), d = mk<T>(T(0.5) * (y.x - c.x), T(0.5) * (y.y - c.y));
+    const cx<T> o1 = mk<T>(a.scale * x1.x, a.scale * x1.y), o2 = mk<T>(a.scale2 * d.y, -a.scale2 * d.x);              // d / i
+    ct_store<(int)sizeof(cx<T>)>(reinterpret_cast<cx<T>*>(a.out) + sb, o * (unsigned)sizeof(cx<T>), &o1, wt);
+    ct_store<(int)sizeof(cx<T>)>(reinterpret_cast<cx<T>*>(a.out2) + sb, o * (unsigned)sizeof(cx<T>), &o2, wt);
+    return;
+  }
+  if (a.lmul_out) y = mul_il(y, a.lmul_out[k]);
+  const cx<T> o1 = mk<T>(a.scale * y.x, a.scale * y.y);
+  ct_store<(int)sizeof(cx<T>)>(reinterpret_cast<cx<T>*>(a.out) + sb, o * (unsigned)sizeof(cx<T>), &o1, wt);
+}
+
+// debug builds (-DCMBL_STAMPS -DCMBL_STAMPS_ROWS -DCMBL_STAMPS_CT): phase timestamps of the launches whose kind (+ 8 for the d/dx pass)
+// equals CMBL_CT_STAMP_KIND, read back with cmbl_debug_stamps (tools/gpu_stamps_ct.py)
+#ifdef CMBL_STAMPS_CT
+#define CMBL_CT_STAMP(i) do { if (stamp && threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = (i) >= 14 ? wall_clock64() : clock64(); } while (0)
+#else
+#define CMBL_CT_STAMP(i) do {} while (0)
+#endif
+
+template <typename T> constexpr int ct_min_waves() { return sizeof(T) == 4 ? 4 : 2; }       // two workgroups per CU
+
+template <typename T, int N>
+__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft(GenDft<T> a, int kind) {
+  constexpr int S = ct_S<T>(), LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* s = tw + NTW;
+  const bool in_by_seq = a.in_elem != 1, out_by_seq = a.out_elem != 1;
+  const int seq0 = ((in_by_seq || out_by_seq) ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * S;
+  const size_t sl = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef CMBL_STAMPS_CT
+  const bool stamp = (kind >> 8) != 0;
+  kind &= 255;
+#endif
+  CMBL_CT_STAMP(14); CMBL_CT_STAMP(0);
+  TwStage<T, NT, NTW> twr;
+  twr.issue(a.tw);
+  switch (kind) {                                                        // uniform: one straight-line fetch per variant
+    case CT_C: ct_fetch<T, N, CT_C, false>(a, s, sl, seq0, in_by_seq); break;
+    case CT_R1: ct_fetch<T, N, CT_R1, false>(a, s, sl, seq0, in_by_seq); break;
+    case CT_R2: ct_fetch<T, N, CT_R2, false>(a, s, sl, seq0, in_by_seq); break;
+    case CT_H1: if (a.lmul_in) ct_fetch<T, N, CT_H1, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_H1, false>(a, s, sl, seq0, in_by_seq); break;
+    case CT_H2: if (a.lmul_in) ct_fetch<T, N, CT_H2, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_H2, false>(a, s, sl, seq0, in_by_seq); break;
+    case CT_P1: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P1, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P1, false>(a, s, sl, seq0, in_by_seq); break;
+    case CT_P2: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P2, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P2, false>(a, s, sl, seq0, in_by_seq); break;
+    default: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P3, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P3, false>(a, s, sl, seq0, in_by_seq); break;
+  }
+  twr.commit(tw);
+  CMBL_CT_STAMP(1);
+  __syncthreads();
+  CMBL_CT_STAMP(2);
+  cx<T>* row = s + wave * LD;
+  const bool live = seq0 + wave < a.nseq;                                // wave-uniform
+  if (live) {
+    ct_transform<T, N>(row, tw, lane);
+    CMBL_CT_STAMP(3);
+    if (a.lmul_mid) {                                                    // X <- conj(i l X), forward again: the inverse transform is conj(forward(conj .))
+#pragma unroll
+      for (int i = 0; i < (N + 63) / 64; ++i) {
+        const int k = lane + 64 * i;
+        if (N % 64 == 0 || k < N) row[pad(k)] = conj(mul_il(row[pad(k)], a.lmul_mid[k]));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      ct_transform<T, N>(row, tw, lane);
+    }
+  }
+  CMBL_CT_STAMP(4);
+  __syncthreads();
+  CMBL_CT_STAMP(5);
+  // Stores: all LDS reads of the thread first, then the global stores (a read-store loop waits for LDS once per element: 4.5k cycles
+  // per launch measured, against 1.5k)
+  const bool mid = a.lmul_mid != nullptr, split = a.in_real && a.in2;
+  constexpr int E = (N + 63) / 64, NPC = (E + 11) / 12, PCH = (E + NPC - 1) / NPC;
+#pragma unroll
+  for (int c = 0; c < NPC; ++c) {
+    cx<T> y[PCH], yr[PCH];
+#pragma unroll
+    for (int ii = 0; ii < PCH; ++ii) {
+      const int i = c * PCH + ii, k0 = out_by_seq ? ((threadIdx.x + i * NT) >> LGS) : (lane + 64 * i), k = min(k0, a.nout - 1);
+      const cx<T>* p = s + (out_by_seq ? ((threadIdx.x + i * NT) & (S - 1)) : wave) * LD;
+      y[ii] = p[pad(k)];
+      yr[ii] = p[pad(split && k ? N - k : 0)];                           // Z[N - k]: only the pair split reads it
+    }
+#pragma unroll
+    for (int ii = 0; ii < PCH; ++ii) {
+      const int i = c * PCH + ii, k = out_by_seq ? ((threadIdx.x + i * NT) >> LGS) : (lane + 64 * i);
+      const int seq = seq0 + (out_by_seq ? ((threadIdx.x + i * NT) & (S - 1)) : wave);
+      if (i < E && k < a.nout && seq < a.nseq) ct_put(a, sl, seq, k, mid ? conj(y[ii]) : y[ii], yr[ii]);
+    }
+  }
+  CMBL_CT_STAMP(6); CMBL_CT_STAMP(15);
+}
+
+}  // namespace cmbl
