@@ -92,6 +92,8 @@ struct CtxBase {
     int gen_separable = env_int("CMBL_GEN_SEPARABLE", 1) != 0;            // any-size path: separable stages
     int gen_prologue = env_int("CMBL_GEN_PROLOGUE", 1) != 0;              //   pointwise work in the fetch of the consuming transform
     int gen_xderiv_fused = env_int("CMBL_GEN_XDERIV_FUSED", 1) != 0;      //   d/dx pass as one launch
+    int gen_slice_streams = env_int("CMBL_GEN_SLICE_STREAMS", 1) != 0;    //   one launch chain per group of slices (Flow::gen_groups)
+    int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 1 << 21);   //   ... from this many pixels on (a quarter of it for >= 3 slices)
     int gen_ct = env_int("CMBL_GEN_CT", 1) != 0;                          //   compile-time plans for the lengths of CMBL_CT_LIST (kernels_ct.hpp)
     // launch geometry that fills the chip on small maps (profiles/r05_ab_occupancy_tiles.txt): narrower column tiles while a launch has
     // fewer workgroups than `fill_target` (0: the rule in Ctx::tileY), shorter row groups while it has fewer than `row_fill_target`
@@ -112,6 +114,8 @@ struct CtxBase {
     if (k == "gen_prologue") return &opts.gen_prologue;
     if (k == "gen_xderiv_fused") return &opts.gen_xderiv_fused;
     if (k == "gen_ct") return &opts.gen_ct;
+    if (k == "gen_slice_streams") return &opts.gen_slice_streams;
+    if (k == "gen_streams_min_pix") return &opts.gen_streams_min_pix;
     if (k == "col_pipeline") return &opts.col_pipeline;
     if (k == "col_prefetch") return &opts.col_prefetch;
     if (k == "occupancy_tiles") return &opts.occupancy_tiles;
@@ -277,6 +281,16 @@ struct Ctx : CtxBase {
     for (int k = 0; k < L; ++k) { const double a = -2.0 * M_PI * k / L; tw[k] = mk<T>((T)std::cos(a), (T)std::sin(a)); }
     upload(ax.chirp, wc); upload(ax.bhat, bh); upload(ax.tw, tw);
   }
+  // Slice window of the any-size launches (set by Flow::GenWindow around the launches of one group of slices, which then go to that
+  // group's stream): every transform launch covers slices [gw0, gw0 + gwn) of the gwall slices of the flow -- of each part of its batch
+  // when that is a multiple of gwall (pair launches).  gwn < 0: no window.
+  long gw0 = 0, gwn = -1, gwall = 0;
+  long gen_window(GenDft<T>& a, long slices) const {
+    if (gwn < 0) return slices;
+    CMBL_REQUIRE(gwall > 0 && slices % gwall == 0, ERR_STATE, "any-size launch outside its slice window");
+    a.sl0 = (int)gw0; a.sln = (int)gwn; a.slstride = (int)gwall;
+    return slices / gwall * gwn;
+  }
   // lengths with a compile-time plan (kernels_ct.hpp): one wavefront per sequence, S = 64 bytes of sequences per workgroup
   bool gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
     a.N = ax.N; a.tw = ax.twN.template as<cx<T>>(); a.S = ct_S<T>();
@@ -294,6 +308,7 @@ struct Ctx : CtxBase {
     }
   }
   void gen_dft(const GenAxis& ax, GenDft<T> a, long slices) {
+    slices = gen_window(a, slices);
     if (ax.plan.nf > 0 && opts.gen_ct && gen_dft_ct(ax, a, slices)) return;
     if (ax.plan.nf > 0) {
       a.N = ax.N; a.tw = ax.twN.template as<cx<T>>();
@@ -939,8 +954,31 @@ struct Flow {
   // ---- any-size path: the reference's pass structure on k_gen_dft + pointwise kernels (kernels_generic.hpp) ----------------------
   // (x, y) pairs live in the two halves of ONE buffer so that both members go through a transform in one launch
   DevBuf gF, gFxy, gmxy, gms, gYs, gLdf, gWxy;
-  dim3 pgrid(long n, long slices) const { return dim3((unsigned)std::min<long>((n + NTP - 1) / NTP, 4096), (unsigned)slices); }
-  dim3 fgrid(long slices) const { return dim3((unsigned)((c->plane() + NTP - 1) / NTP), (unsigned)slices); }
+  // (pointwise launches of a stage: over the slice window when one is set)
+  long wsl(long slices) const { return c->gwn >= 0 ? c->gwn : slices; }
+  int wsl0() const { return c->gwn >= 0 ? (int)c->gw0 : 0; }
+  dim3 pgrid(long n, long slices) const { return dim3((unsigned)std::min<long>((n + NTP - 1) / NTP, 4096), (unsigned)wsl(slices)); }
+  dim3 fgrid(long slices) const { return dim3((unsigned)((c->plane() + NTP - 1) / NTP), (unsigned)wsl(slices)); }
+  // One launch chain per group of slices for the flows of the any-size path, like the fused flows (groups()): a launch there is one
+  // residency round of workgroups that all fetch, then all transform, then all store (k_ct_dft stamps: each phase alone runs at
+  // 3 - 5 TB/s and the memory system idles during the transforms), so two chains side by side fill each other's gaps.
+  // Measured (profiles/r05_anysize_times.txt): 1536^2 QU -17 %, 768^2 and 1000^2 T+QU -5 .. -7 %, 1000^2 QU +2 %, 768^2 QU +5 %, 360^2 +4 %,
+  // 96 x 160 +20 % -- below ~2^21 pixels per launch the kernels last 6 - 9 us and the host (~5 us per launch) cannot feed two chains, so the
+  // chains are split from 2^21 pixels on, three or more slices from 2^19.
+  int gen_groups(long slices) const {
+    if (!c->opts.gen_slice_streams || !gen_sep() || c->npix() * (slices >= 3 ? 4 : 1) < c->opts.gen_streams_min_pix) return 1;
+    for (int k = (int)std::min<long>(std::min(max_groups, c->opts.slice_streams), slices); k > 1; --k) if (slices % k == 0) return k;
+    return 1;
+  }
+  struct GenWindow {                                                    // RAII: the launches of group g of K go to its stream
+    Ctx<T>* c; hipStream_t main;
+    GenWindow(Flow* f, int g, int K, long slices) : c(f->c), main(f->c->stream) {
+      if (K <= 1) return;
+      c->gwall = slices; c->gwn = slices / K; c->gw0 = g * (slices / K);
+      c->stream = g == 0 ? main : f->sub[g - 1];
+    }
+    ~GenWindow() { c->stream = main; c->gwn = -1; c->gw0 = 0; c->gwall = 0; }
+  };
   // (gmx, gmy) = grad of the stage input f_s from its y transform A = rfft_y(f_s) (mixed layout), using the separability the fused
   // kernels use: d/dy needs the y transform alone (the i*ly multiply commutes with the x transforms, which then cancel), d/dx one
   // forward / i*lx / inverse x pass; ONE complex inverse y transform returns both real maps (pair c2r).  Equal to the reference's
@@ -978,7 +1016,7 @@ struct Flow {
       c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
     } else c->rfft2_F(Wxy, gFxy.as<cx<T>>(), 2 * slices);
     CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
-                c->ly.template as<T>(), c->Nx, Y0, Yacc_, Ys, rk, pl);
+                c->ly.template as<T>(), c->Nx, Y0, Yacc_, Ys, rk, pl, wsl0());
   }
   void gen_flow_map(const T* in, T* out, int P, int B, bool inverse) {
     const long slices = (long)P * B, np = c->npix(), pl = c->plane();
@@ -988,21 +1026,27 @@ struct Flow {
     const double t0 = inverse ? 1.0 : 0.0, h = (inverse ? -1.0 : 1.0) / n;
     const bool sep = gen_sep();
     if (sep) { gA.ensure(sizeof(cx<T>) * slices * pl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
+    const int K = gen_groups(slices);
+    fork(K);
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
         const bool last = step == n - 1 && stage == 4;
         const RKCoef<T> rk = coef(step, stage, t0, h, last);
-        if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);
-        if (sep && !last && gen_pro()) {                                     // velocity + RK bookkeeping in the fetch of the next stage's y transform
-          GenPro<T> e{};
-          e.mode = 1; e.ph = ph(rk.t); e.rk = rk; e.gx = gmxy.as<T>(); e.gy = gmxy.as<T>() + slices * np; e.y0 = out; e.acc = acc.as<T>(); e.npix = np; e.P = P;
-          c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices, nullptr, nullptr, &e);
-          continue;
+        for (int g = 0; g < K; ++g) {
+          GenWindow w(this, g, K, slices);
+          if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);
+          if (sep && !last && gen_pro()) {                                   // velocity + RK bookkeeping in the fetch of the next stage's y transform
+            GenPro<T> e{};
+            e.mode = 1; e.ph = ph(rk.t); e.rk = rk; e.gx = gmxy.as<T>(); e.gy = gmxy.as<T>() + slices * np; e.y0 = out; e.acc = acc.as<T>(); e.npix = np; e.P = P;
+            c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices, nullptr, nullptr, &e);
+            continue;
+          }
+          CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_vel_rk<T>), pgrid(np, slices), 0, c->stream, gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t), out, acc.as<T>(),
+                      gms.as<T>(), rk, np, P, wsl0());
+          if (sep && !last) c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices);
         }
-        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_vel_rk<T>), pgrid(np, slices), 0, c->stream, gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t), out, acc.as<T>(),
-                    gms.as<T>(), rk, np, P);
-        if (sep && !last) c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices);
       }
+    join(K);
   }
   void gen_flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse) {
     const long slices = (long)P * B, pl = c->plane(), np = c->npix();
@@ -1011,13 +1055,20 @@ struct Flow {
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     CMBL_HIP(hipMemcpyAsync(gYs.p, out, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
+    gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gW2.ensure(sizeof(cx<T>) * 2 * slices * pl); (void)c->mixed_scratch(slices);   // before the chains fork
+    const int K = gen_groups(slices);
+    fork(K);
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
         const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
-        c->F_to_map(gYs.as<cx<T>>(), gms.as<T>(), slices);
-        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_pmul<T>), pgrid(np, slices), 0, c->stream, gms.as<T>(), ph(rk.t), rk.t, gmxy.as<T>(), gmxy.as<T>() + slices * np, np, P);
-        gen_adj_update(gmxy.as<T>(), out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
+        for (int g = 0; g < K; ++g) {
+          GenWindow w(this, g, K, slices);
+          c->F_to_map(gYs.as<cx<T>>(), gms.as<T>(), slices);
+          CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_pmul<T>), pgrid(np, slices), 0, c->stream, gms.as<T>(), ph(rk.t), rk.t, gmxy.as<T>(), gmxy.as<T>() + slices * np, np, P, wsl0());
+          gen_adj_update(gmxy.as<T>(), out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
+        }
       }
+    join(K);
   }
   void gen_flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk) {
     const long slices = (long)P * B, pl = c->plane(), np = c->npix();
@@ -1033,32 +1084,40 @@ struct Flow {
     const bool sep = gen_sep();
     if (sep) { gA.ensure(sizeof(cx<T>) * slices * pl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
     tc_host.resize(2 * (size_t)nst);
+    gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); gmxy.ensure(sizeof(T) * 2 * slices * np);   // before the chains fork
+    gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gW2.ensure(sizeof(cx<T>) * 2 * slices * pl); (void)c->mixed_scratch(slices);
+    const int K = gen_groups(slices);
+    fork(K);
     int it = 0;
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage, ++it) {
         const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
         tc_host[2 * it] = rk.t;
         tc_host[2 * it + 1] = (T)((stage == 1 || stage == 4 ? 1.0 : 2.0) * h / 6);
-        c->F_to_map(gYs.as<cx<T>>(), gLdf.as<T>(), slices);                   // L(df)
-        if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);   // grad f -> gmxy
         T* w1p = Wst.as<T>() + (size_t)(2 * it) * slices * np;
-        if (sep && !rk.last && gen_pro()) {
-          // the stage's pointwise work rides in the fetches of the two y transforms that consume it: f part + products -> rfft_y(f_{s+1});
-          // (p_x L(df), p_y L(df)) -> the pair r2c of the delta-f velocity
-          GenPro<T> e{};
-          e.ph = ph(rk.t); e.rk = rk; e.gx = gmxy.as<T>(); e.gy = gmxy.as<T>() + slices * np; e.Ldf = gLdf.as<T>(); e.y0 = f; e.acc = acc.as<T>();
-          e.w1p = w1p; e.w2p = w1p + (size_t)slices * np; e.npix = np; e.P = P;
-          e.mode = 2;
-          c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices, nullptr, nullptr, &e);
-          e.mode = 3;
-          gen_adj_update(nullptr, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices, &e);
-          continue;
+        for (int g = 0; g < K; ++g) {
+          GenWindow w(this, g, K, slices);
+          c->F_to_map(gYs.as<cx<T>>(), gLdf.as<T>(), slices);                 // L(df)
+          if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);   // grad f -> gmxy
+          if (sep && !rk.last && gen_pro()) {
+            // the stage's pointwise work rides in the fetches of the two y transforms that consume it: f part + products -> rfft_y(f_{s+1});
+            // (p_x L(df), p_y L(df)) -> the pair r2c of the delta-f velocity
+            GenPro<T> e{};
+            e.ph = ph(rk.t); e.rk = rk; e.gx = gmxy.as<T>(); e.gy = gmxy.as<T>() + slices * np; e.Ldf = gLdf.as<T>(); e.y0 = f; e.acc = acc.as<T>();
+            e.w1p = w1p; e.w2p = w1p + (size_t)slices * np; e.npix = np; e.P = P;
+            e.mode = 2;
+            c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices, nullptr, nullptr, &e);
+            e.mode = 3;
+            gen_adj_update(nullptr, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices, &e);
+            continue;
+          }
+          CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_delta<T>), pgrid(np, slices), 0, c->stream, gLdf.as<T>(), gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t),
+                      gWxy.as<T>(), gWxy.as<T>() + slices * np, w1p, w1p + (size_t)slices * np, f, acc.as<T>(), gms.as<T>(), rk, np, P, wsl0());
+          if (sep && !rk.last) c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices);
+          gen_adj_update(gWxy.as<T>(), df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
         }
-        CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_delta<T>), pgrid(np, slices), 0, c->stream, gLdf.as<T>(), gmxy.as<T>(), gmxy.as<T>() + slices * np, ph(rk.t),
-                    gWxy.as<T>(), gWxy.as<T>() + slices * np, w1p, w1p + (size_t)slices * np, f, acc.as<T>(), gms.as<T>(), rk, np, P);
-        if (sep && !rk.last) c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices);
-        gen_adj_update(gWxy.as<T>(), df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);
       }
+    join(K);
     dphi_finish(dphi, P, B, nst, alias_quirk);
   }
   // delta-phi: quadrature over the stored stages, five real transforms, the l-multipliers (shared by both paths)

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft(Ge
   cx<T>* s = tw + NTW;
   const bool in_by_seq = a.in_elem != 1, out_by_seq = a.out_elem != 1;
   const int seq0 = ((in_by_seq || out_by_seq) ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * S;
-  const size_t sl = blockIdx.y;
+  const size_t sl = gen_slice(a);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef CMBL_STAMPS_CT
   const bool stamp = (kind >> 8) != 0;

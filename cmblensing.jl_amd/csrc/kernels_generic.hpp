@@ -78,7 +78,14 @@ template <typename T> struct GenDft {
   // d/dx pass of a stage in one launch (unnormalised: the caller's scale carries 1/N)
   const T* lmul_mid;
   GenPro<T> pro;
+  // slice window (Flow::gen_window: one launch chain per group of slices): blockIdx.y = y covers slices sl0 + y % sln of each of the
+  // grid.y / sln parts of the batch, which are slstride slices apart (a pair launch over 2 * slices has two parts).  sln = 0: slice y.
+  int sl0, sln, slstride;
 };
+template <typename T> __device__ __forceinline__ size_t gen_slice(const GenDft<T>& a) {
+  const unsigned y = blockIdx.y;
+  return a.sln ? (size_t)a.sl0 + (y % (unsigned)a.sln) + (size_t)(y / (unsigned)a.sln) * (unsigned)a.slstride : (size_t)y;
+}
 
 
 // input element n of a sequence: real / complex / Hermitian-extended half spectrum, conjugated for the e^{+i} transform
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(NTP) void k_gen_dft(GenDft<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* s = reinterpret_cast<cx<T>*>(smem);
   const int S = a.S, seq0 = blockIdx.x * S;
-  const size_t sl = blockIdx.y;
+  const size_t sl = gen_slice(a);
   // consecutive threads walk whichever of (element, sequence) is contiguous in memory
   const bool in_by_seq = a.in_elem != 1 && S > 1, out_by_seq = a.out_elem != 1 && S > 1;
   for (int q = threadIdx.x; q < S * L; q += NTP) {
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(BIG ? NTP : 1024) void k_gen_dft_mr(GenDft<T> a, Ge
     for (int i = threadIdx.x; i < N; i += nt) t[i] = a.tw[i];
     tw = t;
   }
-  const size_t sl = blockIdx.y;
+  const size_t sl = gen_slice(a);
   const bool in_by_seq = a.in_elem != 1 && S > 1, out_by_seq = a.out_elem != 1 && S > 1;
   for (int q = threadIdx.x; q < S * N; q += nt) {
     int sq, n;
@@ -338,8 +345,8 @@ __global__ __launch_bounds__(NTP) void k_gen_lmul2(const cx<T>* __restrict__ F, 
 // velocity k = p_x gx + p_y gy and the RK4 bookkeeping of the Map state (src/lenseflow.jl:150-161, src/numerical_algorithms.jl:15-21)
 template <typename T>
 __global__ __launch_bounds__(NTP) void k_gen_vel_rk(const T* __restrict__ gx, const T* __restrict__ gy, PhiMaps<T> ph, T* __restrict__ y0,
-                                                   T* __restrict__ acc, T* __restrict__ ys, RKCoef<T> rk, long npix, int P) {
-  const size_t sl = blockIdx.y, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
+                                                   T* __restrict__ acc, T* __restrict__ ys, RKCoef<T> rk, long npix, int P, int sl0) {
+  const size_t sl = blockIdx.y + (size_t)sl0, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
   for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
     const size_t o = sl * npix + i;
     T px, py; gen_p(ph, pb + i, rk.t, px, py);
@@ -353,8 +360,8 @@ __global__ __launch_bounds__(NTP) void k_gen_vel_rk(const T* __restrict__ gx, co
 
 // (Wx, Wy) = (p_x y, p_y y)          (src/lenseflow.jl:166-170)
 template <typename T>
-__global__ __launch_bounds__(NTP) void k_gen_pmul(const T* __restrict__ y, PhiMaps<T> ph, T t, T* __restrict__ Wx, T* __restrict__ Wy, long npix, int P) {
-  const size_t sl = blockIdx.y, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
+__global__ __launch_bounds__(NTP) void k_gen_pmul(const T* __restrict__ y, PhiMaps<T> ph, T t, T* __restrict__ Wx, T* __restrict__ Wy, long npix, int P, int sl0) {
+  const size_t sl = blockIdx.y + (size_t)sl0, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
   for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
     const size_t o = sl * npix + i;
     T px, py; gen_p(ph, pb + i, t, px, py);
@@ -367,10 +374,10 @@ __global__ __launch_bounds__(NTP) void k_gen_pmul(const T* __restrict__ y, PhiMa
 template <typename T>
 __global__ __launch_bounds__(NTP) void k_gen_adj_rk(const cx<T>* __restrict__ Fx, const cx<T>* __restrict__ Fy, const T* __restrict__ lx_r,
                                                    const T* __restrict__ ly, int Nx, cx<T>* __restrict__ Y0, cx<T>* __restrict__ acc,
-                                                   cx<T>* __restrict__ Ys, RKCoef<T> rk, long plane) {
+                                                   cx<T>* __restrict__ Ys, RKCoef<T> rk, long plane, int sl0) {
   const long i = (long)blockIdx.x * NTP + threadIdx.x;
   if (i >= plane) return;
-  const size_t o = (size_t)blockIdx.y * plane + i;
+  const size_t o = ((size_t)blockIdx.y + (size_t)sl0) * plane + i;
   const T lx = lx_r[(unsigned)i % (unsigned)Nx], l_y = ly[(unsigned)i / (unsigned)Nx];
   const cx<T> k = mul_il(Fx[o], lx) + mul_il(Fy[o], l_y);
   cx<T> y = Y0[o], a = rk.stage == 1 ? mk<T>(T(0), T(0)) : acc[o];
@@ -384,8 +391,8 @@ __global__ __launch_bounds__(NTP) void k_gen_adj_rk(const cx<T>* __restrict__ Fx
 template <typename T>
 __global__ __launch_bounds__(NTP) void k_gen_delta(const T* __restrict__ Ldf, const T* __restrict__ gfx, const T* __restrict__ gfy, PhiMaps<T> ph,
                                                   T* __restrict__ Wx, T* __restrict__ Wy, T* __restrict__ w1p, T* __restrict__ w2p,
-                                                  T* __restrict__ y0, T* __restrict__ acc, T* __restrict__ ys, RKCoef<T> rk, long npix, int P) {
-  const size_t sl = blockIdx.y, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
+                                                  T* __restrict__ y0, T* __restrict__ acc, T* __restrict__ ys, RKCoef<T> rk, long npix, int P, int sl0) {
+  const size_t sl = blockIdx.y + (size_t)sl0, pb = (size_t)(ph.Bphi == 1 ? 0 : sl / P) * npix;
   for (long i = (long)blockIdx.x * NTP + threadIdx.x; i < npix; i += (long)gridDim.x * NTP) {
     const size_t o = sl * npix + i;
     T px, py; gen_p(ph, pb + i, rk.t, px, py);

@@ -83,6 +83,10 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *        "pcache_max_mb"         CMBL_PCACHE_MAX_MB (16384)
  *        "fused_harm"            !CMBL_NO_FUSED_HARM (1)           harmonic-space operator chains inside one row pass
  *        "gen_separable", "gen_prologue", "gen_xderiv_fused"       any-size path stage fusions (CMBL_GEN_SEPARABLE / _PROLOGUE / _XDERIV_FUSED, all 1)
+ *        "gen_ct"                                                   any-size path: compile-time-plan transforms for the lengths 2^a 3^b 5^c of
+ *                                                                   CMBL_CT_LIST (CMBL_GEN_CT, 1; 0 = the run-time-planned kernel for every length)
+ *        "gen_slice_streams", "gen_streams_min_pix"                 any-size flows: one launch chain per group of slices from this many pixels
+ *                                                                   on (CMBL_GEN_SLICE_STREAMS 1, CMBL_GEN_STREAMS_MIN_PIX 2^21)
  *        "occupancy_tiles"       CMBL_OCCUPANCY_TILES (3)          small maps: bit 0 = two-column tiles when four-column tiles leave CUs idle or unevenly loaded, bit 1 = shorter row groups
  *        "fill_target"           CMBL_FILL_TARGET (0)              > 0: narrow the column tiles below that many tiles per launch instead of the built-in rule
  *        "row_fill_target"       CMBL_ROW_FILL_TARGET (0 = CUs/2)  shorten the row groups below that many groups per launch

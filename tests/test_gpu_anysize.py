@@ -103,6 +103,29 @@ def test_compile_time_plans_equal_run_time_plans(camb, prec):
         close(f"compile-time vs run-time plans {name}", a, b, tol)
 
 
+@pytest.mark.parametrize("P", [2, 3])
+def test_anysize_slice_streams_give_identical_results(camb, P):
+    """one launch chain per group of slices (option gen_slice_streams; forced on at this small size with gen_streams_min_pix = 0) against one
+    launch over all slices: the same kernels on the same data, bit for bit -- flows, adjoint flow and the delta-flow gradient"""
+    C = _pkg()
+    Ny, Nx, n = 96, 160, 7
+    oproj, simf, simp = sims(camb, Ny, Nx, P, 1)
+    f, phi = simf(1).astype(np.float32), simp(2, 1).astype(np.float32)
+    delta = O.rfft2(simf(7).astype(np.float64)).astype(np.complex64)
+    p = C.ProjLambert(Ny, Nx, 2.0, torch.float32, 0)
+    p.set_option("gen_streams_min_pix", 0)
+    res = {}
+    for on in (0, 1):
+        p.set_option("gen_slice_streams", on)
+        L = C.LenseFlow(p, n)(C.Field(p, p.tensor(phi), C.MAP))
+        ft = L * C.Field(p, p.tensor(f), C.MAP)
+        back = L.ldiv(ft)
+        dphi, df, _ = L.gradient(C.FLOW_FWD, ft, C.Field(p, p.tensor(delta), C.FOURIER))
+        res[on] = [ft.arr.clone(), back.arr.clone(), (L.adjoint * C.Field(p, p.tensor(delta), C.FOURIER)).arr.clone(), dphi.arr.clone(), df.arr.clone()]
+    for name, a, b in zip(("L*f", "L\\f", "L'g", "dphi", "df"), res[1], res[0]):
+        assert torch.equal(a, b), name
+
+
 def test_360_square_flow_and_gradient(camb):
     """the judge's second size: 360² QU fp32, flows + gradient against the oracle"""
     TP.test_lenseflow_ops(camb, "f32", 360, 360, 2, 1, 1, 7)
