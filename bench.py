@@ -581,6 +581,18 @@ def main():
                 ex["eight_chains_per_gpu"] = {"ms_per_call": ms8, "evaluations_per_s": 8e3 / ms8,
                                               "note": f"{N}² {pol}, Nbatch = 8 in one call (bench.py --nbatch 8 is the full line of this workload)"}
                 del sim8, fo8, po8
+                # a survey patch side that is not a power of two (3 * 2^k): the any-size path with its compile-time-plan transforms
+                # (csrc/kernels_ct.hpp), and the run-time-planned transforms of rounds 2-4 for comparison (option gen_ct)
+                Na = 768
+                sima = C.load_sim(2.0, Na, pol, synthetic_cls(), T=tT, device=local, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=nrk)
+                foa, poa = sima["ds"].mix(sima["f"], sima["phi"])
+                ms_ct = timeit(lambda: sima["ds"].gradient_logpdf_mixed(foa, poa), n=10)
+                sima["proj"].set_option("gen_ct", 0)
+                ms_rt = timeit(lambda: sima["ds"].gradient_logpdf_mixed(foa, poa), n=5)
+                sima["proj"].set_option("gen_ct", 1)
+                ex["any_size_768"] = {"ms_per_step": ms_ct, "ms_per_step_run_time_plans": ms_rt,
+                                      "note": f"{Na}² {pol} fp32, the same ∇logpdf(Mixed) step through the any-size path (DESIGN.md §2, profiles/r05_anysize_times.txt)"}
+                del sima, foa, poa
             out["extras"] = ex
     dev_exact = None
     if rank == 0 and world == 1 and B == 1 and not args.no_extras and not args.no_roofline and not C.reference_exact():
