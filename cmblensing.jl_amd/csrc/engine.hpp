@@ -94,6 +94,7 @@ struct CtxBase {
     int gen_xderiv_fused = env_int("CMBL_GEN_XDERIV_FUSED", 1) != 0;      //   d/dx pass as one launch
     int gen_slice_streams = env_int("CMBL_GEN_SLICE_STREAMS", 1) != 0;    //   one launch chain per group of slices (Flow::gen_groups)
     int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 1 << 21);   //   ... from this many pixels on (a quarter of it for >= 3 slices)
+    int gen_yy = env_int("CMBL_GEN_YY", 1) != 0;                          //   the y passes of a forward stage in one launch (GenDft::yy; needs gen_ct)
     int gen_ct = env_int("CMBL_GEN_CT", 1) != 0;                          //   compile-time plans for the lengths of CMBL_CT_LIST (kernels_ct.hpp)
     // launch geometry that fills the chip on small maps (profiles/r05_ab_occupancy_tiles.txt): narrower column tiles while a launch has
     // fewer workgroups than `fill_target` (0: the rule in Ctx::tileY), shorter row groups while it has fewer than `row_fill_target`
@@ -114,6 +115,7 @@ struct CtxBase {
     if (k == "gen_prologue") return &opts.gen_prologue;
     if (k == "gen_xderiv_fused") return &opts.gen_xderiv_fused;
     if (k == "gen_ct") return &opts.gen_ct;
+    if (k == "gen_yy") return &opts.gen_yy;
     if (k == "gen_slice_streams") return &opts.gen_slice_streams;
     if (k == "gen_streams_min_pix") return &opts.gen_streams_min_pix;
     if (k == "col_pipeline") return &opts.col_pipeline;
@@ -381,6 +383,35 @@ struct Ctx : CtxBase {
     a.scale = s1; a.scale2 = s2;
     a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
     gen_dft(genY, a, slices);
+  }
+  // the y axis has a compile-time plan (and they are switched on): the fused y passes of a flow stage exist
+  bool gen_ct_y() const {
+    if (!opts.gen_ct || genY.plan.nf == 0) return false;
+    switch (Ny) {
+#define CMBL_X(n) case n: return true;
+      CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+      default: return false;
+    }
+  }
+  // pair c2r of (G1, i ly G2) + the stage's velocity / RK update on the maps of `pro` + rfft_y of the next stage input -> Anext, one launch
+  // (GenDft::yy, kernels_ct.hpp ct_flow_stage); last: the flow ends, only y0 is updated
+  void gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, bool last, long slices) {
+    GenDft<T> a{};
+    a.pro = pro;
+    a.in = G1; a.in2 = G2; a.lmul_in = lmul2; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx;
+    a.scale = s1; a.scale2 = s2;
+    a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
+    a.yy = 1; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext;
+    slices = gen_window(a, slices);
+    a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S<T>();
+    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
+    switch (Ny) {
+#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_flow_y<T, n>), grid, ct_lds<T>(n), stream, a); return;
+      CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+      default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
+    }
   }
   // out = ifft_x(i lx fft_x(in)) unnormalised, in ONE launch when the axis has a mixed-radix plan (else two: chirp-z transforms)
   bool gen_x_deriv(const cx<T>* in, cx<T>* out, cx<T>* tmp, const T* lx, long slices) {
@@ -1027,6 +1058,8 @@ struct Flow {
     const bool sep = gen_sep();
     if (sep) { gA.ensure(sizeof(cx<T>) * slices * pl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
     const int K = gen_groups(slices);
+    const bool yy = sep && gen_pro() && c->opts.gen_yy && c->opts.gen_xderiv_fused && c->gen_ct_y();
+    if (yy) { gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); }
     fork(K);
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
@@ -1034,6 +1067,14 @@ struct Flow {
         const RKCoef<T> rk = coef(step, stage, t0, h, last);
         for (int g = 0; g < K; ++g) {
           GenWindow w(this, g, K, slices);
+          if (yy) {                                                          // d/dx pass, then every y pass of the stage in one launch
+            GenPro<T> e{};
+            e.mode = 1; e.ph = ph(rk.t); e.rk = rk; e.y0 = out; e.acc = acc.as<T>(); e.npix = np; e.P = P;
+            c->gen_x_deriv(gA.as<cx<T>>(), gGx.as<cx<T>>(), gT.as<cx<T>>(), c->lx_r.template as<T>(), slices);
+            c->gen_y_flow_stage(gGx.as<cx<T>>(), gA.as<cx<T>>(), c->ly.template as<T>(), (T)(1.0 / ((double)c->Ny * c->Nx)), (T)(1.0 / (double)c->Ny), e,
+                                gA.as<cx<T>>(), last, slices);
+            continue;
+          }
           if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);
           if (sep && !last && gen_pro()) {                                   // velocity + RK bookkeeping in the fetch of the next stage's y transform
             GenPro<T> e{};

@@ -311,6 +311,88 @@ __device__ __forceinline__ void ct_put(const GenDft<T>& a, size_t sl, int seq, i
   ct_store<(int)sizeof(cx<T>)>(reinterpret_cast<cx<T>*>(a.out) + sb, o * (unsigned)sizeof(cx<T>), &o1, wt);
 }
 
+// Stores: all LDS reads of the thread first, then the global stores (a read-store loop waits for LDS once per element)
+template <typename T, int N>
+__device__ __forceinline__ void ct_store_rows(const GenDft<T>& a, const cx<T>* __restrict__ s, size_t sl, int seq0, bool out_by_seq, int wave, int lane, bool mid) {
+  constexpr int S = ct_S<T>(), LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N);
+  const bool split = a.in_real && a.in2;
+  constexpr int E = (N + 63) / 64, NPC = (E + 11) / 12, PCH = (E + NPC - 1) / NPC;
+#pragma unroll
+  for (int c = 0; c < NPC; ++c) {
+    cx<T> y[PCH], yr[PCH];
+#pragma unroll
+    for (int ii = 0; ii < PCH; ++ii) {
+      const int i = c * PCH + ii, k0 = out_by_seq ? ((threadIdx.x + i * NT) >> LGS) : (lane + 64 * i), k = min(k0, a.nout - 1);
+      const cx<T>* p = s + (out_by_seq ? ((threadIdx.x + i * NT) & (S - 1)) : wave) * LD;
+      y[ii] = p[pad(k)];
+      yr[ii] = p[pad(split && k ? N - k : 0)];                           // Z[N - k]: only the pair split reads it
+    }
+#pragma unroll
+    for (int ii = 0; ii < PCH; ++ii) {
+      const int i = c * PCH + ii, k = out_by_seq ? ((threadIdx.x + i * NT) >> LGS) : (lane + 64 * i);
+      const int seq = seq0 + (out_by_seq ? ((threadIdx.x + i * NT) & (S - 1)) : wave);
+      if (i < E && k < a.nout && seq < a.nseq) ct_put(a, sl, seq, k, mid ? conj(y[ii]) : y[ii], yr[ii]);
+    }
+  }
+}
+
+// Fused y passes of a forward flow stage, on the wavefront's own column `seq` (row = its LDS row, holding the fetched pair
+// conj(ext(Gx) + i ext(i ly A))):  inverse transform -> (d/dx f, d/dy f) at the column's pixels -> velocity p . grad f and the RK4
+// bookkeeping (src/lenseflow.jl:150-161, src/numerical_algorithms.jl:15-21; y0 / acc in memory like k_gen_vel_rk) -> the next stage
+// input as a real sequence -> forward transform.  Everything between the two workgroup barriers of the launch is wave-private.
+template <typename T, int N>
+__device__ __forceinline__ void ct_flow_stage(const GenDft<T>& a, cx<T>* __restrict__ row, const cx<T>* __restrict__ tw, size_t sl, int seq, int lane) {
+  constexpr int E = (N + 63) / 64;
+  const GenPro<T>& e = a.pro;
+  const size_t mb = sl * (size_t)e.npix, pb = (size_t)(e.ph.Bphi == 1 ? 0 : sl / e.P) * e.npix;
+  const bool pc = e.ph.pcx != nullptr;
+  // the pixels' operands: requested before the transform so that they arrive under it (up to 12 pixels per lane, p(t) from the cache;
+  // longer columns and the five-map form request them after it: the registers are the transform's)
+  constexpr bool EARLY = E <= 12;
+  T px[E], py[E], y0v[E], acv[E];
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int n = min(lane + 64 * i, N - 1);
+      const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+      y0v[i] = at32(e.y0 + mb, o); acv[i] = at32(e.acc + mb, o);
+      if (pc) { px[i] = at32(e.ph.pcx + pb, o); py[i] = at32(e.ph.pcy + pb, o); }
+    }
+  }
+  ct_transform<T, N>(row, tw, lane);
+  if constexpr (!EARLY) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int n = min(lane + 64 * i, N - 1);
+      const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+      y0v[i] = at32(e.y0 + mb, o); acv[i] = at32(e.acc + mb, o);
+      if (pc) { px[i] = at32(e.ph.pcx + pb, o); py[i] = at32(e.ph.pcy + pb, o); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const int n0 = lane + 64 * i, n = min(n0, N - 1);
+    const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+    if (!pc) {
+      T m11, m12, m22;
+      flow_pm(e.rk.t, at32(e.ph.gx + pb, o), at32(e.ph.gy + pb, o), at32(e.ph.hxx + pb, o), at32(e.ph.hyx + pb, o), at32(e.ph.hyy + pb, o), px[i], py[i], m11, m12, m22);
+    }
+    const cx<T> z = row[pad(n)];                                         // the e^{+i} transform is conj(forward(conj .)): y = conj(z)
+    const T gx = a.scale * z.x, gy = -a.scale2 * z.y;
+    const T k = px[i] * gx + py[i] * gy;
+    T y = y0v[i], ac = e.rk.stage == 1 ? T(0) : acv[i];
+    const T nxt = rk_update(e.rk, k, y, ac);
+    if (N % 64 == 0 || n0 < N) {
+      if (e.rk.stage == 4) at32(e.y0 + mb, o) = y; else at32(e.acc + mb, o) = ac;
+      row[pad(n)] = mk<T>(nxt, T(0));
+    }
+  }
+  if (a.yy_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  ct_transform<T, N>(row, tw, lane);
+}
+
 // debug builds (-DCMBL_STAMPS -DCMBL_STAMPS_ROWS -DCMBL_STAMPS_CT): phase timestamps of the launches whose kind (+ 8 for the d/dx pass)
 // equals CMBL_CT_STAMP_KIND, read back with cmbl_debug_stamps (tools/gpu_stamps_ct.py)
 #ifdef CMBL_STAMPS_CT
@@ -371,28 +453,35 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft(Ge
   CMBL_CT_STAMP(4);
   __syncthreads();
   CMBL_CT_STAMP(5);
-  // Stores: all LDS reads of the thread first, then the global stores (a read-store loop waits for LDS once per element: 4.5k cycles
-  // per launch measured, against 1.5k)
-  const bool mid = a.lmul_mid != nullptr, split = a.in_real && a.in2;
-  constexpr int E = (N + 63) / 64, NPC = (E + 11) / 12, PCH = (E + NPC - 1) / NPC;
-#pragma unroll
-  for (int c = 0; c < NPC; ++c) {
-    cx<T> y[PCH], yr[PCH];
-#pragma unroll
-    for (int ii = 0; ii < PCH; ++ii) {
-      const int i = c * PCH + ii, k0 = out_by_seq ? ((threadIdx.x + i * NT) >> LGS) : (lane + 64 * i), k = min(k0, a.nout - 1);
-      const cx<T>* p = s + (out_by_seq ? ((threadIdx.x + i * NT) & (S - 1)) : wave) * LD;
-      y[ii] = p[pad(k)];
-      yr[ii] = p[pad(split && k ? N - k : 0)];                           // Z[N - k]: only the pair split reads it
-    }
-#pragma unroll
-    for (int ii = 0; ii < PCH; ++ii) {
-      const int i = c * PCH + ii, k = out_by_seq ? ((threadIdx.x + i * NT) >> LGS) : (lane + 64 * i);
-      const int seq = seq0 + (out_by_seq ? ((threadIdx.x + i * NT) & (S - 1)) : wave);
-      if (i < E && k < a.nout && seq < a.nseq) ct_put(a, sl, seq, k, mid ? conj(y[ii]) : y[ii], yr[ii]);
-    }
-  }
+  ct_store_rows<T, N>(a, s, sl, seq0, out_by_seq, wave, lane, a.lmul_mid != nullptr);
   CMBL_CT_STAMP(6); CMBL_CT_STAMP(15);
+}
+
+// The y passes of a forward flow stage in one launch (GenDft::yy; Ctx::gen_y_flow_stage): pair-c2r fetch, ct_flow_stage on every column,
+// rfft_y(f_next) stored as a half spectrum in the layout of the inputs.  A kernel of its own: its register needs are not k_ct_dft's.
+// (register budget: ONE workgroup per CU -- the operands of the pixels are held across a transform; at the sizes where a second resident
+// workgroup would matter the launch has more workgroups than CUs anyway and the slice streams overlap the chains)
+template <typename T, int N>
+__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_flow_y(GenDft<T> a) {
+  constexpr int S = ct_S<T>(), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* s = tw + NTW;
+  const int seq0 = xcd_tile(blockIdx.x, gridDim.x) * S;
+  const size_t sl = gen_slice(a);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  TwStage<T, NT, NTW> twr;
+  twr.issue(a.tw);
+  ct_fetch<T, N, CT_H2, true>(a, s, sl, seq0, true);
+  twr.commit(tw);
+  __syncthreads();
+  if (seq0 + wave < a.nseq) ct_flow_stage<T, N>(a, s + wave * LD, tw, sl, seq0 + wave, lane);
+  if (a.yy_last) return;
+  __syncthreads();
+  GenDft<T> b{};                                                         // the store side: rfft_y(f_next) as a half spectrum, [ky][x]
+  b.out = a.yy_out; b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1);
+  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
+  ct_store_rows<T, N>(b, s, sl, seq0, true, wave, lane, false);
 }
 
 }  // namespace cmbl

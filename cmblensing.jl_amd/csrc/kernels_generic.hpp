@@ -81,6 +81,12 @@ template <typename T> struct GenDft {
   // slice window (Flow::gen_window: one launch chain per group of slices): blockIdx.y = y covers slices sl0 + y % sln of each of the
   // grid.y / sln parts of the batch, which are slstride slices apart (a pair launch over 2 * slices has two parts).  sln = 0: slice y.
   int sl0, sln, slstride;
+  // Fused y passes of a flow stage (k_ct_dft only; kernels_ct.hpp): yy = 1 -- this launch is the pair c2r of a forward stage (herm, in2,
+  // lmul_in, inverse, scale, scale2 as usual), but (d/dx f, d/dy f) stay in LDS: the stage's velocity and RK update (pro: ph, rk, y0, acc)
+  // are applied there and the NEXT stage's rfft_y(f) is transformed and written to yy_out ([ky][x] like the inputs, yy_nout entries);
+  // yy_last: the flow ends here (only y0 is updated).  One launch instead of two and no round trip of the two gradient maps.
+  int yy, yy_last, yy_nout;
+  void* yy_out;
 };
 template <typename T> __device__ __forceinline__ size_t gen_slice(const GenDft<T>& a) {
   const unsigned y = blockIdx.y;
