@@ -413,6 +413,29 @@ struct Ctx : CtxBase {
       default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
     }
   }
+  // ... and the four y passes of a delta-flow stage (two LDS rows per column: up to Ny ~ 1150)
+  bool gen_ct_y2() const { return gen_ct_y() && ct_lds<T>(Ny, 2) <= 160 * 1024; }
+  // c2r of T3 = ifft_x(delta f) -> L(df), pair c2r of (G1, i ly G2) -> grad f, the delta stage's pointwise work on the maps of `pro`
+  // (w1p, w2p, y0, acc), rfft_y of the next f -> Anext, pair r2c of (p_x, p_y) L(df) -> (W2a, W2b): one launch (k_ct_delta_y)
+  void gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext,
+                         cx<T>* W2a, cx<T>* W2b, bool last, long slices) {
+    GenDft<T> a{};
+    a.pro = pro;
+    a.in = G1; a.in2 = G2; a.lmul_in = lmul2; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx;
+    a.scale = s1; a.scale2 = s2;
+    a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
+    a.yy = 2; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext; a.yy_in3 = T3; a.yy_scale3 = s3; a.yy_out2 = W2a; a.yy_out3 = W2b;
+    slices = gen_window(a, slices);
+    a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S<T>();
+    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
+    switch (Ny) {
+#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2) <= 160 * 1024) { CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_delta_y<T, n>), grid, ct_lds<T>(n, 2), stream, a); return; } break;
+      CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+      default: break;
+    }
+    fail(ERR_STATE, "fused delta-stage y passes need a compile-time plan for Ny that fits LDS twice");
+  }
   // out = ifft_x(i lx fft_x(in)) unnormalised, in ONE launch when the axis has a mixed-radix plan (else two: chirp-z transforms)
   bool gen_x_deriv(const cx<T>* in, cx<T>* out, cx<T>* tmp, const T* lx, long slices) {
     if (genX.plan.nf == 0 || !opts.gen_xderiv_fused) {
@@ -1128,6 +1151,7 @@ struct Flow {
     gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); gmxy.ensure(sizeof(T) * 2 * slices * np);   // before the chains fork
     gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gW2.ensure(sizeof(cx<T>) * 2 * slices * pl); (void)c->mixed_scratch(slices);
     const int K = gen_groups(slices);
+    const bool yy = sep && gen_pro() && c->opts.gen_yy && c->opts.gen_xderiv_fused && c->gen_ct_y2() && c->genX.plan.nf > 0;
     fork(K);
     int it = 0;
     for (int step = 0; step < n; ++step)
@@ -1138,6 +1162,21 @@ struct Flow {
         T* w1p = Wst.as<T>() + (size_t)(2 * it) * slices * np;
         for (int g = 0; g < K; ++g) {
           GenWindow w(this, g, K, slices);
+          if (yy) {
+            // x passes (ifft_x of delta f, d/dx of rfft_y(f)), then every y pass of the stage in one launch, then the delta-f velocity's x pass + RK update
+            cx<T>* t3 = c->mixed_scratch(slices);
+            c->gen_x(gYs.as<cx<T>>(), t3, true, nullptr, slices);
+            c->gen_x_deriv(gA.as<cx<T>>(), gGx.as<cx<T>>(), gT.as<cx<T>>(), c->lx_r.template as<T>(), slices);
+            GenPro<T> e{};
+            e.mode = 2; e.ph = ph(rk.t); e.rk = rk; e.y0 = f; e.acc = acc.as<T>(); e.w1p = w1p; e.w2p = w1p + (size_t)slices * np; e.npix = np; e.P = P;
+            c->gen_y_delta_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), gGx.as<cx<T>>(), gA.as<cx<T>>(), c->ly.template as<T>(),
+                                 (T)(1.0 / ((double)c->Ny * c->Nx)), (T)(1.0 / (double)c->Ny), e, gA.as<cx<T>>(), gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl,
+                                 rk.last != 0, slices);
+            c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
+            CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
+                        c->ly.template as<T>(), c->Nx, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, pl, wsl0());
+            continue;
+          }
           c->F_to_map(gYs.as<cx<T>>(), gLdf.as<T>(), slices);                 // L(df)
           if (sep) gen_grad_sep(gA.as<cx<T>>(), slices); else gen_grad(gms.as<T>(), slices);   // grad f -> gmxy
           if (sep && !rk.last && gen_pro()) {

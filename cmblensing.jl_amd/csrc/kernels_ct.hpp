@@ -33,7 +33,7 @@ constexpr int ct_radix(int N, int i) {
 constexpr int ct_ns(int N, int i) { int ns = 1; for (int k = 0; k < i; ++k) ns *= ct_radix(N, k); return ns; }   // product of the earlier radices
 constexpr int ct_ld(int N) { return pad(N) + ((8 - pad(N) % 32) + 32) % 32; }                        // row stride, 8 (mod 32) slots
 template <typename T> constexpr int ct_S() { return 64 / (int)sizeof(cx<T>); }                       // sequences (= wavefronts) per workgroup
-template <typename T> constexpr size_t ct_lds(int N) { return ((size_t)(N / 2) + (size_t)ct_S<T>() * ct_ld(N)) * sizeof(cx<T>); }
+template <typename T> constexpr size_t ct_lds(int N, int rowsets = 1) { return ((size_t)(N / 2) + (size_t)rowsets * ct_S<T>() * ct_ld(N)) * sizeof(cx<T>); }
 
 // fetch variants
 enum { CT_C = 0, CT_R1, CT_R2, CT_H1, CT_H2, CT_P1, CT_P2, CT_P3 };
@@ -482,6 +482,84 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_fl
   b.out = a.yy_out; b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1);
   b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
   ct_store_rows<T, N>(b, s, sl, seq0, true, wave, lane, false);
+}
+
+// The four y passes of a delta-flow stage in one launch (GenDft::yy = 2; Ctx::gen_y_delta_stage): the c2r of ifft_x(delta f) -> L(df), the pair
+// c2r -> (d/dx f, d/dy f), the stage's pointwise work (src/lenseflow.jl:184-200: the products for the delta-phi quadrature, the f velocity
+// with its RK update, the pair (p_x, p_y) L(df)), rfft_y of the next f and the pair r2c of the delta-f velocity.  Two LDS rows per column
+// (rows 0..S-1: the gradient pair / next f; rows S..2S-1: L(df) / the velocity pair); a wavefront runs its column's four transforms.
+template <typename T, int N>
+__device__ __forceinline__ void ct_delta_stage(const GenDft<T>& a, cx<T>* __restrict__ r1, cx<T>* __restrict__ r2, const cx<T>* __restrict__ tw, size_t sl, int seq, int lane) {
+  constexpr int E = (N + 63) / 64, PCH = E <= 8 ? E : (E + ((E + 7) / 8) - 1) / ((E + 7) / 8), NPC = (E + PCH - 1) / PCH;
+  const GenPro<T>& e = a.pro;
+  const size_t mb = sl * (size_t)e.npix, pb = (size_t)(e.ph.Bphi == 1 ? 0 : sl / e.P) * e.npix;
+  const bool pc = e.ph.pcx != nullptr;
+  ct_transform<T, N>(r1, tw, lane);
+  ct_transform<T, N>(r2, tw, lane);
+#pragma unroll
+  for (int c = 0; c < NPC; ++c) {
+    T px[PCH], py[PCH], y0v[PCH], acv[PCH];
+#pragma unroll
+    for (int ii = 0; ii < PCH; ++ii) {
+      const int n = min(lane + 64 * (c * PCH + ii), N - 1);
+      const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+      y0v[ii] = at32(e.y0 + mb, o); acv[ii] = at32(e.acc + mb, o);
+      if (pc) { px[ii] = at32(e.ph.pcx + pb, o); py[ii] = at32(e.ph.pcy + pb, o); }
+      else {
+        T m11, m12, m22;
+        flow_pm(e.rk.t, at32(e.ph.gx + pb, o), at32(e.ph.gy + pb, o), at32(e.ph.hxx + pb, o), at32(e.ph.hyx + pb, o), at32(e.ph.hyy + pb, o), px[ii], py[ii], m11, m12, m22);
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < PCH; ++ii) {
+      const int n0 = lane + 64 * (c * PCH + ii), n = min(n0, N - 1);
+      const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+      const cx<T> z = r1[pad(n)], zl = r2[pad(n)];                       // e^{+i} transforms: the values are conj(z), conj(zl)
+      const T gx = a.scale * z.x, gy = -a.scale2 * z.y, l = a.yy_scale3 * zl.x;
+      const T k = px[ii] * gx + py[ii] * gy;
+      T y = y0v[ii], ac = e.rk.stage == 1 ? T(0) : acv[ii];
+      const T nxt = rk_update(e.rk, k, y, ac);
+      if ((N % 64 == 0 || n0 < N) && (c * PCH + ii) < E) {
+        at32(e.w1p + mb, o) = l * gx; at32(e.w2p + mb, o) = l * gy;
+        if (e.rk.stage == 4) at32(e.y0 + mb, o) = y; else at32(e.acc + mb, o) = ac;
+        r1[pad(n)] = mk<T>(nxt, T(0));
+        r2[pad(n)] = mk<T>(px[ii] * l, py[ii] * l);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (!a.yy_last) ct_transform<T, N>(r1, tw, lane);
+  ct_transform<T, N>(r2, tw, lane);
+}
+template <typename T, int N>
+__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_delta_y(GenDft<T> a) {
+  constexpr int S = ct_S<T>(), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* s = tw + NTW;
+  cx<T>* s2 = s + S * LD;
+  const int seq0 = xcd_tile(blockIdx.x, gridDim.x) * S;
+  const size_t sl = gen_slice(a);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  TwStage<T, NT, NTW> twr;
+  twr.issue(a.tw);
+  ct_fetch<T, N, CT_H2, true>(a, s, sl, seq0, true);
+  {
+    GenDft<T> a3 = a;                                                    // ifft_x(delta f): a single half plane, no multiplier
+    a3.in = a.yy_in3; a3.in2 = nullptr; a3.lmul_in = nullptr;
+    ct_fetch<T, N, CT_H1, false>(a3, s2, sl, seq0, true);
+  }
+  twr.commit(tw);
+  __syncthreads();
+  if (seq0 + wave < a.nseq) ct_delta_stage<T, N>(a, s + wave * LD, s2 + wave * LD, tw, sl, seq0 + wave, lane);
+  __syncthreads();
+  GenDft<T> b{};                                                         // store side, [ky][x] like the inputs
+  b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1); b.scale2 = T(1);
+  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
+  if (!a.yy_last) { b.out = a.yy_out; ct_store_rows<T, N>(b, s, sl, seq0, true, wave, lane, false); }
+  b.out = a.yy_out2; b.out2 = a.yy_out3; b.in2 = a.yy_out3;              // in2 != nullptr marks the pair split (ct_put)
+  ct_store_rows<T, N>(b, s2, sl, seq0, true, wave, lane, false);
 }
 
 }  // namespace cmbl

@@ -85,8 +85,13 @@ template <typename T> struct GenDft {
   // lmul_in, inverse, scale, scale2 as usual), but (d/dx f, d/dy f) stay in LDS: the stage's velocity and RK update (pro: ph, rk, y0, acc)
   // are applied there and the NEXT stage's rfft_y(f) is transformed and written to yy_out ([ky][x] like the inputs, yy_nout entries);
   // yy_last: the flow ends here (only y0 is updated).  One launch instead of two and no round trip of the two gradient maps.
+  // yy = 2: the same for a delta-flow stage (k_ct_delta_y): a third half plane yy_in3 = ifft_x(delta f) gives L(df) (scale yy_scale3) next to
+  // the gradient pair; the stage's products go to pro.w1p / w2p, the f part is updated like above (-> yy_out), and the pair
+  // (p_x L(df), p_y L(df)) is transformed and split into yy_out2 / yy_out3 (what the pair r2c of gen_adj_update writes).
   int yy, yy_last, yy_nout;
   void* yy_out;
+  const void* yy_in3; void* yy_out2; void* yy_out3;
+  T yy_scale3;
 };
 template <typename T> __device__ __forceinline__ size_t gen_slice(const GenDft<T>& a) {
   const unsigned y = blockIdx.y;
