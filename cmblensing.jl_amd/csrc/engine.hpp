@@ -436,6 +436,23 @@ struct Ctx : CtxBase {
     }
     fail(ERR_STATE, "fused delta-stage y passes need a compile-time plan for Ny that fits LDS twice");
   }
+  // c2r of T3 = ifft_x(y) -> y, (p_x y, p_y y) at stage time t, its pair r2c -> (W2a, W2b): the y passes of an adjoint stage in one launch
+  void gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, int P, cx<T>* W2a, cx<T>* W2b, long slices) {
+    GenDft<T> a{};
+    a.pro.ph = phm; a.pro.rk.t = t; a.pro.npix = npix(); a.pro.P = P;
+    a.in = T3; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx; a.scale = s3;
+    a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
+    a.yy = 3; a.yy_nout = Nyh; a.yy_out2 = W2a; a.yy_out3 = W2b;
+    slices = gen_window(a, slices);
+    a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S<T>();
+    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
+    switch (Ny) {
+#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_y<T, n>), grid, ct_lds<T>(n), stream, a); return;
+      CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+      default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
+    }
+  }
   // out = ifft_x(i lx fft_x(in)) unnormalised, in ONE launch when the axis has a mixed-radix plan (else two: chirp-z transforms)
   bool gen_x_deriv(const cx<T>* in, cx<T>* out, cx<T>* tmp, const T* lx, long slices) {
     if (genX.plan.nf == 0 || !opts.gen_xderiv_fused) {
@@ -1121,12 +1138,22 @@ struct Flow {
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
     gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gW2.ensure(sizeof(cx<T>) * 2 * slices * pl); (void)c->mixed_scratch(slices);   // before the chains fork
     const int K = gen_groups(slices);
+    const bool yy = gen_sep() && c->opts.gen_yy && c->gen_ct_y();
     fork(K);
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
         const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
         for (int g = 0; g < K; ++g) {
           GenWindow w(this, g, K, slices);
+          if (yy) {                                                          // ifft_x, every y pass of the stage in one launch, fft_x of the pair, RK update
+            cx<T>* t3 = c->mixed_scratch(slices);
+            c->gen_x(gYs.as<cx<T>>(), t3, true, nullptr, slices);
+            c->gen_y_adj_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), ph(rk.t), rk.t, P, gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, slices);
+            c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
+            CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
+                        c->ly.template as<T>(), c->Nx, out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, pl, wsl0());
+            continue;
+          }
           c->F_to_map(gYs.as<cx<T>>(), gms.as<T>(), slices);
           CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_pmul<T>), pgrid(np, slices), 0, c->stream, gms.as<T>(), ph(rk.t), rk.t, gmxy.as<T>(), gmxy.as<T>() + slices * np, np, P, wsl0());
           gen_adj_update(gmxy.as<T>(), out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices);

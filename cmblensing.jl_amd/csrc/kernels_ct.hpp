@@ -562,4 +562,60 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_de
   ct_store_rows<T, N>(b, s2, sl, seq0, true, wave, lane, false);
 }
 
+// The y passes of an adjoint flow stage in one launch (GenDft::yy = 3; Ctx::gen_y_adj_stage): c2r of yy_in3 = ifft_x(y) -> the map y, the
+// pair (p_x y, p_y y) (src/lenseflow.jl:166-170), its pair r2c split into yy_out2 / yy_out3.  One LDS row per column.
+template <typename T, int N>
+__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_adj_y(GenDft<T> a) {
+  constexpr int S = ct_S<T>(), NT = 64 * S, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64;
+  constexpr int PCH = E <= 12 ? E : (E + ((E + 11) / 12) - 1) / ((E + 11) / 12), NPC = (E + PCH - 1) / PCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* s = tw + NTW;
+  const int seq0 = xcd_tile(blockIdx.x, gridDim.x) * S;
+  const size_t sl = gen_slice(a);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  TwStage<T, NT, NTW> twr;
+  twr.issue(a.tw);
+  ct_fetch<T, N, CT_H1, false>(a, s, sl, seq0, true);
+  twr.commit(tw);
+  __syncthreads();
+  const int seq = seq0 + wave;
+  if (seq < a.nseq) {
+    cx<T>* row = s + wave * LD;
+    const GenPro<T>& e = a.pro;
+    const size_t pb = (size_t)(e.ph.Bphi == 1 ? 0 : sl / e.P) * e.npix;
+    const bool pc = e.ph.pcx != nullptr;
+    ct_transform<T, N>(row, tw, lane);
+#pragma unroll
+    for (int c = 0; c < NPC; ++c) {
+      T px[PCH], py[PCH];
+#pragma unroll
+      for (int ii = 0; ii < PCH; ++ii) {
+        const int n = min(lane + 64 * (c * PCH + ii), N - 1);
+        const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+        if (pc) { px[ii] = at32(e.ph.pcx + pb, o); py[ii] = at32(e.ph.pcy + pb, o); }
+        else {
+          T m11, m12, m22;
+          flow_pm(e.rk.t, at32(e.ph.gx + pb, o), at32(e.ph.gy + pb, o), at32(e.ph.hxx + pb, o), at32(e.ph.hyx + pb, o), at32(e.ph.hyy + pb, o), px[ii], py[ii], m11, m12, m22);
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < PCH; ++ii) {
+        const int n0 = lane + 64 * (c * PCH + ii), n = min(n0, N - 1);
+        const T y = a.scale * row[pad(n)].x;                             // e^{+i} transform: the value is conj(z); real part
+        if ((N % 64 == 0 || n0 < N) && (c * PCH + ii) < E) row[pad(n)] = mk<T>(px[ii] * y, py[ii] * y);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ct_transform<T, N>(row, tw, lane);
+  }
+  __syncthreads();
+  GenDft<T> b{};
+  b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1); b.scale2 = T(1);
+  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
+  b.out = a.yy_out2; b.out2 = a.yy_out3; b.in2 = a.yy_out3;              // in2 != nullptr marks the pair split (ct_put)
+  ct_store_rows<T, N>(b, s, sl, seq0, true, wave, lane, false);
+}
+
 }  // namespace cmbl
