@@ -27,7 +27,7 @@ def test_geometry_and_basis_transforms(prec, Ny, Nx):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(96, 160, 2, 1, 1), (160, 96, 3, 1, 1), (45, 75, 2, 2, 2), (100, 128, 1, 2, 1), (91, 60, 2, 1, 1), (51, 38, 2, 1, 1)])
+@pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(96, 160, 2, 1, 1), (160, 96, 3, 1, 1), (45, 75, 2, 2, 2), (100, 128, 1, 2, 1), (91, 60, 2, 1, 1), (51, 38, 2, 1, 1), (96, 34, 2, 2, 2)])
 @pytest.mark.parametrize("n", [7, 10])
 def test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi, n):
     TP.test_lenseflow_ops(camb, prec, Ny, Nx, P, B, Bphi, n)
@@ -123,6 +123,32 @@ def test_anysize_slice_streams_give_identical_results(camb, P):
         dphi, df, _ = L.gradient(C.FLOW_FWD, ft, C.Field(p, p.tensor(delta), C.FOURIER))
         res[on] = [ft.arr.clone(), back.arr.clone(), (L.adjoint * C.Field(p, p.tensor(delta), C.FOURIER)).arr.clone(), dphi.arr.clone(), df.arr.clone()]
     for name, a, b in zip(("L*f", "L\\f", "L'g", "dphi", "df"), res[1], res[0]):
+        assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(96, 160, 3, 2, 2), (160, 96, 2, 1, 1), (96, 34, 2, 2, 1)])
+def test_anysize_fused_y_passes_give_identical_results(camb, prec, Ny, Nx, P, B, Bphi):
+    """the y passes of a flow stage in one launch (option gen_yy: k_ct_flow_y / k_ct_delta_y / k_ct_adj_y, csrc/kernels_ct.hpp) against the
+    separate launches they replace: the same arithmetic in the same order, bit for bit -- with batch slots that carry their own phi, and
+    with an x axis that has no mixed-radix plan (34 = 2 * 17: chirp-z transforms around the fused y kernels)"""
+    C = _pkg()
+    tT, nT = DT[prec]
+    n = 7
+    oproj, simf, simp = sims(camb, Ny, Nx, P, B)
+    f, phi = simf(1).astype(nT), simp(2, Bphi).astype(nT)
+    delta = O.rfft2(simf(7).astype(np.float64)).astype(np.complex64 if prec == "f32" else np.complex128)
+    p = C.ProjLambert(Ny, Nx, 2.0, tT, 0)
+    res = {}
+    for on in (0, 1):
+        p.set_option("gen_yy", on)
+        L = C.LenseFlow(p, n)(C.Field(p, p.tensor(phi), C.MAP))
+        ft = L * C.Field(p, p.tensor(f), C.MAP)
+        back = L.ldiv(ft)
+        g = C.Field(p, p.tensor(delta), C.FOURIER)
+        dphi, df, f0 = L.gradient(C.FLOW_FWD, ft, g)
+        res[on] = [ft.arr.clone(), back.arr.clone(), (L.adjoint * g).arr.clone(), L.adjoint.ldiv(g).arr.clone(), dphi.arr.clone(), df.arr.clone(), f0.arr.clone()]
+    for name, a, b in zip(("L*f", "L\\f", "L'g", "L'\\g", "dphi", "df", "f0"), res[1], res[0]):
         assert torch.equal(a, b), name
 
 
