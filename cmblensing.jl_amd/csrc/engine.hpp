@@ -414,7 +414,7 @@ struct Ctx : CtxBase {
     }
   }
   // ... and the four y passes of a delta-flow stage (two LDS rows per column: up to Ny ~ 1150)
-  bool gen_ct_y2() const { return gen_ct_y() && ct_lds<T>(Ny, 2) <= 160 * 1024; }
+  bool gen_ct_y2() const { return gen_ct_y() && ct_lds<T>(Ny, 2, ct_S2<T>(Ny)) <= 160 * 1024; }
   // c2r of T3 = ifft_x(delta f) -> L(df), pair c2r of (G1, i ly G2) -> grad f, the delta stage's pointwise work on the maps of `pro`
   // (w1p, w2p, y0, acc), rfft_y of the next f -> Anext, pair r2c of (p_x, p_y) L(df) -> (W2a, W2b): one launch (k_ct_delta_y)
   void gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext,
@@ -426,15 +426,37 @@ struct Ctx : CtxBase {
     a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
     a.yy = 2; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext; a.yy_in3 = T3; a.yy_scale3 = s3; a.yy_out2 = W2a; a.yy_out3 = W2b;
     slices = gen_window(a, slices);
-    a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S<T>();
+    a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S2<T>(Ny);
     const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
     switch (Ny) {
-#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2) <= 160 * 1024) { CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_delta_y<T, n>), grid, ct_lds<T>(n, 2), stream, a); return; } break;
+#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2, ct_S2<T>(n)) <= 160 * 1024) { CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S2<T>(n), (k_ct_delta_y<T, n>), grid, ct_lds<T>(n, 2, ct_S2<T>(n)), stream, a); return; } break;
       CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
       default: break;
     }
     fail(ERR_STATE, "fused delta-stage y passes need a compile-time plan for Ny that fits LDS twice");
+  }
+  // t3 = ifft_x(F) (unnormalised) and gx = ifft_x(i lx fft_x(A)) in ONE launch where the x axis has a compile-time plan (else two launches)
+  void gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices) {
+    bool ct = opts.gen_ct && opts.gen_xderiv_fused && genX.plan.nf > 0;
+    if (ct) {
+      GenDft<T> a0{}, a1{};
+      a0.in = F; a0.out = t3; a0.nin = Nx; a0.nout = Nx; a0.nseq = Nyh; a0.scale = 1; a0.inverse = 1;
+      a0.in_seq = Nx; a0.in_elem = 1; a0.in_slice = plane(); a0.out_seq = Nx; a0.out_elem = 1; a0.out_slice = plane();
+      a1 = a0; a1.in = A_; a1.out = gx; a1.inverse = 0; a1.lmul_mid = lx;
+      const long ws = gen_window(a0, slices);
+      (void)gen_window(a1, slices);
+      a0.N = a1.N = Nx; a0.tw = a1.tw = genX.twN.template as<cx<T>>(); a0.S = a1.S = ct_S<T>();
+      const dim3 grid((unsigned)((a0.nseq + a0.S - 1) / a0.S), (unsigned)(2 * ws));
+      switch (Nx) {
+#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft2<T, n>), grid, ct_lds<T>(n), stream, a0, ct_kind(a0), (int)ws, a1, ct_kind(a1)); return;
+        CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+        default: break;
+      }
+    }
+    gen_x(F, t3, true, nullptr, slices);
+    gen_x_deriv(A_, gx, tmp, lx, slices);
   }
   // c2r of T3 = ifft_x(y) -> y, (p_x y, p_y y) at stage time t, its pair r2c -> (W2a, W2b): the y passes of an adjoint stage in one launch
   void gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, int P, cx<T>* W2a, cx<T>* W2b, long slices) {
@@ -1192,8 +1214,7 @@ struct Flow {
           if (yy) {
             // x passes (ifft_x of delta f, d/dx of rfft_y(f)), then every y pass of the stage in one launch, then the delta-f velocity's x pass + RK update
             cx<T>* t3 = c->mixed_scratch(slices);
-            c->gen_x(gYs.as<cx<T>>(), t3, true, nullptr, slices);
-            c->gen_x_deriv(gA.as<cx<T>>(), gGx.as<cx<T>>(), gT.as<cx<T>>(), c->lx_r.template as<T>(), slices);
+            c->gen_x_inv_and_deriv(gYs.as<cx<T>>(), t3, gA.as<cx<T>>(), gGx.as<cx<T>>(), gT.as<cx<T>>(), c->lx_r.template as<T>(), slices);
             GenPro<T> e{};
             e.mode = 2; e.ph = ph(rk.t); e.rk = rk; e.y0 = f; e.acc = acc.as<T>(); e.w1p = w1p; e.w2p = w1p + (size_t)slices * np; e.npix = np; e.P = P;
             c->gen_y_delta_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), gGx.as<cx<T>>(), gA.as<cx<T>>(), c->ly.template as<T>(),

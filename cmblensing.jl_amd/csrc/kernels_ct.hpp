@@ -33,7 +33,10 @@ constexpr int ct_radix(int N, int i) {
 constexpr int ct_ns(int N, int i) { int ns = 1; for (int k = 0; k < i; ++k) ns *= ct_radix(N, k); return ns; }   // product of the earlier radices
 constexpr int ct_ld(int N) { return pad(N) + ((8 - pad(N) % 32) + 32) % 32; }                        // row stride, 8 (mod 32) slots
 template <typename T> constexpr int ct_S() { return 64 / (int)sizeof(cx<T>); }                       // sequences (= wavefronts) per workgroup
-template <typename T> constexpr size_t ct_lds(int N, int rowsets = 1) { return ((size_t)(N / 2) + (size_t)rowsets * ct_S<T>() * ct_ld(N)) * sizeof(cx<T>); }
+template <typename T> constexpr size_t ct_lds(int N, int rowsets = 1, int S = ct_S<T>()) { return ((size_t)(N / 2) + (size_t)rowsets * S * ct_ld(N)) * sizeof(cx<T>); }
+// columns per workgroup of the delta-stage kernel (two LDS rows per column): the usual count, or half of it where that does not fit (Ny > ~1150;
+// the transposed side then moves 32-byte pieces)
+template <typename T> constexpr int ct_S2(int N) { return ct_lds<T>(N, 2) <= 160 * 1024 ? ct_S<T>() : ct_S<T>() / 2; }
 
 // fetch variants
 enum { CT_C = 0, CT_R1, CT_R2, CT_H1, CT_H2, CT_P1, CT_P2, CT_P3 };
@@ -224,9 +227,9 @@ constexpr int ct_chunk(int E, int kind, bool flag) {
   const int nch = (E + ch - 1) / ch;
   return (E + nch - 1) / nch;
 }
-template <typename T, int N, int KIND, bool FLAG>
+template <typename T, int N, int KIND, bool FLAG, int S = ct_S<T>()>
 __device__ __forceinline__ void ct_fetch(const GenDft<T>& a, cx<T>* __restrict__ s, size_t sl, int seq0, bool by_seq) {
-  constexpr int S = ct_S<T>(), LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), E = (N + 63) / 64, CH = ct_chunk(E, KIND, FLAG), NCH = (E + CH - 1) / CH;
+  constexpr int LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), E = (N + 63) / 64, CH = ct_chunk(E, KIND, FLAG), NCH = (E + CH - 1) / CH;
   const int tid = threadIdx.x;
   constexpr bool WB = KIND == CT_P1 || KIND == CT_P2;                    // kinds that write back to memory
   constexpr int WBN = E <= 16 ? NCH : 1;                                 // chunks whose write-backs are held back (all of them up to 16 elements per thread)
@@ -312,9 +315,9 @@ __device__ __forceinline__ void ct_put(const GenDft<T>& a, size_t sl, int seq, i
 }
 
 // Stores: all LDS reads of the thread first, then the global stores (a read-store loop waits for LDS once per element)
-template <typename T, int N>
+template <typename T, int N, int S = ct_S<T>()>
 __device__ __forceinline__ void ct_store_rows(const GenDft<T>& a, const cx<T>* __restrict__ s, size_t sl, int seq0, bool out_by_seq, int wave, int lane, bool mid) {
-  constexpr int S = ct_S<T>(), LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N);
+  constexpr int LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N);
   const bool split = a.in_real && a.in2;
   constexpr int E = (N + 63) / 64, NPC = (E + 11) / 12, PCH = (E + NPC - 1) / NPC;
 #pragma unroll
@@ -403,15 +406,15 @@ __device__ __forceinline__ void ct_flow_stage(const GenDft<T>& a, cx<T>* __restr
 
 template <typename T> constexpr int ct_min_waves() { return sizeof(T) == 4 ? 4 : 2; }       // two workgroups per CU
 
-template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft(GenDft<T> a, int kind) {
+template <typename T, int N, bool CONLY = false /*complex in, complex out only (x passes): no other fetch variant is compiled in*/>
+__device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsigned ysl) {
   constexpr int S = ct_S<T>(), LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
   const bool in_by_seq = a.in_elem != 1, out_by_seq = a.out_elem != 1;
   const int seq0 = ((in_by_seq || out_by_seq) ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * S;
-  const size_t sl = gen_slice(a);
+  const size_t sl = gen_slice(a, ysl);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef CMBL_STAMPS_CT
   const bool stamp = (kind >> 8) != 0;
@@ -420,7 +423,8 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft(Ge
   CMBL_CT_STAMP(14); CMBL_CT_STAMP(0);
   TwStage<T, NT, NTW> twr;
   twr.issue(a.tw);
-  switch (kind) {                                                        // uniform: one straight-line fetch per variant
+  if constexpr (CONLY) ct_fetch<T, N, CT_C, false>(a, s, sl, seq0, in_by_seq);
+  else switch (kind) {                                                   // uniform: one straight-line fetch per variant
     case CT_C: ct_fetch<T, N, CT_C, false>(a, s, sl, seq0, in_by_seq); break;
     case CT_R1: ct_fetch<T, N, CT_R1, false>(a, s, sl, seq0, in_by_seq); break;
     case CT_R2: ct_fetch<T, N, CT_R2, false>(a, s, sl, seq0, in_by_seq); break;
@@ -455,6 +459,15 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft(Ge
   CMBL_CT_STAMP(5);
   ct_store_rows<T, N>(a, s, sl, seq0, out_by_seq, wave, lane, a.lmul_mid != nullptr);
   CMBL_CT_STAMP(6); CMBL_CT_STAMP(15);
+}
+template <typename T, int N>
+__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft(GenDft<T> a, int kind) { ct_dft_body<T, N>(a, kind, blockIdx.y); }
+// Two independent transform launches of the same length as one (grid.y = ny0 + the second's): the two x passes that open a delta-flow
+// stage -- ifft_x(delta f) and the d/dx pass of rfft_y(f) -- have no dependence on each other.
+template <typename T, int N>
+__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft2(GenDft<T> a0, int kind0, int ny0, GenDft<T> a1, int kind1) {
+  if ((int)blockIdx.y < ny0) ct_dft_body<T, N, true>(a0, kind0, blockIdx.y);
+  else ct_dft_body<T, N, true>(a1, kind1, blockIdx.y - (unsigned)ny0);
 }
 
 // The y passes of a forward flow stage in one launch (GenDft::yy; Ctx::gen_y_flow_stage): pair-c2r fetch, ct_flow_stage on every column,
@@ -533,8 +546,8 @@ __device__ __forceinline__ void ct_delta_stage(const GenDft<T>& a, cx<T>* __rest
   ct_transform<T, N>(r2, tw, lane);
 }
 template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_delta_y(GenDft<T> a) {
-  constexpr int S = ct_S<T>(), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
+__global__ __launch_bounds__(64 * ct_S2<T>(N)) void k_ct_delta_y(GenDft<T> a) {
+  constexpr int S = ct_S2<T>(N), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
@@ -544,11 +557,11 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_de
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   TwStage<T, NT, NTW> twr;
   twr.issue(a.tw);
-  ct_fetch<T, N, CT_H2, true>(a, s, sl, seq0, true);
+  ct_fetch<T, N, CT_H2, true, S>(a, s, sl, seq0, true);
   {
     GenDft<T> a3 = a;                                                    // ifft_x(delta f): a single half plane, no multiplier
     a3.in = a.yy_in3; a3.in2 = nullptr; a3.lmul_in = nullptr;
-    ct_fetch<T, N, CT_H1, false>(a3, s2, sl, seq0, true);
+    ct_fetch<T, N, CT_H1, false, S>(a3, s2, sl, seq0, true);
   }
   twr.commit(tw);
   __syncthreads();
@@ -557,9 +570,9 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_de
   GenDft<T> b{};                                                         // store side, [ky][x] like the inputs
   b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1); b.scale2 = T(1);
   b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
-  if (!a.yy_last) { b.out = a.yy_out; ct_store_rows<T, N>(b, s, sl, seq0, true, wave, lane, false); }
+  if (!a.yy_last) { b.out = a.yy_out; ct_store_rows<T, N, S>(b, s, sl, seq0, true, wave, lane, false); }
   b.out = a.yy_out2; b.out2 = a.yy_out3; b.in2 = a.yy_out3;              // in2 != nullptr marks the pair split (ct_put)
-  ct_store_rows<T, N>(b, s2, sl, seq0, true, wave, lane, false);
+  ct_store_rows<T, N, S>(b, s2, sl, seq0, true, wave, lane, false);
 }
 
 // The y passes of an adjoint flow stage in one launch (GenDft::yy = 3; Ctx::gen_y_adj_stage): c2r of yy_in3 = ifft_x(y) -> the map y, the

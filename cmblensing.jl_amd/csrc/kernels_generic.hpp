@@ -93,8 +93,7 @@ template <typename T> struct GenDft {
   const void* yy_in3; void* yy_out2; void* yy_out3;
   T yy_scale3;
 };
-template <typename T> __device__ __forceinline__ size_t gen_slice(const GenDft<T>& a) {
-  const unsigned y = blockIdx.y;
+template <typename T> __device__ __forceinline__ size_t gen_slice(const GenDft<T>& a, unsigned y = blockIdx.y) {
   return a.sln ? (size_t)a.sl0 + (y % (unsigned)a.sln) + (size_t)(y / (unsigned)a.sln) * (unsigned)a.slstride : (size_t)y;
 }
 
