@@ -436,6 +436,25 @@ struct Ctx : CtxBase {
     }
     fail(ERR_STATE, "fused delta-stage y passes need a compile-time plan for Ny that fits LDS twice");
   }
+  // fft_x of the pair (W2a, W2b) and the RK update of the Fourier state (Y0, acc -> Ys) with k = i lx Fx + i ly Fy in ONE launch where the x axis has
+  // a compile-time plan; false: not available (the caller runs the x transform and k_gen_adj_rk)
+  bool gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices) {
+    if (!opts.gen_ct || !opts.gen_yy || genX.plan.nf == 0) return false;
+    GenDft<T> a{};
+    a.in = W2a; a.in2 = W2b; a.nin = Nx; a.nout = Nx; a.nseq = Nyh; a.scale = 1;
+    a.in_seq = Nx; a.in_elem = 1; a.in_slice = plane(); a.out_seq = Nx; a.out_elem = 1; a.out_slice = plane();
+    a.pro.rk = rk; a.yy_out = Y0; a.out2 = acc_; a.out = Ys; a.lmul_out = lx_r.template as<T>(); a.lmul_in = ly.template as<T>();
+    slices = gen_window(a, slices);
+    a.N = Nx; a.tw = genX.twN.template as<cx<T>>(); a.S = ct_S<T>();
+    const int R = ct_S<T>() / 2;
+    const dim3 grid((unsigned)((a.nseq + R - 1) / R), (unsigned)slices);
+    switch (Nx) {
+#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x<T, n>), grid, ct_lds<T>(n), stream, a); return true;
+      CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+      default: return false;
+    }
+  }
   // t3 = ifft_x(F) (unnormalised) and gx = ifft_x(i lx fft_x(A)) in ONE launch where the x axis has a compile-time plan (else two launches)
   void gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices) {
     bool ct = opts.gen_ct && opts.gen_xderiv_fused && genX.plan.nf > 0;
@@ -1171,6 +1190,7 @@ struct Flow {
             cx<T>* t3 = c->mixed_scratch(slices);
             c->gen_x(gYs.as<cx<T>>(), t3, true, nullptr, slices);
             c->gen_y_adj_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), ph(rk.t), rk.t, P, gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, slices);
+            if (c->gen_x_adj_update(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices)) continue;
             c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
             CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
                         c->ly.template as<T>(), c->Nx, out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, pl, wsl0());
@@ -1220,6 +1240,7 @@ struct Flow {
             c->gen_y_delta_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), gGx.as<cx<T>>(), gA.as<cx<T>>(), c->ly.template as<T>(),
                                  (T)(1.0 / ((double)c->Ny * c->Nx)), (T)(1.0 / (double)c->Ny), e, gA.as<cx<T>>(), gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl,
                                  rk.last != 0, slices);
+            if (c->gen_x_adj_update(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices)) continue;
             c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
             CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
                         c->ly.template as<T>(), c->Nx, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, pl, wsl0());

@@ -631,4 +631,59 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_ad
   ct_store_rows<T, N>(b, s, sl, seq0, true, wave, lane, false);
 }
 
+// The x pass that closes an adjoint-type stage in one launch (Ctx::gen_x_adj_update): fft_x of both members of the velocity pair and the RK
+// update of the Fourier state, k = i lx Fx + i ly Fy (src/lenseflow.jl:163-174; k_gen_adj_rk).  A workgroup takes S/2 adjacent ky rows of
+// both members (wave w: member w / (S/2), row w % (S/2)); after the transforms the two wavefronts of a row share its kx range in alternating
+// 64-element pieces.  a.in / a.in2: the pair; a.yy_out / a.out2 / a.out: Y0 / acc / Ys; a.lmul_out / a.lmul_in: lx / ly.
+template <typename T, int N>
+__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_adj_x(GenDft<T> a) {
+  constexpr int S = ct_S<T>(), R = S / 2, NT = 64 * S, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64, EH = (E + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* s = tw + NTW;
+  const size_t sl = gen_slice(a), sb = sl * a.in_slice;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = wave / R, r = wave % R, ky = blockIdx.x * R + r;
+  const bool live = ky < a.nseq;
+  const int kyc = live ? ky : a.nseq - 1;
+  TwStage<T, NT, NTW> twr;
+  twr.issue(a.tw);
+  const RKCoef<T> rk = a.pro.rk;
+  const cx<T>* Y0 = reinterpret_cast<const cx<T>*>(a.yy_out) + sb;
+  const cx<T>* Ac = reinterpret_cast<const cx<T>*>(a.out2) + sb;
+  cx<T> v[E] = {}, y0v[EH] = {}, acv[EH] = {};
+  {
+    const cx<T>* src = reinterpret_cast<const cx<T>*>(m ? a.in2 : a.in) + sb;
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = at32(src, (unsigned)kyc * (unsigned)N + (unsigned)min(lane + 64 * i, N - 1));
+#pragma unroll
+    for (int j = 0; j < EH; ++j) {                                       // the RK operands of this wavefront's share, requested up front
+      const unsigned o = (unsigned)kyc * (unsigned)N + (unsigned)min(lane + 64 * (2 * j + m), N - 1);
+      y0v[j] = at32(Y0, o); acv[j] = at32(Ac, o);
+    }
+  }
+  cx<T>* row = s + wave * LD;
+#pragma unroll
+  for (int i = 0; i < E; ++i) { const int n = lane + 64 * i; if (N % 64 == 0 || n < N) row[pad(n)] = v[i]; }
+  twr.commit(tw);
+  __syncthreads();
+  if (live) ct_transform<T, N>(row, tw, lane);
+  __syncthreads();
+  if (!live) return;
+  const T l_y = a.lmul_in[ky];
+  cx<T>* Ys = reinterpret_cast<cx<T>*>(a.out) + sb;
+  cx<T>* dst = (rk.stage == 4 ? reinterpret_cast<cx<T>*>(a.yy_out) : reinterpret_cast<cx<T>*>(a.out2)) + sb;
+#pragma unroll
+  for (int j = 0; j < EH; ++j) {
+    const int k = lane + 64 * (2 * j + m);
+    if (2 * j + m < E && (N % 64 == 0 || k < N)) {
+      const cx<T> kv = mul_il(s[r * LD + pad(k)], a.lmul_out[k]) + mul_il(s[(R + r) * LD + pad(k)], l_y);
+      cx<T> y = y0v[j], ac = rk.stage == 1 ? mk<T>(T(0), T(0)) : acv[j];
+      const cx<T> nxt = rk_update(rk, kv, y, ac);
+      const unsigned o = (unsigned)ky * (unsigned)N + (unsigned)k;
+      at32(dst, o) = rk.stage == 4 ? y : ac;
+      at32(Ys, o) = nxt;
+    }
+  }
+}
+
 }  // namespace cmbl
