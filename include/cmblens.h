@@ -85,8 +85,8 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *        "gen_separable", "gen_prologue", "gen_xderiv_fused"       any-size path stage fusions (CMBL_GEN_SEPARABLE / _PROLOGUE / _XDERIV_FUSED, all 1)
  *        "gen_ct"                                                   any-size path: compile-time-plan transforms for the lengths 2^a 3^b 5^c of
  *                                                                   CMBL_CT_LIST (CMBL_GEN_CT, 1; 0 = the run-time-planned kernel for every length)
- *        "gen_yy"                                                   any-size flows: the y passes of a stage in one launch where Ny has a
- *                                                                   compile-time plan (CMBL_GEN_YY, 1; results bit-identical either way)
+ *        "gen_yy"                                                   any-size flows: the passes of a stage that can share a launch do, where the axes have
+ *                                                                   compile-time plans (CMBL_GEN_YY, 1; results bit-identical either way)
  *        "gen_slice_streams", "gen_streams_min_pix"                 any-size flows: one launch chain per group of slices from this many pixels
  *                                                                   on (CMBL_GEN_SLICE_STREAMS 1, CMBL_GEN_STREAMS_MIN_PIX 2^21)
  *        "occupancy_tiles"       CMBL_OCCUPANCY_TILES (3)          small maps: bit 0 = two-column tiles when four-column tiles leave CUs idle or unevenly loaded, bit 1 = shorter row groups
