@@ -429,7 +429,7 @@ struct Ctx : CtxBase {
     a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S2<T>(Ny);
     const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
     switch (Ny) {
-#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2, ct_S2<T>(n)) <= 160 * 1024) { CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S2<T>(n), (k_ct_delta_y<T, n>), grid, ct_lds<T>(n, 2, ct_S2<T>(n)), stream, a); return; } break;
+#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2, ct_S2<T>(n)) <= 160 * 1024) { CMBL_LAUNCH_NT(this, K_GEN_DFT, 128 * ct_S2<T>(n), (k_ct_delta_y<T, n>), grid, ct_lds<T>(n, 2, ct_S2<T>(n)), stream, a); return; } break;
       CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
       default: break;

@@ -228,9 +228,8 @@ constexpr int ct_chunk(int E, int kind, bool flag) {
   return (E + nch - 1) / nch;
 }
 template <typename T, int N, int KIND, bool FLAG, int S = ct_S<T>()>
-__device__ __forceinline__ void ct_fetch(const GenDft<T>& a, cx<T>* __restrict__ s, size_t sl, int seq0, bool by_seq) {
+__device__ __forceinline__ void ct_fetch(const GenDft<T>& a, cx<T>* __restrict__ s, size_t sl, int seq0, bool by_seq, int tid = threadIdx.x) {
   constexpr int LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), E = (N + 63) / 64, CH = ct_chunk(E, KIND, FLAG), NCH = (E + CH - 1) / CH;
-  const int tid = threadIdx.x;
   constexpr bool WB = KIND == CT_P1 || KIND == CT_P2;                    // kinds that write back to memory
   constexpr int WBN = E <= 16 ? NCH : 1;                                 // chunks whose write-backs are held back (all of them up to 16 elements per thread)
   T so[WB ? WBN * CH : 1][3];
@@ -316,7 +315,7 @@ __device__ __forceinline__ void ct_put(const GenDft<T>& a, size_t sl, int seq, i
 
 // Stores: all LDS reads of the thread first, then the global stores (a read-store loop waits for LDS once per element)
 template <typename T, int N, int S = ct_S<T>()>
-__device__ __forceinline__ void ct_store_rows(const GenDft<T>& a, const cx<T>* __restrict__ s, size_t sl, int seq0, bool out_by_seq, int wave, int lane, bool mid) {
+__device__ __forceinline__ void ct_store_rows(const GenDft<T>& a, const cx<T>* __restrict__ s, size_t sl, int seq0, bool out_by_seq, int wave, int lane, bool mid, int tid = threadIdx.x) {
   constexpr int LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N);
   const bool split = a.in_real && a.in2;
   constexpr int E = (N + 63) / 64, NPC = (E + 11) / 12, PCH = (E + NPC - 1) / NPC;
@@ -325,15 +324,15 @@ __device__ __forceinline__ void ct_store_rows(const GenDft<T>& a, const cx<T>* _
     cx<T> y[PCH], yr[PCH];
 #pragma unroll
     for (int ii = 0; ii < PCH; ++ii) {
-      const int i = c * PCH + ii, k0 = out_by_seq ? ((threadIdx.x + i * NT) >> LGS) : (lane + 64 * i), k = min(k0, a.nout - 1);
-      const cx<T>* p = s + (out_by_seq ? ((threadIdx.x + i * NT) & (S - 1)) : wave) * LD;
+      const int i = c * PCH + ii, k0 = out_by_seq ? ((tid + i * NT) >> LGS) : (lane + 64 * i), k = min(k0, a.nout - 1);
+      const cx<T>* p = s + (out_by_seq ? ((tid + i * NT) & (S - 1)) : wave) * LD;
       y[ii] = p[pad(k)];
       yr[ii] = p[pad(split && k ? N - k : 0)];                           // Z[N - k]: only the pair split reads it
     }
 #pragma unroll
     for (int ii = 0; ii < PCH; ++ii) {
-      const int i = c * PCH + ii, k = out_by_seq ? ((threadIdx.x + i * NT) >> LGS) : (lane + 64 * i);
-      const int seq = seq0 + (out_by_seq ? ((threadIdx.x + i * NT) & (S - 1)) : wave);
+      const int i = c * PCH + ii, k = out_by_seq ? ((tid + i * NT) >> LGS) : (lane + 64 * i);
+      const int seq = seq0 + (out_by_seq ? ((tid + i * NT) & (S - 1)) : wave);
       if (i < E && k < a.nout && seq < a.nseq) ct_put(a, sl, seq, k, mid ? conj(y[ii]) : y[ii], yr[ii]);
     }
   }
@@ -500,79 +499,81 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_fl
 // The four y passes of a delta-flow stage in one launch (GenDft::yy = 2; Ctx::gen_y_delta_stage): the c2r of ifft_x(delta f) -> L(df), the pair
 // c2r -> (d/dx f, d/dy f), the stage's pointwise work (src/lenseflow.jl:184-200: the products for the delta-phi quadrature, the f velocity
 // with its RK update, the pair (p_x, p_y) L(df)), rfft_y of the next f and the pair r2c of the delta-f velocity.  Two LDS rows per column
-// (rows 0..S-1: the gradient pair / next f; rows S..2S-1: L(df) / the velocity pair); a wavefront runs its column's four transforms.
+// (row set 0: the gradient pair / next f; row set 1: L(df) / the velocity pair) and TWO WAVEFRONTS per column, one per row set: the two
+// fetches, the two inverse transforms, the two forward transforms and the two stores each run side by side (the first version ran a
+// column's four transforms on one wavefront: 23.4 us per launch at 768^2, profiles/r05_kernel_stats_768QU_f32_anysize_pre2w.csv); the
+// pointwise part is split between them in alternating 64-pixel pieces.  Four workgroup barriers.
 template <typename T, int N>
-__device__ __forceinline__ void ct_delta_stage(const GenDft<T>& a, cx<T>* __restrict__ r1, cx<T>* __restrict__ r2, const cx<T>* __restrict__ tw, size_t sl, int seq, int lane) {
-  constexpr int E = (N + 63) / 64, PCH = E <= 8 ? E : (E + ((E + 7) / 8) - 1) / ((E + 7) / 8), NPC = (E + PCH - 1) / PCH;
-  const GenPro<T>& e = a.pro;
-  const size_t mb = sl * (size_t)e.npix, pb = (size_t)(e.ph.Bphi == 1 ? 0 : sl / e.P) * e.npix;
-  const bool pc = e.ph.pcx != nullptr;
-  ct_transform<T, N>(r1, tw, lane);
-  ct_transform<T, N>(r2, tw, lane);
-#pragma unroll
-  for (int c = 0; c < NPC; ++c) {
-    T px[PCH], py[PCH], y0v[PCH], acv[PCH];
-#pragma unroll
-    for (int ii = 0; ii < PCH; ++ii) {
-      const int n = min(lane + 64 * (c * PCH + ii), N - 1);
-      const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
-      y0v[ii] = at32(e.y0 + mb, o); acv[ii] = at32(e.acc + mb, o);
-      if (pc) { px[ii] = at32(e.ph.pcx + pb, o); py[ii] = at32(e.ph.pcy + pb, o); }
-      else {
-        T m11, m12, m22;
-        flow_pm(e.rk.t, at32(e.ph.gx + pb, o), at32(e.ph.gy + pb, o), at32(e.ph.hxx + pb, o), at32(e.ph.hyx + pb, o), at32(e.ph.hyy + pb, o), px[ii], py[ii], m11, m12, m22);
-      }
-    }
-#pragma unroll
-    for (int ii = 0; ii < PCH; ++ii) {
-      const int n0 = lane + 64 * (c * PCH + ii), n = min(n0, N - 1);
-      const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
-      const cx<T> z = r1[pad(n)], zl = r2[pad(n)];                       // e^{+i} transforms: the values are conj(z), conj(zl)
-      const T gx = a.scale * z.x, gy = -a.scale2 * z.y, l = a.yy_scale3 * zl.x;
-      const T k = px[ii] * gx + py[ii] * gy;
-      T y = y0v[ii], ac = e.rk.stage == 1 ? T(0) : acv[ii];
-      const T nxt = rk_update(e.rk, k, y, ac);
-      if ((N % 64 == 0 || n0 < N) && (c * PCH + ii) < E) {
-        at32(e.w1p + mb, o) = l * gx; at32(e.w2p + mb, o) = l * gy;
-        if (e.rk.stage == 4) at32(e.y0 + mb, o) = y; else at32(e.acc + mb, o) = ac;
-        r1[pad(n)] = mk<T>(nxt, T(0));
-        r2[pad(n)] = mk<T>(px[ii] * l, py[ii] * l);
-      }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (!a.yy_last) ct_transform<T, N>(r1, tw, lane);
-  ct_transform<T, N>(r2, tw, lane);
-}
-template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S2<T>(N)) void k_ct_delta_y(GenDft<T> a) {
-  constexpr int S = ct_S2<T>(N), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
+__global__ __launch_bounds__(128 * ct_S2<T>(N)) void k_ct_delta_y(GenDft<T> a) {
+  constexpr int S = ct_S2<T>(N), NTH = 64 * S, NT = 2 * NTH, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64, EH = (E + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
   cx<T>* s2 = s + S * LD;
   const int seq0 = xcd_tile(blockIdx.x, gridDim.x) * S;
   const size_t sl = gen_slice(a);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int set = threadIdx.x / NTH, tid = threadIdx.x % NTH, wave = tid >> 6, lane = tid & 63, seq = seq0 + wave;
   TwStage<T, NT, NTW> twr;
   twr.issue(a.tw);
-  ct_fetch<T, N, CT_H2, true, S>(a, s, sl, seq0, true);
-  {
+  if (set == 0) ct_fetch<T, N, CT_H2, true, S>(a, s, sl, seq0, true, tid);
+  else {
     GenDft<T> a3 = a;                                                    // ifft_x(delta f): a single half plane, no multiplier
     a3.in = a.yy_in3; a3.in2 = nullptr; a3.lmul_in = nullptr;
-    ct_fetch<T, N, CT_H1, false, S>(a3, s2, sl, seq0, true);
+    ct_fetch<T, N, CT_H1, false, S>(a3, s2, sl, seq0, true, tid);
   }
   twr.commit(tw);
+  const bool live = seq < a.nseq;
+  const GenPro<T>& e = a.pro;
+  const size_t mb = sl * (size_t)e.npix, pb = (size_t)(e.ph.Bphi == 1 ? 0 : sl / e.P) * e.npix;
+  const bool pc = e.ph.pcx != nullptr;
+  cx<T>* r1 = s + wave * LD;
+  cx<T>* r2 = s2 + wave * LD;
+  // this wavefront's share of the column's pixels: pieces i = 2 j + set; their operands are requested before the transform
+  T px[EH], py[EH], y0v[EH], acv[EH];
+  const int seqc = live ? seq : a.nseq - 1;
+#pragma unroll
+  for (int j = 0; j < EH; ++j) {
+    const unsigned o = (unsigned)seqc * (unsigned)N + (unsigned)min(lane + 64 * (2 * j + set), N - 1);
+    y0v[j] = at32(e.y0 + mb, o); acv[j] = at32(e.acc + mb, o);
+    if (pc) { px[j] = at32(e.ph.pcx + pb, o); py[j] = at32(e.ph.pcy + pb, o); }
+    else {
+      T m11, m12, m22;
+      flow_pm(e.rk.t, at32(e.ph.gx + pb, o), at32(e.ph.gy + pb, o), at32(e.ph.hxx + pb, o), at32(e.ph.hyx + pb, o), at32(e.ph.hyy + pb, o), px[j], py[j], m11, m12, m22);
+    }
+  }
   __syncthreads();
-  if (seq0 + wave < a.nseq) ct_delta_stage<T, N>(a, s + wave * LD, s2 + wave * LD, tw, sl, seq0 + wave, lane);
+  if (live) ct_transform<T, N>(set ? r2 : r1, tw, lane);
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < EH; ++j) {
+      const int n = lane + 64 * (2 * j + set);
+      if (2 * j + set < E && (N % 64 == 0 || n < N)) {
+        const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+        const cx<T> z = r1[pad(n)], zl = r2[pad(n)];                     // e^{+i} transforms: the values are conj(z), conj(zl)
+        const T gx = a.scale * z.x, gy = -a.scale2 * z.y, l = a.yy_scale3 * zl.x;
+        const T k = px[j] * gx + py[j] * gy;
+        T y = y0v[j], ac = e.rk.stage == 1 ? T(0) : acv[j];
+        const T nxt = rk_update(e.rk, k, y, ac);
+        at32(e.w1p + mb, o) = l * gx; at32(e.w2p + mb, o) = l * gy;
+        if (e.rk.stage == 4) at32(e.y0 + mb, o) = y; else at32(e.acc + mb, o) = ac;
+        r1[pad(n)] = mk<T>(nxt, T(0));
+        r2[pad(n)] = mk<T>(px[j] * l, py[j] * l);
+      }
+    }
+  }
+  __syncthreads();
+  if (live && !(set == 0 && a.yy_last)) ct_transform<T, N>(set ? r2 : r1, tw, lane);
   __syncthreads();
   GenDft<T> b{};                                                         // store side, [ky][x] like the inputs
   b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1); b.scale2 = T(1);
   b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
-  if (!a.yy_last) { b.out = a.yy_out; ct_store_rows<T, N, S>(b, s, sl, seq0, true, wave, lane, false); }
-  b.out = a.yy_out2; b.out2 = a.yy_out3; b.in2 = a.yy_out3;              // in2 != nullptr marks the pair split (ct_put)
-  ct_store_rows<T, N, S>(b, s2, sl, seq0, true, wave, lane, false);
+  if (set == 0) {
+    if (!a.yy_last) { b.out = a.yy_out; ct_store_rows<T, N, S>(b, s, sl, seq0, true, wave, lane, false, tid); }
+  } else {
+    b.out = a.yy_out2; b.out2 = a.yy_out3; b.in2 = a.yy_out3;            // in2 != nullptr marks the pair split (ct_put)
+    ct_store_rows<T, N, S>(b, s2, sl, seq0, true, wave, lane, false, tid);
+  }
 }
 
 // The y passes of an adjoint flow stage in one launch (GenDft::yy = 3; Ctx::gen_y_adj_stage): c2r of yy_in3 = ifft_x(y) -> the map y, the
