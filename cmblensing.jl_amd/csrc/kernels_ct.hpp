@@ -678,10 +678,11 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_adj_x(
     const int k = lane + 64 * (2 * j + m);
     if (2 * j + m < E && (N % 64 == 0 || k < N)) {
       const cx<T> kv = mul_il(s[r * LD + pad(k)], a.lmul_out[k]) + mul_il(s[(R + r) * LD + pad(k)], l_y);
-      cx<T> y = y0v[j], ac = rk.stage == 1 ? mk<T>(T(0), T(0)) : acv[j];
+      cx<T> y = y0v[j], ac = acv[j];
+      if (rk.stage == 1) { ac.x = T(0); ac.y = T(0); }                   // (member-wise: a select between aggregates goes through scratch memory in double precision)
       const cx<T> nxt = rk_update(rk, kv, y, ac);
       const unsigned o = (unsigned)ky * (unsigned)N + (unsigned)k;
-      at32(dst, o) = rk.stage == 4 ? y : ac;
+      if (rk.stage == 4) at32(dst, o) = y; else at32(dst, o) = ac;
       at32(Ys, o) = nxt;
     }
   }
