@@ -294,56 +294,8 @@ struct Ctx : CtxBase {
     return slices / gwall * gwn;
   }
   // lengths with a compile-time plan (kernels_ct.hpp): one wavefront per sequence, S = 64 bytes of sequences per workgroup
-  bool gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
-    a.N = ax.N; a.tw = ax.twN.template as<cx<T>>(); a.S = ct_S<T>();
-    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
-    int kind = ct_kind(a);
-#ifdef CMBL_STAMPS_CT
-    static const int stamp_kind = env_int("CMBL_CT_STAMP_KIND", -1);
-    if (kind + (a.lmul_mid ? 8 : 0) == stamp_kind) kind |= 256;
-#endif
-    switch (ax.N) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft<T, n>), grid, ct_lds<T>(n), stream, a, kind); return true;
-      CMBL_CT_LIST(CMBL_X)
-#undef CMBL_X
-      default: return false;
-    }
-  }
-  void gen_dft(const GenAxis& ax, GenDft<T> a, long slices) {
-    slices = gen_window(a, slices);
-    if (ax.plan.nf > 0 && opts.gen_ct && gen_dft_ct(ax, a, slices)) return;
-    if (ax.plan.nf > 0) {
-      a.N = ax.N; a.tw = ax.twN.template as<cx<T>>();
-      // sequences per workgroup: enough of them for coalesced strided access, but not so many that the launch has fewer than a few
-      // workgroups per CU (small maps); the two LDS buffers + the twiddle table within 64 KB
-      auto lds_of = [&](int S, bool tw) { return ((size_t)2 * S * ax.N + (tw ? ax.N : 0)) * sizeof(cx<T>); };
-      int minR = 13; bool big = false;
-      for (int i = 0; i < ax.plan.nf; ++i) { minR = std::min(minR, ax.plan.radix[i]); big = big || ax.plan.radix[i] > 5; }
-      const long total = (long)a.nseq * slices;
-      const bool strided = a.in_elem != 1 || a.out_elem != 1;
-      a.S = (int)std::max<long>(1, std::min<long>(std::min(16, 2048 / ax.N), total / (4L * num_cus)));
-      while (a.S > 1 && lds_of(a.S, true) > 64 * 1024) --a.S;
-      // a strided side is read / written in pieces of S elements: at least 64 bytes of them, in one large workgroup per CU
-      const int Smin = 64 / (int)sizeof(cx<T>);
-      if (strided && !big && a.S < Smin && total >= (long)Smin * num_cus / 2 && lds_of(Smin, false) <= 150 * 1024) a.S = Smin;
-      const bool tw_lds = lds_of(a.S, true) <= 158 * 1024;
-      const int nthr = std::max(64, std::min(big ? NTP : 1024, ((a.S * ax.N / minR + 63) / 64) * 64));
-      const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
-      if (big) CMBL_LAUNCH_NT(this, K_GEN_DFT, nthr, (k_gen_dft_mr<T, true>), grid, lds_of(a.S, tw_lds), stream, a, ax.plan, tw_lds ? 1 : 0);
-      else CMBL_LAUNCH_NT(this, K_GEN_DFT, nthr, (k_gen_dft_mr<T, false>), grid, lds_of(a.S, tw_lds), stream, a, ax.plan, tw_lds ? 1 : 0);
-      return;
-    }
-    const int L = 1 << ax.lgL;
-    a.chirp = ax.chirp.template as<cx<T>>(); a.bhat = ax.bhat.template as<cx<T>>(); a.tw = ax.tw.template as<cx<T>>(); a.N = ax.N;
-    a.S = std::max(1, std::min(8, 2048 / L));
-    const size_t lds = (size_t)a.S * tile_ld(L) * sizeof(cx<T>);
-    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
-    bool done = false;
-#define CMBL_X(lg) if (!done && ax.lgL == lg) { CMBL_LAUNCH(this, K_GEN_DFT, (k_gen_dft<T, lg>), grid, lds, stream, a); done = true; }
-    CMBL_GEN_LIST(CMBL_X)
-#undef CMBL_X
-    if (!done) fail(ERR_SHAPE, "unsupported transform length");
-  }
+  bool gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
+  void gen_dft(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   void gen_rfft2(const T* map, cx<T>* F, long slices) {
     cx<T>* tmp = mixed_scratch(slices);
     GenDft<T> a{};                                                          // y: map [x][y] -> tmp [ky][x]
@@ -396,104 +348,19 @@ struct Ctx : CtxBase {
   }
   // pair c2r of (G1, i ly G2) + the stage's velocity / RK update on the maps of `pro` + rfft_y of the next stage input -> Anext, one launch
   // (GenDft::yy, kernels_ct.hpp ct_flow_stage); last: the flow ends, only y0 is updated
-  void gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, bool last, long slices) {
-    GenDft<T> a{};
-    a.pro = pro;
-    a.in = G1; a.in2 = G2; a.lmul_in = lmul2; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx;
-    a.scale = s1; a.scale2 = s2;
-    a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
-    a.yy = 1; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext;
-    slices = gen_window(a, slices);
-    a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S<T>();
-    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
-    switch (Ny) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_flow_y<T, n>), grid, ct_lds<T>(n), stream, a); return;
-      CMBL_CT_LIST(CMBL_X)
-#undef CMBL_X
-      default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
-    }
-  }
+  void gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, bool last, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // ... and the four y passes of a delta-flow stage (two LDS rows per column: up to Ny ~ 1150)
   bool gen_ct_y2() const { return gen_ct_y() && ct_lds<T>(Ny, 2, ct_S2<T>(Ny)) <= 160 * 1024; }
   // c2r of T3 = ifft_x(delta f) -> L(df), pair c2r of (G1, i ly G2) -> grad f, the delta stage's pointwise work on the maps of `pro`
   // (w1p, w2p, y0, acc), rfft_y of the next f -> Anext, pair r2c of (p_x, p_y) L(df) -> (W2a, W2b): one launch (k_ct_delta_y)
-  void gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext,
-                         cx<T>* W2a, cx<T>* W2b, bool last, long slices) {
-    GenDft<T> a{};
-    a.pro = pro;
-    a.in = G1; a.in2 = G2; a.lmul_in = lmul2; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx;
-    a.scale = s1; a.scale2 = s2;
-    a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
-    a.yy = 2; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext; a.yy_in3 = T3; a.yy_scale3 = s3; a.yy_out2 = W2a; a.yy_out3 = W2b;
-    slices = gen_window(a, slices);
-    a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S2<T>(Ny);
-    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
-    switch (Ny) {
-#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2, ct_S2<T>(n)) <= 160 * 1024) { CMBL_LAUNCH_NT(this, K_GEN_DFT, 128 * ct_S2<T>(n), (k_ct_delta_y<T, n>), grid, ct_lds<T>(n, 2, ct_S2<T>(n)), stream, a); return; } break;
-      CMBL_CT_LIST(CMBL_X)
-#undef CMBL_X
-      default: break;
-    }
-    fail(ERR_STATE, "fused delta-stage y passes need a compile-time plan for Ny that fits LDS twice");
-  }
+  void gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext,                          cx<T>* W2a, cx<T>* W2b, bool last, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // fft_x of the pair (W2a, W2b) and the RK update of the Fourier state (Y0, acc -> Ys) with k = i lx Fx + i ly Fy in ONE launch where the x axis has
   // a compile-time plan; false: not available (the caller runs the x transform and k_gen_adj_rk)
-  bool gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices) {
-    if (!opts.gen_ct || !opts.gen_yy || genX.plan.nf == 0) return false;
-    GenDft<T> a{};
-    a.in = W2a; a.in2 = W2b; a.nin = Nx; a.nout = Nx; a.nseq = Nyh; a.scale = 1;
-    a.in_seq = Nx; a.in_elem = 1; a.in_slice = plane(); a.out_seq = Nx; a.out_elem = 1; a.out_slice = plane();
-    a.pro.rk = rk; a.yy_out = Y0; a.out2 = acc_; a.out = Ys; a.lmul_out = lx_r.template as<T>(); a.lmul_in = ly.template as<T>();
-    slices = gen_window(a, slices);
-    a.N = Nx; a.tw = genX.twN.template as<cx<T>>(); a.S = ct_S<T>();
-    const int R = ct_S<T>() / 2;
-    const dim3 grid((unsigned)((a.nseq + R - 1) / R), (unsigned)slices);
-    switch (Nx) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x<T, n>), grid, ct_lds<T>(n), stream, a); return true;
-      CMBL_CT_LIST(CMBL_X)
-#undef CMBL_X
-      default: return false;
-    }
-  }
+  bool gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // t3 = ifft_x(F) (unnormalised) and gx = ifft_x(i lx fft_x(A)) in ONE launch where the x axis has a compile-time plan (else two launches)
-  void gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices) {
-    bool ct = opts.gen_ct && opts.gen_xderiv_fused && genX.plan.nf > 0;
-    if (ct) {
-      GenDft<T> a0{}, a1{};
-      a0.in = F; a0.out = t3; a0.nin = Nx; a0.nout = Nx; a0.nseq = Nyh; a0.scale = 1; a0.inverse = 1;
-      a0.in_seq = Nx; a0.in_elem = 1; a0.in_slice = plane(); a0.out_seq = Nx; a0.out_elem = 1; a0.out_slice = plane();
-      a1 = a0; a1.in = A_; a1.out = gx; a1.inverse = 0; a1.lmul_mid = lx;
-      const long ws = gen_window(a0, slices);
-      (void)gen_window(a1, slices);
-      a0.N = a1.N = Nx; a0.tw = a1.tw = genX.twN.template as<cx<T>>(); a0.S = a1.S = ct_S<T>();
-      const dim3 grid((unsigned)((a0.nseq + a0.S - 1) / a0.S), (unsigned)(2 * ws));
-      switch (Nx) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft2<T, n>), grid, ct_lds<T>(n), stream, a0, ct_kind(a0), (int)ws, a1, ct_kind(a1)); return;
-        CMBL_CT_LIST(CMBL_X)
-#undef CMBL_X
-        default: break;
-      }
-    }
-    gen_x(F, t3, true, nullptr, slices);
-    gen_x_deriv(A_, gx, tmp, lx, slices);
-  }
+  void gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // c2r of T3 = ifft_x(y) -> y, (p_x y, p_y y) at stage time t, its pair r2c -> (W2a, W2b): the y passes of an adjoint stage in one launch
-  void gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, int P, cx<T>* W2a, cx<T>* W2b, long slices) {
-    GenDft<T> a{};
-    a.pro.ph = phm; a.pro.rk.t = t; a.pro.npix = npix(); a.pro.P = P;
-    a.in = T3; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx; a.scale = s3;
-    a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
-    a.yy = 3; a.yy_nout = Nyh; a.yy_out2 = W2a; a.yy_out3 = W2b;
-    slices = gen_window(a, slices);
-    a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S<T>();
-    const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
-    switch (Ny) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_y<T, n>), grid, ct_lds<T>(n), stream, a); return;
-      CMBL_CT_LIST(CMBL_X)
-#undef CMBL_X
-      default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
-    }
-  }
+  void gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, int P, cx<T>* W2a, cx<T>* W2b, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // out = ifft_x(i lx fft_x(in)) unnormalised, in ONE launch when the axis has a mixed-radix plan (else two: chirp-z transforms)
   bool gen_x_deriv(const cx<T>* in, cx<T>* out, cx<T>* tmp, const T* lx, long slices) {
     if (genX.plan.nf == 0 || !opts.gen_xderiv_fused) {

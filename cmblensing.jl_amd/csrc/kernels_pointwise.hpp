@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NTP) void k_sign_map(const T* __restrict__ d, unsig
   neg = block_sum<unsigned long long>(neg); zero = block_sum<unsigned long long>(zero);
   if (threadIdx.x == 0) { part2[2 * ((long)bt * gridDim.x + blockIdx.x)] = neg; part2[2 * ((long)bt * gridDim.x + blockIdx.x) + 1] = zero; }
 }
-__global__ __launch_bounds__(NTP) void k_sign_final(const unsigned long long* __restrict__ part2, double* __restrict__ inout, int nblk) {
+static __global__ __launch_bounds__(NTP) void k_sign_final(const unsigned long long* __restrict__ part2, double* __restrict__ inout, int nblk) {
   const int bt = blockIdx.x;
   unsigned long long neg = 0, zero = 0;
   for (int i = threadIdx.x; i < nblk; i += NTP) { neg += part2[2 * ((long)bt * nblk + i)]; zero += part2[2 * ((long)bt * nblk + i) + 1]; }
@@ -245,14 +245,14 @@ struct CgState {
   int *done, *nan, *nh, *better;
 };
 // after res = dot(r, z) of the start vector
-__global__ void k_cg_start(CgState s, int B) {
+static __global__ void k_cg_start(CgState s, int B) {
   if (threadIdx.x != 0) return;
   int nanf = 0;
   for (int b = 0; b < B; ++b) { s.best[b] = s.res[b]; s.hist[b] = s.res[b]; nanf |= isnan(s.res[b]); }
   *s.nh = 1; *s.done = 0; *s.better = 1; *s.nan = nanf;
 }
 // alpha = res / pAp  (:102)
-__global__ void k_cg_alpha(CgState s, int B) {
+static __global__ void k_cg_alpha(CgState s, int B) {
   if (threadIdx.x != 0 || *s.done) return;
   for (int b = 0; b < B; ++b) s.alpha[b] = s.res[b] / s.pAp[b];
 }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NTP) void k_cg_xr(T* __restrict__ x, T* __restrict_
   }
 }
 // beta = res' / res ; res = res' ; best-iterate bookkeeping, history, stop test  (:106-125)
-__global__ void k_cg_beta(CgState s, int B, double tol) {
+static __global__ void k_cg_beta(CgState s, int B, double tol) {
   if (threadIdx.x != 0) return;
   if (*s.done) { *s.better = 0; return; }
   int better = 1, done = 1, nanf = 0;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NTP) void k_max_step(const T* __restrict__ hp, cons
     part[(long)bt * gridDim.x + blockIdx.x] = r;
   }
 }
-__global__ __launch_bounds__(NTP) void k_min_final(const double* __restrict__ part, double* __restrict__ out, int nblk) {
+static __global__ __launch_bounds__(NTP) void k_min_final(const double* __restrict__ part, double* __restrict__ out, int nblk) {
   __shared__ double red[NTP / 64];
   const int bt = blockIdx.x;
   double best = 1e300;

@@ -33,19 +33,76 @@ def library_path():
     return os.environ.get("CMBL_LIB") or os.path.join(_HERE, "libcmblens_hip.so")
 
 
-def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU.  In-tree output: cmblensing.jl_amd/libcmblens_hip.so"""
-    src = os.path.join(_HERE, "csrc", "api.hip")
-    out = library_path()
-    deps = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
-    deps.append(os.path.join(_HERE, "..", "include", "cmblens.h"))
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-        return out
+# translation units of the library (csrc/api_decl.hpp has the map): the entry points, and per precision the typed bodies with the
+# power-of-two kernels and the any-size transform launches.  Built in parallel, one object each, then linked.
+UNITS = ["api", "tu_main_f32", "tu_main_f64", "tu_gen_f32", "tu_gen_f64"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def build(force=False, verbose=False, jobs=None, extra_flags=(), out=None, objdir=None):
+    """hipcc cross-compiles for gfx950 without a GPU.  In-tree output: cmblensing.jl_amd/libcmblens_hip.so
+
+    One object per translation unit under build/obj (git-ignored), compiled `jobs` at a time (default: all of them, they are fewer than the
+    cores of any box this runs on), re-compiled only when a source it includes (-MMD dependency file) or the flags changed.  `extra_flags`
+    / `out` / `objdir`: variant builds of the same sources (tools/devbuild.py)."""
+    csrc = os.path.join(_HERE, "csrc")
+    out = out or library_path()
+    objdir = objdir or os.path.join(_HERE, "..", "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    flags = HIPCC_FLAGS + list(extra_flags)
+    stamp = " ".join([hipcc] + flags)
+
+    def stale(unit):
+        obj, dep, flg = (os.path.join(objdir, unit + e) for e in (".o", ".d", ".flags"))
+        if force or not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(flg)) or open(flg).read() != stamp:
+            return True
+        deps = open(dep).read().replace("\\\n", " ").split(":", 1)[1].split()
+        t = os.path.getmtime(obj)
+        return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
+    todo = [u for u in UNITS if stale(u)]
+    procs, failed = [], []
+    jobs = jobs or int(os.environ.get("CMBL_BUILD_JOBS", "0")) or len(UNITS)
+
+    def reap(block):
+        for item in list(procs):
+            unit, p, log = item
+            if block or p.poll() is not None:
+                rc = p.wait()
+                log.close()
+                procs.remove(item)
+                if rc != 0:
+                    failed.append(unit)
+                else:
+                    open(os.path.join(objdir, unit + ".flags"), "w").write(stamp)
+                if not block:
+                    continue
+                return
+
+    for unit in todo:
+        while len(procs) >= jobs:
+            reap(True)
+        obj = os.path.join(objdir, unit + ".o")
+        cmd = [hipcc] + flags + ["-MMD", "-MF", os.path.join(objdir, unit + ".d"), "-c", os.path.join(csrc, unit + ".hip"), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        for e in (".flags",):
+            if os.path.exists(os.path.join(objdir, unit + e)):
+                os.remove(os.path.join(objdir, unit + e))
+        log = open(os.path.join(objdir, unit + ".log"), "w")
+        procs.append((unit, subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), log))
+    while procs:
+        reap(True)
+    if failed:
+        msgs = "".join(f"\n--- {u} ---\n" + open(os.path.join(objdir, u + ".log")).read()[-4000:] for u in failed)
+        raise RuntimeError("hipcc failed for " + ", ".join(failed) + msgs)
+    objs = [os.path.join(objdir, u + ".o") for u in UNITS]
+    if todo or not os.path.exists(out) or any(os.path.getmtime(o) > os.path.getmtime(out) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return out
 
 
