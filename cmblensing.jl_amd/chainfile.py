@@ -67,13 +67,20 @@ def _jld2_value(v):
     return v
 
 
-def _jld2_sample(state):
-    """Dict{Symbol,Any} state of the reference -> sample dict with this package's key names; a NamedTuple θ is flattened"""
+def _jld2_sample(state, own_legacy=False):
+    """Dict{Symbol,Any} state of the reference -> sample dict with this package's key names; a NamedTuple θ is flattened.
+    own_legacy: the file was written by THIS package (header stamp, `written_by_julia`) -- only then can the legacy key `i` be its round-4
+    writer's, which stored package numbering; in a file of the Julia package `i` carries the reference's numbering like `step`."""
     out = {}
     for k, v in state.items():
         v = _jld2_value(v)
         if k == "θ" and isinstance(v, dict):
             out.update({"theta_" + kk: vv for kk, vv in v.items()})
+        elif k == "i" and own_legacy:
+            # this package's first `.jld2` writer (round 4): `i` already in PACKAGE numbering (first Gibbs pass = step 1).  Re-expressed the way
+            # the reference numbers `step` (initial state = step 1) so that every reader below can shift uniformly (ADVICE r05: such a file
+            # used to be resumed one step early)
+            out["step"] = int(v) + 1
         else:
             out[JLD2_KEYS.get(k, k)] = v
     return out
@@ -172,7 +179,8 @@ def read_chunk(filename, index, dropmaps=False):
     if _is_jld2(filename):
         from .jld2 import to_python
         chains = to_python(_jld2(filename)[f"chunks_{index}"])            # Vector (chains) of Vector{Any} (samples) of Dict{Symbol,Any}
-        samples = [[_jld2_sample(s) for s in ch] for ch in chains]
+        own = not written_by_julia(filename)
+        samples = [[_jld2_sample(s, own) for s in ch] for ch in chains]
         if dropmaps:
             samples = [[{k: v for k, v in s.items() if np.ndim(v) == 0 and not isinstance(v, (dict, list))} for s in ch] for ch in samples]
         return samples

@@ -104,6 +104,7 @@ struct CtxBase {
     int occupancy_tiles = env_int("CMBL_OCCUPANCY_TILES", 3);             // bit 0: narrower column tiles, bit 1: shorter row groups
     int fill_target = env_int("CMBL_FILL_TARGET", 0);
     int row_fill_target = env_int("CMBL_ROW_FILL_TARGET", 0);
+    int small_flow = env_int("CMBL_SMALL_FLOW", 1);                       // small maps: a whole flow as ONE launch, one workgroup per slice (kernels_small.hpp): 0 off, 1 up to 64 x 64, 2 wherever compiled (128 x 128)
   } opts;
   int* opt_ptr(const std::string& k) {
     if (k == "slice_streams") return &opts.slice_streams;
@@ -123,6 +124,7 @@ struct CtxBase {
     if (k == "occupancy_tiles") return &opts.occupancy_tiles;
     if (k == "fill_target") return &opts.fill_target;
     if (k == "row_fill_target") return &opts.row_fill_target;
+    if (k == "small_flow") return &opts.small_flow;
     return nullptr;
   }
   double theta = 0;
@@ -924,6 +926,12 @@ struct Flow {
     return r;
   }
 
+  // Small maps: the whole flow in one launch, one workgroup per slice with the half plane resident in LDS (kernels_small.hpp; defined in
+  // engine_small.hpp, compiled by tu_small_*.hip).  small_ok: the shape has such a kernel in this precision and p(t) is cached.
+  bool small_ok() const;
+  void small_flow_map(const T* in, T* out, int P, int B, bool inverse);
+  void small_flow_adj(const cx<T>* in, cx<T>* out, int P, int B, bool inverse);
+
   void check_ready(int B) const {
     CMBL_REQUIRE(Bphi >= 1, ERR_STATE, "cmbl_lenseflow_set_phi has not been called");
     CMBL_REQUIRE(Bphi == 1 || Bphi == B, ERR_SHAPE, "nbatch of phi must be 1 or equal to nbatch of f");
@@ -1007,7 +1015,10 @@ struct Flow {
     if (sep) { gA.ensure(sizeof(cx<T>) * slices * pl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
     const int K = gen_groups(slices);
     const bool yy = sep && gen_pro() && c->opts.gen_yy && c->opts.gen_xderiv_fused && c->gen_ct_y();
-    if (yy) { gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); }
+    // every scratch buffer a stage can grow is sized BEFORE the chains fork: a growth (hipFree / hipMalloc) inside the multi-stream region
+    // would pull a buffer from under a launch of another chain (the separate-launch path used to ensure inside gen_grad_sep / gen_grad)
+    if (sep) { gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); if (!yy) gmxy.ensure(sizeof(T) * 2 * slices * np); }
+    else { gF.ensure(sizeof(cx<T>) * slices * pl); gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gmxy.ensure(sizeof(T) * 2 * slices * np); c->mixed_scratch(2 * slices); }
     fork(K);
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
@@ -1174,6 +1185,11 @@ struct Flow {
   void flow_map(const T* in, T* out, int P, int B, bool inverse, bool a_ready = false, bool emit_last = false, DevBuf* abuf = nullptr) {
     check_ready(B);
     if (c->generic) return gen_flow_map(in, out, P, B, inverse);
+    if (small_ok()) {                                                      // (a_ready: `in` itself is still the state; emit_last: one y pass more)
+      small_flow_map(in, out, P, B, inverse);
+      if (emit_last) c->y_r2c(out, abuf_ensure(abuf ? *abuf : A, (long)P * B), (long)P * B);
+      return;
+    }
     const long slices = (long)P * B, pl = c->mplane(), np = c->npix();          // A, Gx: mixed layout
     DevBuf& Ab = abuf ? *abuf : A;
     Ab.ensure(sizeof(cx<T>) * slices * pl); A2.ensure(sizeof(cx<T>) * slices * pl); Gx.ensure(sizeof(cx<T>) * slices * pl);
@@ -1216,6 +1232,7 @@ struct Flow {
   void flow_adj_F(const cx<T>* in, cx<T>* out, int P, int B, bool inverse, bool h_ready = false) {
     check_ready(B);
     if (c->generic) return gen_flow_adj_F(in, out, P, B, inverse);
+    if (small_ok()) return small_flow_adj(in, out, P, B, inverse);       // (h_ready: `in` itself is still the state)
     const long slices = (long)P * B, pl = c->plane(), mpl = c->mplane();
     H.ensure(sizeof(cx<T>) * slices * mpl); Wx.ensure(sizeof(cx<T>) * slices * mpl); Wy.ensure(sizeof(cx<T>) * slices * mpl);
     Yacc.ensure(sizeof(cx<T>) * slices * pl);

@@ -86,6 +86,10 @@ __device__ __forceinline__ void ct_stage(cx<T>* __restrict__ s, const cx<T>* __r
 #pragma unroll
     for (int m = 0; m < R; ++m) v[b][m] = vload(s + pad(j + m * nb));
   }
+  // The stage is IN PLACE with no workgroup barrier: lanes read slots that other lanes of the wave overwrite below.  LDS operations of a wave
+  // execute in issue order, so what has to hold is that every load above is ISSUED before the first store below -- made explicit here (a
+  // scheduling fence; nothing crosses it) instead of resting on the compiler's inability to prove the accesses disjoint
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     const int j = lane + 64 * b;

@@ -213,7 +213,12 @@ def quadratic_estimate_native(ds, which=None, wiener_filtered=True, AL=None):
     which = which or ("TT" if ds.P == 1 else "EB")
     off = {1: {"T": 0}, 2: {"E": 0, "B": 1}, 3: {"T": 0, "E": 3, "B": 4}}[ds.P]
     comps = {"TT": ["T"], "EE": ["E"], "EB": ["E", "B"]}[which]
-    key = (which,) + tuple(id(h[k]) for k in ("Cf", "Cftilde", "Cn", "Mf", "B", "Cphi"))
+    # key: the identity of the host operators AND a content fingerprint (a strided sum of ~1000 entries each) -- an in-place edit of a host
+    # plane (`h["Cn"].p[...] *= a`) keeps the ids; `ds.set_op` drops the cache as well
+    def fp(op):
+        a = np.asarray(op.p if hasattr(op, "p") else op).ravel()
+        return float(np.abs(a[:: max(1, a.size // 1009)]).sum())
+    key = (which,) + tuple((id(h[k]), fp(h[k])) for k in ("Cf", "Cftilde", "Cn", "Mf", "B", "Cphi"))
     cache = ds.__dict__.setdefault("_qe_planes", {})
     if key not in cache:
         cache.clear()

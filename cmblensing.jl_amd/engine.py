@@ -445,6 +445,7 @@ class BaseDataSet:
         self.ops[name] = t
         if name == "Mpix":
             self._mask_full = (None, None)          # expanded copy of the pixel mask is stale
+        self.__dict__.pop("_qe_planes", None)       # device copies of the estimator's planes (drivers.quadratic_estimate_native) are stale too
         check(self.lib.cmbl_dataset_set_op(self._h, self._ids[name], _ptr(t), t.shape[0]))
 
     def _apply(self, name, f, basis_out=HARMONIC):

@@ -93,6 +93,10 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *        "fill_target"           CMBL_FILL_TARGET (0)              > 0: narrow the column tiles below that many tiles per launch instead of the built-in rule
  *        "row_fill_target"       CMBL_ROW_FILL_TARGET (0 = CUs/2)  shorten the row groups below that many groups per launch
  *        "col_prefetch"          CMBL_COL_PREFETCH (-1)            touch prefetch of the double-precision >= 2048-row column kernels: -1 = built-in distance, 0 = off, > 0 = blocks ahead
+ *        "small_flow"            CMBL_SMALL_FLOW (1)               maps of 32..128 pixels per side: L*f, L\f, L'g, L'\g as ONE launch, one workgroup per (pol, batch) slice with
+ *                                                                   the half plane resident in LDS (csrc/kernels_small.hpp): 0 = off, 1 = up to 64 x 64 pixels (faster at every
+ *                                                                   batch size), 2 = wherever compiled (up to 128 x 128 in single, 64 x 64 in double precision).  Results agree
+ *                                                                   with the staged path to rounding, not bit for bit (tests/test_gpu_small.py)
  *      (the launch-geometry and prefetch switches change no result at all: tests/test_gpu_boundary.py, tests/test_gpu_fullsize.py)
  *      Unknown names return CMBL_ERR_ARG.  The reference has no counterpart (its switches are Julia keyword arguments). */
 int cmbl_ctx_set_option(cmbl_ctx* ctx, const char* name, int value);

@@ -44,6 +44,10 @@ reference_exact() = get(ENV, "CMBL_CONSISTENT", "0") in ("", "0")
 chk(rc::Integer) = rc == 0 ? nothing : error("libcmblens_hip error $rc: ", unsafe_string(ccall((:cmbl_last_error, lib), Cstring, ())))
 const CMBL_ABI_VERSION = 3          # include/cmblens.h: the revision these ccall signatures were written against
 function __init__()
+    # CMBL_REFERENCE_EXACT (the switch of the Python host and of earlier revisions of this glue) stays an accepted alias: =0 means CMBL_CONSISTENT=1
+    if haskey(ENV, "CMBL_REFERENCE_EXACT") && !haskey(ENV, "CMBL_CONSISTENT")
+        ENV["CMBL_CONSISTENT"] = ENV["CMBL_REFERENCE_EXACT"] in ("", "0") ? "1" : "0"
+    end
     v = ccall((:cmbl_abi_version, lib), Cint, ())
     v == CMBL_ABI_VERSION || error("libcmblens_hip.so has ABI version $v, this extension binds version $CMBL_ABI_VERSION: rebuild one of them")
 end

@@ -27,6 +27,15 @@ def test_self_launch_command():
     assert cmd[i + 1:] == argv                                                               # the user's flags reach every rank unchanged
 
 
+def test_self_launch_shares_the_host_cores_between_the_ranks():
+    """eight ranks on one host: each gets an eighth of the cores for its NumPy / pocketfft / BLAS set-up work, unless the caller chose"""
+    env = bench.launch_env({"PATH": "/bin"}, 8, ncpu=256)
+    assert env["OMP_NUM_THREADS"] == env["CMBL_ORACLE_FFT_WORKERS"] == env["MKL_NUM_THREADS"] == "32"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/bin"
+    env = bench.launch_env({"OMP_NUM_THREADS": "4"}, 8, ncpu=4)
+    assert env["OMP_NUM_THREADS"] == "4" and env["CMBL_ORACLE_FFT_WORKERS"] == "1"
+
+
 def test_one_gpu_per_rank():
     assert bench.assign_devices(8, 8, "nccl") == list(range(8))
     assert bench.assign_devices(2, 8, "nccl") == [0, 1]

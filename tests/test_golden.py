@@ -57,6 +57,29 @@ def test_oracle_reproduces_golden_posterior():
     check_sample(z, "d", s["d"], 1e-12)
 
 
+def test_headline_goldens_are_the_oracle():
+    """Drift guard of tests/golden/headline_*.npz and config4_gibbs_pass.npz (the oracle's answers at 1024² / 2048², committed as sampled data
+    because the GPU test run has no time to recompute them: tools/make_headline_golden.py, tools/make_config4_golden.py).  The CPU suite has no
+    time for the full evaluations either (3-4 minutes on 8 cores), so it re-derives the INPUT fingerprints of the 1024² QU case and its cheapest
+    output -- logpdf(Mixed) at the float32-rounded (f°, ϕ°, d): one inverse flow + the data model -- and requires the others to exist with
+    the fields the GPU tests read."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mhg", os.path.join(os.path.dirname(G), "..", "tools", "make_headline_golden.py"))
+    mhg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mhg)
+    g = np.load(os.path.join(G, "headline_grad_P.npz"))
+    so, ods, fo, po = mhg.grad_inputs("P")
+    for k, a in (("d", ods.d), ("fo", fo), ("po", po), ("Nphi", ods.Nphi)):
+        np.testing.assert_allclose(mhg.fingerprint(a), g["fp_" + k], rtol=1e-9, err_msg=k)
+    scalars_close("headline golden: logpdf(Mixed) 1024² QU", ods.logpdf_mixed(fo, po), g["lp_q0"], rtol=1e-12)
+    np.testing.assert_allclose(g["lp_q0"], g["lp_q1"], rtol=0)                   # the alias quirk touches the gradient only
+    need = {"headline_grad_IP.npz": ["lp_q0", "gf_q1_val", "gp_q0_idx", "fp_fo"], "headline_flow_2048.npz": ["Lf_val", "adj_val", "f0_val", "df_val", "dp_val", "fp_gl"],
+            "headline_qe_2048.npz": ["phiqe_val", "ALm_val", "fp_d"], "config4_gibbs_pass.npz": ["f_sample_val", "phio_out_val", "dH", "H0", "cg_res", "fp_wp"]}
+    for name, keys in need.items():
+        z = np.load(os.path.join(G, name))
+        for k in keys:
+            assert k in z.files and np.all(np.isfinite(np.asarray(z[k]).view(np.float64) if np.iscomplexobj(z[k]) else z[k])), (name, k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("Ny,Nx,P", [(64, 128, 2), (128, 128, 1)])

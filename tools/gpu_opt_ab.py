@@ -8,11 +8,12 @@ import cmblensing_jl_amd as C
 from bench import synthetic_cls
 
 opt, vals = sys.argv[1], [int(v) for v in sys.argv[2].split(",")]
-N = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+N = (tuple(int(v) for v in sys.argv[3].split("x")) if "x" in sys.argv[3] else int(sys.argv[3])) if len(sys.argv) > 3 else 1024     # N or NyxNx
 pol = sys.argv[4] if len(sys.argv) > 4 else "P"
 T = torch.float64 if (len(sys.argv) > 5 and sys.argv[5] == "f64") else torch.float32
 nrk = int(sys.argv[6]) if len(sys.argv) > 6 else 7
-s = C.load_sim(2.0, N, pol, synthetic_cls(), T=T, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=nrk)
+NB = int(os.environ.get("NBATCH", 1))                                    # batch slots (NBATCH=64: small maps filling the chip)
+s = C.load_sim(2.0, N, pol, synthetic_cls(), T=T, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0) if np.min(N) >= 256 else dict(pad_deg=0.2, apod_deg=0.2), nsteps=nrk, Nbatch=NB)
 ds, p, f, phi = s["ds"], s["proj"], s["f"], s["phi"]
 fm = f.to(C.MAP); gl = fm.to(C.FOURIER)
 fo, po = ds.mix(f, phi)
