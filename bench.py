@@ -592,7 +592,31 @@ def main():
                 ms8 = timeit(lambda: sim8["ds"].gradient_logpdf_mixed(fo8, po8), n=10)
                 ex["eight_chains_per_gpu"] = {"ms_per_call": ms8, "evaluations_per_s": 8e3 / ms8,
                                               "note": f"{N}² {pol}, Nbatch = 8 in one call (bench.py --nbatch 8 is the full line of this workload)"}
+                # ... and the Wiener-CG iteration in that mode (what `sample_joint` with several chains per GPU spends its time in)
+                nit8 = 20
+                sim8["ds"].argmaxf_logpdf(sim8["phi"], tol=0.0, nsteps=3)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                sim8["ds"].argmaxf_logpdf(sim8["phi"], tol=0.0, nsteps=nit8)
+                torch.cuda.synchronize(); ms_it8 = (time.perf_counter() - t0) / nit8 * 1e3
+                cg1 = ex["cg_iteration"][f"{N}_{pol}"]
+                ex["cg_iteration"][f"{N}_{pol}_B8"] = {"ms_per_iteration": ms_it8, "ms_per_iteration_per_chain": ms_it8 / 8, "iterations_timed": nit8}
+                if "traffic_GB_per_iteration" in cg1:
+                    ex["cg_iteration"][f"{N}_{pol}_B8"].update(
+                        frac_traffic=8 * cg1["traffic_GB_per_iteration"] / ms_it8 / 1e-3 / PEAK_GBS,
+                        traffic_note="8 x the counter traffic of the B = 1 iteration (no counter pass exists for the B = 8 iteration itself)")
                 del sim8, fo8, po8
+                # small maps (the reference's own test sizes): the one-launch flows of csrc/kernels_small.hpp against the two-launches-per-stage path
+                sm = {}
+                for nb in (1, 64):
+                    sims = C.load_sim(2.0, 64, pol, synthetic_cls(), T=tT, device=local, pixel_mask=dict(pad_deg=0.2, apod_deg=0.2), nsteps=nrk, Nbatch=nb)
+                    Ls, fms = sims["ds"].L(sims["phi"]), sims["f"].to(C.MAP)
+                    gls = fms.to(C.FOURIER)
+                    for v, name in ((0, "staged"), (1, "one_launch")):
+                        sims["proj"].set_option("small_flow", v)
+                        sm[f"B{nb}_{name}"] = {"L*f_ms": timeit(lambda: Ls * fms, n=20), "L'g_ms": timeit(lambda: Ls.adjoint * gls, n=20)}
+                    del sims, Ls, fms, gls
+                sm["note"] = "64² QU fp32: L*f / L'g with option small_flow = 0 (two launches per RK stage) and 1 (default: one launch per flow), B = 1 and B = 64"
+                ex["small_maps_64"] = sm
                 # a survey patch side that is not a power of two (3 * 2^k): the any-size path with its compile-time-plan transforms
                 # (csrc/kernels_ct.hpp), and the run-time-planned transforms of rounds 2-4 for comparison (option gen_ct)
                 Na = 768

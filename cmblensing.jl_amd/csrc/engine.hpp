@@ -95,6 +95,8 @@ struct CtxBase {
     int gen_slice_streams = env_int("CMBL_GEN_SLICE_STREAMS", 1) != 0;    //   one launch chain per group of slices (Flow::gen_groups)
     int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 1 << 21);   //   ... from this many pixels on (a quarter of it for >= 3 slices)
     int gen_yy = env_int("CMBL_GEN_YY", 1) != 0;                          //   the y passes of a forward stage in one launch (GenDft::yy; needs gen_ct)
+    int gen_xmerge = env_int("CMBL_GEN_XMERGE", 1) != 0;                  //   the row update of an adjoint-type stage also opens the next stage (gen_x_adj_next): one launch less per stage
+    int gen_ct_rows = env_int("CMBL_GEN_CT_ROWS", 1) != 0;                //   shorter row groups in x-pass launches with fewer groups than CUs (Ctx::ct_rows_per_group)
     int gen_ct = env_int("CMBL_GEN_CT", 1) != 0;                          //   compile-time plans for the lengths of CMBL_CT_LIST (kernels_ct.hpp)
     // launch geometry that fills the chip on small maps (profiles/r05_ab_occupancy_tiles.txt): narrower column tiles while a launch has
     // fewer workgroups than `fill_target` (0: the rule in Ctx::tileY), shorter row groups while it has fewer than `row_fill_target`
@@ -116,6 +118,8 @@ struct CtxBase {
     if (k == "gen_prologue") return &opts.gen_prologue;
     if (k == "gen_xderiv_fused") return &opts.gen_xderiv_fused;
     if (k == "gen_ct") return &opts.gen_ct;
+    if (k == "gen_ct_rows") return &opts.gen_ct_rows;
+    if (k == "gen_xmerge") return &opts.gen_xmerge;
     if (k == "gen_yy") return &opts.gen_yy;
     if (k == "gen_slice_streams") return &opts.gen_slice_streams;
     if (k == "gen_streams_min_pix") return &opts.gen_streams_min_pix;
@@ -296,6 +300,16 @@ struct Ctx : CtxBase {
     return slices / gwall * gwn;
   }
   // lengths with a compile-time plan (kernels_ct.hpp): one wavefront per sequence, S = 64 bytes of sequences per workgroup
+  // rows per workgroup of an x-pass launch over `rows` contiguous rows (`per`: wavefronts per row): the full group of ct_S wavefronts unless the
+  // launch would then have fewer workgroups than HALF the CUs; down to a quarter (2 in single, 1 in double precision).  Measured
+  // (profiles/r06_ab_anysize_row_groups.txt, first rule "fewer than the CUs"): 360^2 QU grad lnP -8 %, 768^2 QU -2.7 %, but 768^2 T+QU +1 % and 1536^2
+  // +4 % (145 / 193 groups of 8: nearly one per CU already) -- hence the half
+  int ct_rows_per_group(long rows, int per) const {
+    int S = ct_S<T>();
+    if (!opts.gen_ct_rows) return S;
+    while (S > std::max(per, ct_S<T>() / 4) && (rows * per + S - 1) / S < num_cus / 2) S >>= 1;
+    return S;
+  }
   bool gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   void gen_dft(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   void gen_rfft2(const T* map, cx<T>* F, long slices) {
@@ -359,6 +373,17 @@ struct Ctx : CtxBase {
   // fft_x of the pair (W2a, W2b) and the RK update of the Fourier state (Y0, acc -> Ys) with k = i lx Fx + i ly Fy in ONE launch where the x axis has
   // a compile-time plan; false: not available (the caller runs the x transform and k_gen_adj_rk)
   bool gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
+  // the x axis has a compile-time plan: the row update of an adjoint-type stage can open the next stage in the same launch (gen_x_adj_next)
+  bool gen_ct_x() const {
+    if (!opts.gen_ct || !opts.gen_yy || !opts.gen_xmerge || genX.plan.nf == 0) return false;
+    switch (Nx) {
+#define CMBL_X(n) case n: return true;
+      CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+      default: return false;
+    }
+  }
+  void gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, const RKCoef<T>& rk, cx<T>* t3, const cx<T>* A_next, cx<T>* gx, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // t3 = ifft_x(F) (unnormalised) and gx = ifft_x(i lx fft_x(A)) in ONE launch where the x axis has a compile-time plan (else two launches)
   void gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // c2r of T3 = ifft_x(y) -> y, (p_x y, p_y y) at stage time t, its pair r2c -> (W2a, W2b): the y passes of an adjoint stage in one launch
@@ -1066,8 +1091,10 @@ struct Flow {
           GenWindow w(this, g, K, slices);
           if (yy) {                                                          // ifft_x, every y pass of the stage in one launch, fft_x of the pair, RK update
             cx<T>* t3 = c->mixed_scratch(slices);
-            c->gen_x(gYs.as<cx<T>>(), t3, true, nullptr, slices);
+            const bool mrg = c->gen_ct_x();                                  // the row update of stage s also writes t3 = ifft_x(Ys) of stage s + 1
+            if (!mrg || (step == 0 && stage == 1)) c->gen_x(gYs.as<cx<T>>(), t3, true, nullptr, slices);
             c->gen_y_adj_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), ph(rk.t), rk.t, P, gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, slices);
+            if (mrg && !rk.last) { c->gen_x_adj_next(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, out, Yacc.as<cx<T>>(), rk, t3, nullptr, nullptr, slices); continue; }
             if (c->gen_x_adj_update(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices)) continue;
             c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
             CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
@@ -1112,12 +1139,17 @@ struct Flow {
           if (yy) {
             // x passes (ifft_x of delta f, d/dx of rfft_y(f)), then every y pass of the stage in one launch, then the delta-f velocity's x pass + RK update
             cx<T>* t3 = c->mixed_scratch(slices);
-            c->gen_x_inv_and_deriv(gYs.as<cx<T>>(), t3, gA.as<cx<T>>(), gGx.as<cx<T>>(), gT.as<cx<T>>(), c->lx_r.template as<T>(), slices);
+            const bool mrg = c->gen_ct_x();                                  // the row update of stage s also runs both x passes that open stage s + 1
+            if (!mrg || it == 0) c->gen_x_inv_and_deriv(gYs.as<cx<T>>(), t3, gA.as<cx<T>>(), gGx.as<cx<T>>(), gT.as<cx<T>>(), c->lx_r.template as<T>(), slices);
             GenPro<T> e{};
             e.mode = 2; e.ph = ph(rk.t); e.rk = rk; e.y0 = f; e.acc = acc.as<T>(); e.w1p = w1p; e.w2p = w1p + (size_t)slices * np; e.npix = np; e.P = P;
             c->gen_y_delta_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), gGx.as<cx<T>>(), gA.as<cx<T>>(), c->ly.template as<T>(),
                                  (T)(1.0 / ((double)c->Ny * c->Nx)), (T)(1.0 / (double)c->Ny), e, gA.as<cx<T>>(), gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl,
                                  rk.last != 0, slices);
+            if (mrg && !rk.last) {
+              c->gen_x_adj_next(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, df, Yacc.as<cx<T>>(), rk, t3, gA.as<cx<T>>(), gGx.as<cx<T>>(), slices);
+              continue;
+            }
             if (c->gen_x_adj_update(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices)) continue;
             c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
             CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),

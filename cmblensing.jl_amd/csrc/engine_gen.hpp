@@ -15,6 +15,21 @@ bool Ctx<T>::gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
   static const int stamp_kind = env_int("CMBL_CT_STAMP_KIND", -1);
   if (kind + (a.lmul_mid ? 8 : 0) == stamp_kind) kind |= 256;
 #endif
+  if (kind == CT_C && a.in_elem == 1 && a.out_elem == 1) {                 // contiguous rows: groups of 8 / 4 / 2 (ct_rows_per_group)
+    const int Sx = ct_rows_per_group((long)a.nseq * slices, 1);
+    a.S = Sx;
+    const dim3 gx((unsigned)((a.nseq + Sx - 1) / Sx), (unsigned)slices);
+    switch (ax.N) {
+#define CMBL_X(n) case n: \
+        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>()>), gx, ct_lds<T>(n), stream, a); \
+        else if (Sx == ct_S<T>() / 2) CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>() / 2>), gx, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
+        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 16 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>() / 4>), gx, (ct_lds<T>(n, 1, ct_S<T>() / 4)), stream, a); \
+        return true;
+      CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+      default: return false;
+    }
+  }
   switch (ax.N) {
 #define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft<T, n>), grid, ct_lds<T>(n), stream, a, kind); return true;
     CMBL_CT_LIST(CMBL_X)
@@ -107,14 +122,61 @@ bool Ctx<T>::gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<
   a.in_seq = Nx; a.in_elem = 1; a.in_slice = plane(); a.out_seq = Nx; a.out_elem = 1; a.out_slice = plane();
   a.pro.rk = rk; a.yy_out = Y0; a.out2 = acc_; a.out = Ys; a.lmul_out = lx_r.template as<T>(); a.lmul_in = ly.template as<T>();
   slices = gen_window(a, slices);
-  a.N = Nx; a.tw = genX.twN.template as<cx<T>>(); a.S = ct_S<T>();
-  const int R = ct_S<T>() / 2;
+  a.N = Nx; a.tw = genX.twN.template as<cx<T>>();
+  const int Sx = std::max(ct_S<T>() / 2, ct_rows_per_group((long)a.nseq * slices, 2));   // S wavefronts = S / 2 rows x the two members of the pair
+  a.S = Sx;
+  const int R = Sx / 2;
   const dim3 grid((unsigned)((a.nseq + R - 1) / R), (unsigned)slices);
   switch (Nx) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x<T, n>), grid, ct_lds<T>(n), stream, a); return true;
+#define CMBL_X(n) case n: \
+      if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
+      else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
+      return true;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: return false;
+  }
+}
+
+// gen_x_adj_update that ALSO opens the next stage (round 6): the row workgroups that hold the new stage input Ys transform it back, t3 = ifft_x(Ys)
+// (no Ys round trip through memory, one launch less per stage), and -- delta flow: A_next given -- the d/dx pass gx = ifft_x(i lx fft_x(A_next)) of
+// the next stage's f rides in the same launch as further workgroups (k_ct_adj_x_dx).  Replaces gen_x_adj_update(s) + gen_x_inv_and_deriv(s + 1)
+// / gen_x(s + 1); needs a compile-time plan for Nx (gen_ct_x()).  Results bit-identical to the separate launches.
+template <typename T>
+void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, const RKCoef<T>& rk, cx<T>* t3, const cx<T>* A_next, cx<T>* gx, long slices) {
+  GenDft<T> a{};
+  a.in = W2a; a.in2 = W2b; a.nin = Nx; a.nout = Nx; a.nseq = Nyh; a.scale = 1;
+  a.in_seq = Nx; a.in_elem = 1; a.in_slice = plane(); a.out_seq = Nx; a.out_elem = 1; a.out_slice = plane();
+  a.pro.rk = rk; a.yy_out = Y0; a.out2 = acc_; a.out = nullptr; a.yy_out2 = t3; a.lmul_out = lx_r.template as<T>(); a.lmul_in = ly.template as<T>();
+  GenDft<T> a1{};
+  if (A_next) {
+    a1.in = A_next; a1.out = gx; a1.nin = Nx; a1.nout = Nx; a1.nseq = Nyh; a1.scale = 1; a1.lmul_mid = lx_r.template as<T>();
+    a1.in_seq = Nx; a1.in_elem = 1; a1.in_slice = plane(); a1.out_seq = Nx; a1.out_elem = 1; a1.out_slice = plane();
+  }
+  const long ws = gen_window(a, slices);
+  if (A_next) (void)gen_window(a1, slices);
+  a.N = a1.N = Nx; a.tw = a1.tw = genX.twN.template as<cx<T>>();
+  // group height: the row-update part has Nyh / (S / 2) workgroups per slice, the d/dx part Nyh / S
+  // (half-height groups while the launch has fewer than 1.5 full-height groups per CU: measured at 768^2 / 1000^2 QU -3.5 %, 768^2 T+QU +1.4 %,
+  //  profiles/r06_ab_anysize_xmerge.txt)
+  int Sx = (opts.gen_ct_rows && ((A_next ? 3L : 2L) * a.nseq * ws + ct_S<T>() - 1) / ct_S<T>() < 3L * num_cus / 2) ? ct_S<T>() / 2 : ct_S<T>();
+  { static const int force = env_int("CMBL_XMERGE_S", 0); if (force == ct_S<T>() || force == ct_S<T>() / 2) Sx = force; }   // (tuning aid)
+  a.S = a1.S = Sx;
+  const int R = Sx / 2;
+  const dim3 grid((unsigned)((a.nseq + R - 1) / R), (unsigned)((A_next ? 2 : 1) * ws));
+  switch (Nx) {
+#define CMBL_X(n) case n: \
+      if (A_next) { \
+        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x_dx<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a, (int)ws, a1); \
+        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_adj_x_dx<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a, (int)ws, a1); \
+      } else { \
+        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
+        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
+      } \
+      return;
+    CMBL_CT_LIST(CMBL_X)
+#undef CMBL_X
+    default: fail(ERR_STATE, "merged x passes need a compile-time plan for Nx");
   }
 }
 
@@ -128,10 +190,15 @@ void Ctx<T>::gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<
     a1 = a0; a1.in = A_; a1.out = gx; a1.inverse = 0; a1.lmul_mid = lx;
     const long ws = gen_window(a0, slices);
     (void)gen_window(a1, slices);
-    a0.N = a1.N = Nx; a0.tw = a1.tw = genX.twN.template as<cx<T>>(); a0.S = a1.S = ct_S<T>();
+    a0.N = a1.N = Nx; a0.tw = a1.tw = genX.twN.template as<cx<T>>();
+    const int Sx = std::max(ct_S<T>() / 2, ct_rows_per_group(2L * a0.nseq * ws, 1));
+    a0.S = a1.S = Sx;
     const dim3 grid((unsigned)((a0.nseq + a0.S - 1) / a0.S), (unsigned)(2 * ws));
     switch (Nx) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft2<T, n>), grid, ct_lds<T>(n), stream, a0, ct_kind(a0), (int)ws, a1, ct_kind(a1)); return;
+#define CMBL_X(n) case n: \
+        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft2<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a0, ct_kind(a0), (int)ws, a1, ct_kind(a1)); \
+        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_dft2<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a0, ct_kind(a0), (int)ws, a1, ct_kind(a1)); \
+        return;
       CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
       default: break;
@@ -165,6 +232,7 @@ void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, 
   template void Ctx<T>::gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, bool last, long slices); \
   template void Ctx<T>::gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, cx<T>* W2a, cx<T>* W2b, bool last, long slices); \
   template bool Ctx<T>::gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices); \
+  template void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, const RKCoef<T>& rk, cx<T>* t3, const cx<T>* A_next, cx<T>* gx, long slices); \
   template void Ctx<T>::gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices); \
   template void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, int P, cx<T>* W2a, cx<T>* W2b, long slices);
 

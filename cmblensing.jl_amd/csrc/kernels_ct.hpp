@@ -79,12 +79,17 @@ template <typename T, int N, int I>
 __device__ __forceinline__ void ct_stage(cx<T>* __restrict__ s, const cx<T>* __restrict__ tw, int lane) {
   using V = typename vreg<T>::type;
   constexpr int R = ct_radix(N, I), Ns = ct_ns(N, I), nb = N / R, tstep = N / (Ns * R), B = (nb + 63) / 64;
+  // LDS addresses as ONE per-butterfly base + compile-time offsets wherever the padding allows it (a quarter of the ~600 vector instructions of a
+  // 768-point transform were pad() arithmetic, one add-shift-add per element and direction): pad(a + c) == pad(a) + pad(c) when c is a multiple
+  // of 16, or when a mod 16 + c mod 16 cannot carry -- loads: c = m nb; stores: c = m Ns with k < Ns, Ns | 16, 16 | Ns R
+  constexpr bool LD_IMM = nb % 16 == 0, ST_IMM = Ns % 16 == 0 || (16 % Ns == 0 && (Ns * R) % 16 == 0);
   V v[B][R];
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     const int j0 = lane + 64 * b, j = (nb % 64 == 0 || j0 < nb) ? j0 : nb - 1;       // spare lanes re-read the last butterfly (and write nothing)
+    const cx<T>* p = s + pad(j);
 #pragma unroll
-    for (int m = 0; m < R; ++m) v[b][m] = vload(s + pad(j + m * nb));
+    for (int m = 0; m < R; ++m) v[b][m] = vload(LD_IMM ? p + pad(m * nb) : s + pad(j + m * nb));
   }
   // The stage is IN PLACE with no workgroup barrier: lanes read slots that other lanes of the wave overwrite below.  LDS operations of a wave
   // execute in issue order, so what has to hold is that every load above is ISSUED before the first store below -- made explicit here (a
@@ -119,8 +124,9 @@ __device__ __forceinline__ void ct_stage(cx<T>* __restrict__ s, const cx<T>* __r
     }
     ct_bfly<T, R>(v[b]);
     if (nb % 64 == 0 || j < nb) {
+      cx<T>* q = s + pad(blk * (Ns * R) + k);
 #pragma unroll
-      for (int m = 0; m < R; ++m) vstore(s + pad(blk * (Ns * R) + k + m * Ns), v[b][ct_loc<R>(m)]);
+      for (int m = 0; m < R; ++m) vstore(ST_IMM ? q + pad(m * Ns) : s + pad(blk * (Ns * R) + k + m * Ns), v[b][ct_loc<R>(m)]);
     }
     // many values in flight: keep the compiler from interleaving the butterflies of a lane (their twiddles and temporaries would all
     // be live at once: spills at 720 / 1000 / 1280 under the two-workgroups-per-CU register cap)
@@ -408,10 +414,17 @@ __device__ __forceinline__ void ct_flow_stage(const GenDft<T>& a, cx<T>* __restr
 #endif
 
 template <typename T> constexpr int ct_min_waves() { return sizeof(T) == 4 ? 4 : 2; }       // two workgroups per CU
+// ... of the x-pass kernels: two workgroups of S wavefronts per CU, and ONE from 1000 points on -- 16-24 elements per lane under the 128-register
+// cap spilled 80-170 registers (1000 = 8 5 5 5: 300 bytes of scratch per lane in the d/dx pass), while a launch of <= 256 row groups has one
+// workgroup per CU whatever the cap allows
+template <typename T, int N, int S> constexpr int ct_min_waves_x() {
+  const int w = ct_min_waves<T>() * S / ct_S<T>() / (N >= 1000 ? 2 : 1);
+  return w < 1 ? 1 : w;
+}
 
-template <typename T, int N, bool CONLY = false /*complex in, complex out only (x passes): no other fetch variant is compiled in*/>
+template <typename T, int N, bool CONLY = false /*complex in, complex out only (x passes): no other fetch variant is compiled in*/, int S = ct_S<T>()>
 __device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsigned ysl) {
-  constexpr int S = ct_S<T>(), LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
+  constexpr int LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
@@ -426,7 +439,7 @@ __device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsign
   CMBL_CT_STAMP(14); CMBL_CT_STAMP(0);
   TwStage<T, NT, NTW> twr;
   twr.issue(a.tw);
-  if constexpr (CONLY) ct_fetch<T, N, CT_C, false>(a, s, sl, seq0, in_by_seq);
+  if constexpr (CONLY) ct_fetch<T, N, CT_C, false, S>(a, s, sl, seq0, in_by_seq);
   else switch (kind) {                                                   // uniform: one straight-line fetch per variant
     case CT_C: ct_fetch<T, N, CT_C, false>(a, s, sl, seq0, in_by_seq); break;
     case CT_R1: ct_fetch<T, N, CT_R1, false>(a, s, sl, seq0, in_by_seq); break;
@@ -460,18 +473,25 @@ __device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsign
   CMBL_CT_STAMP(4);
   __syncthreads();
   CMBL_CT_STAMP(5);
-  ct_store_rows<T, N>(a, s, sl, seq0, out_by_seq, wave, lane, a.lmul_mid != nullptr);
+  ct_store_rows<T, N, S>(a, s, sl, seq0, out_by_seq, wave, lane, a.lmul_mid != nullptr);
   CMBL_CT_STAMP(6); CMBL_CT_STAMP(15);
 }
 template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft(GenDft<T> a, int kind) { ct_dft_body<T, N>(a, kind, blockIdx.y); }
+__global__ __launch_bounds__(64 * ct_S<T>(), (ct_min_waves_x<T, N, ct_S<T>()>())) void k_ct_dft(GenDft<T> a, int kind) { ct_dft_body<T, N>(a, kind, blockIdx.y); }
 // Two independent transform launches of the same length as one (grid.y = ny0 + the second's): the two x passes that open a delta-flow
 // stage -- ifft_x(delta f) and the d/dx pass of rfft_y(f) -- have no dependence on each other.
-template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_dft2(GenDft<T> a0, int kind0, int ny0, GenDft<T> a1, int kind1) {
-  if ((int)blockIdx.y < ny0) ct_dft_body<T, N, true>(a0, kind0, blockIdx.y);
-  else ct_dft_body<T, N, true>(a1, kind1, blockIdx.y - (unsigned)ny0);
+// S: sequences (= wavefronts) per workgroup.  The x passes read and write contiguous rows, so nothing ties them to the 64-byte pieces of the
+// transposed side: a launch with fewer row groups than CUs (768^2 QU: 770 rows = 97 groups of 8 on 256 CUs, two wavefronts per SIMD -- and the
+// transforms are bound by VALU issue per SIMD) takes groups of 4 or 2 rows instead (Ctx::ct_rows_per_group), one wavefront per SIMD on twice
+// as many CUs.
+template <typename T, int N, int S = ct_S<T>()>
+__global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_dft2(GenDft<T> a0, int kind0, int ny0, GenDft<T> a1, int kind1) {
+  if ((int)blockIdx.y < ny0) ct_dft_body<T, N, true, S>(a0, kind0, blockIdx.y);
+  else ct_dft_body<T, N, true, S>(a1, kind1, blockIdx.y - (unsigned)ny0);
 }
+// one complex -> complex transform launch on contiguous rows (the x transforms and the one-launch d/dx pass)
+template <typename T, int N, int S>
+__global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_dftx(GenDft<T> a) { ct_dft_body<T, N, true, S>(a, CT_C, blockIdx.y); }
 
 // The y passes of a forward flow stage in one launch (GenDft::yy; Ctx::gen_y_flow_stage): pair-c2r fetch, ct_flow_stage on every column,
 // rfft_y(f_next) stored as a half spectrum in the layout of the inputs.  A kernel of its own: its register needs are not k_ct_dft's.
@@ -640,13 +660,16 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_ad
 // update of the Fourier state, k = i lx Fx + i ly Fy (src/lenseflow.jl:163-174; k_gen_adj_rk).  A workgroup takes S/2 adjacent ky rows of
 // both members (wave w: member w / (S/2), row w % (S/2)); after the transforms the two wavefronts of a row share its kx range in alternating
 // 64-element pieces.  a.in / a.in2: the pair; a.yy_out / a.out2 / a.out: Y0 / acc / Ys; a.lmul_out / a.lmul_in: lx / ly.
-template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_adj_x(GenDft<T> a) {
-  constexpr int S = ct_S<T>(), R = S / 2, NT = 64 * S, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64, EH = (E + 1) / 2;
+// a.yy_out2 != nullptr (round 6): the workgroup ALSO opens the next stage -- it has the new stage input Ys of its rows in registers, so it
+// transforms them back, T3 = ifft_x(Ys) (unnormalised, what the next stage's y kernel fetches), instead of a launch of its own reading
+// Ys back from memory (k_ct_dft2's first half / gen_x); a.out (Ys) may then be nullptr.  Same wavefront arithmetic: bit-identical.
+template <typename T, int N, int S>
+__device__ __forceinline__ void ct_adj_x_body(const GenDft<T>& a, unsigned ysl) {
+  constexpr int R = S / 2, NT = 64 * S, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64, EH = (E + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
-  const size_t sl = gen_slice(a), sb = sl * a.in_slice;
+  const size_t sl = gen_slice(a, ysl), sb = sl * a.in_slice;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = wave / R, r = wave % R, ky = blockIdx.x * R + r;
   const bool live = ky < a.nseq;
   const int kyc = live ? ky : a.nseq - 1;
@@ -673,23 +696,50 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>()) void k_ct_adj_x(
   __syncthreads();
   if (live) ct_transform<T, N>(row, tw, lane);
   __syncthreads();
-  if (!live) return;
-  const T l_y = a.lmul_in[ky];
-  cx<T>* Ys = reinterpret_cast<cx<T>*>(a.out) + sb;
-  cx<T>* dst = (rk.stage == 4 ? reinterpret_cast<cx<T>*>(a.yy_out) : reinterpret_cast<cx<T>*>(a.out2)) + sb;
+  cx<T>* const T3 = a.yy_out2 ? reinterpret_cast<cx<T>*>(a.yy_out2) + sb : nullptr;       // (uniform)
+  if (live) {
+    const T l_y = a.lmul_in[ky];
+    cx<T>* Ys = a.out ? reinterpret_cast<cx<T>*>(a.out) + sb : nullptr;
+    cx<T>* dst = (rk.stage == 4 ? reinterpret_cast<cx<T>*>(a.yy_out) : reinterpret_cast<cx<T>*>(a.out2)) + sb;
 #pragma unroll
-  for (int j = 0; j < EH; ++j) {
-    const int k = lane + 64 * (2 * j + m);
-    if (2 * j + m < E && (N % 64 == 0 || k < N)) {
-      const cx<T> kv = mul_il(s[r * LD + pad(k)], a.lmul_out[k]) + mul_il(s[(R + r) * LD + pad(k)], l_y);
-      cx<T> y = y0v[j], ac = acv[j];
-      if (rk.stage == 1) { ac.x = T(0); ac.y = T(0); }                   // (member-wise: a select between aggregates goes through scratch memory in double precision)
-      const cx<T> nxt = rk_update(rk, kv, y, ac);
-      const unsigned o = (unsigned)ky * (unsigned)N + (unsigned)k;
-      if (rk.stage == 4) at32(dst, o) = y; else at32(dst, o) = ac;
-      at32(Ys, o) = nxt;
+    for (int j = 0; j < EH; ++j) {
+      const int k = lane + 64 * (2 * j + m);
+      if (2 * j + m < E && (N % 64 == 0 || k < N)) {
+        const cx<T> kv = mul_il(s[r * LD + pad(k)], a.lmul_out[k]) + mul_il(s[(R + r) * LD + pad(k)], l_y);
+        cx<T> y = y0v[j], ac = acv[j];
+        if (rk.stage == 1) { ac.x = T(0); ac.y = T(0); }                   // (member-wise: a select between aggregates goes through scratch memory in double precision)
+        const cx<T> nxt = rk_update(rk, kv, y, ac);
+        const unsigned o = (unsigned)ky * (unsigned)N + (unsigned)k;
+        if (rk.stage == 4) at32(dst, o) = y; else at32(dst, o) = ac;
+        if (Ys) at32(Ys, o) = nxt;
+        if (T3) s[r * LD + pad(k)] = conj(nxt);                            // the inverse transform is conj(forward(conj .)); this lane alone read the slot
+      }
     }
   }
+  if (!T3) return;
+  __syncthreads();
+  if (live && m == 0) ct_transform<T, N>(row, tw, lane);                  // (member 0's wavefront owns row r)
+  __syncthreads();
+  if (live) {
+    const bool wt = wt_line<T>(N);
+#pragma unroll
+    for (int j = 0; j < EH; ++j) {
+      const int k = lane + 64 * (2 * j + m);
+      if (2 * j + m < E && (N % 64 == 0 || k < N)) {
+        const cx<T> y = conj(s[r * LD + pad(k)]);
+        ct_store<(int)sizeof(cx<T>)>(T3, ((unsigned)ky * (unsigned)N + (unsigned)k) * (unsigned)sizeof(cx<T>), &y, wt);
+      }
+    }
+  }
+}
+template <typename T, int N, int S = ct_S<T>()>
+__global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_adj_x(GenDft<T> a) { ct_adj_x_body<T, N, S>(a, blockIdx.y); }
+// ... and, in the delta flow, the d/dx pass of the next stage's f (independent of the row update: the second half of k_ct_dft2) as further
+// workgroups of the same launch: grid.y = ny_adj slices of row updates + the slices of a1; grid.x covers the larger of the two parts
+template <typename T, int N, int S = ct_S<T>()>
+__global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_adj_x_dx(GenDft<T> a, int ny_adj, GenDft<T> a1) {
+  if ((int)blockIdx.y < ny_adj) { if ((int)blockIdx.x * (S / 2) < a.nseq) ct_adj_x_body<T, N, S>(a, blockIdx.y); }
+  else if ((int)blockIdx.x * S < a1.nseq) ct_dft_body<T, N, true, S>(a1, CT_C, blockIdx.y - (unsigned)ny_adj);
 }
 
 }  // namespace cmbl

@@ -72,9 +72,20 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) { return (nb & 7) ? b : (
 // takes 4 adjacent ky rows gathers whole 128-byte lines (4 rows x 4 values), which is as fast as contiguous rows (2.9 us / 2.9 us).
 // The row count of a block is padded to a multiple of 4 (Ny/2+1 is odd): blocks and the gathered 4 x 4 lines then start on 128-byte
 // boundaries (unpadded, every line of a row workgroup straddled two: +35 % measured traffic in the row kernels).
-constexpr int MIXW = 4, LGMIXW = 2;
+// Block width per precision (round 6): 4 columns of 8-byte elements, CMBL_MIXW64 (2) columns of 16-byte ones -- a block row is then 32 bytes in both
+// precisions, 4 padded rows x one block row = one 128-byte line, and the TWO-column tile the double-precision delta-flow kernel runs on (engine.hpp
+// tileY_delta: the four-column tile spills) is ONE contiguous block of whole lines instead of the 32-byte halves of a four-column block's 64-byte
+// rows (those half lines were fetched by both neighbours: +18 % L2 read requests at 2048^2 fp64, profiles/r05_pmc_tcc_requests.txt).
+// -DCMBL_MIXW64=4 restores the round-2..5 layout for A/B.
+#ifndef CMBL_MIXW64
+#define CMBL_MIXW64 4
+#endif
+template <int BYTES> __host__ __device__ constexpr int mixw_b() { return BYTES == 16 ? CMBL_MIXW64 : 4; }      // BYTES = sizeof(cx<T>)
+template <typename T> __host__ __device__ constexpr int mixw() { return mixw_b<(int)sizeof(cx<T>)>(); }
+template <int W> __host__ __device__ constexpr int lg_mixw() { return W == 4 ? 2 : W == 2 ? 1 : 0; }
+static_assert(CMBL_MIXW64 == 1 || CMBL_MIXW64 == 2 || CMBL_MIXW64 == 4, "block width of the double-precision mixed layout");
 __host__ __device__ constexpr int mixed_rows(int Nyh) { return (Nyh + 3) & ~3; }
-__device__ __forceinline__ size_t mix_idx(int ky, int x, int NyhP) { return ((size_t)(x >> LGMIXW) * NyhP + ky) * MIXW + (x & (MIXW - 1)); }
+template <int W> __device__ __forceinline__ size_t mix_idx(int ky, int x, int NyhP) { return ((size_t)(x >> lg_mixw<W>()) * NyhP + ky) * W + (x & (W - 1)); }
 // Addressing: uniform 64-bit base (scalar registers) + 32-bit unsigned byte offset (one vector register) is the form global_load /
 // global_store take directly, with no 64-bit vector arithmetic per access (the fused kernels are partly VALU-issue bound, and a
 // third of their vector instructions was address arithmetic).  Offsets inside one slice of a field stay far below 4 GB.
@@ -127,10 +138,14 @@ template <typename T, bool WT> __device__ __forceinline__ void handoff_store(cx<
 
 // A column tile of C = MIXW columns is ONE contiguous block of the mixed layout: entry (ky, c) of the tile at x0 sits at
 // tile_base(g, x0) + ky * MIXW + c.  Other widths go through mix_idx.
-template <typename V> __device__ __forceinline__ V* tile_base(V* g, int x0, int NyhP) { return g + (size_t)(x0 >> LGMIXW) * NyhP * MIXW; }
-template <int C> __device__ __forceinline__ unsigned tile_off(int ky, int c, int x0, int NyhP) {
-  if constexpr (C == MIXW) return (unsigned)(ky * MIXW + c);
-  else return (unsigned)(mix_idx(ky, x0 + c, NyhP) - (size_t)(x0 >> LGMIXW) * NyhP * MIXW);
+template <typename V> __device__ __forceinline__ V* tile_base(V* g, int x0, int NyhP) {
+  constexpr int W = mixw_b<(int)sizeof(V)>();
+  return g + (size_t)(x0 >> lg_mixw<W>()) * NyhP * W;
+}
+template <typename T, int C> __device__ __forceinline__ unsigned tile_off(int ky, int c, int x0, int NyhP) {
+  constexpr int W = mixw<T>();
+  if constexpr (C == W) return (unsigned)(ky * W + c);
+  else return (unsigned)(mix_idx<W>(ky, x0 + c, NyhP) - (size_t)(x0 >> lg_mixw<W>()) * NyhP * W);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -213,7 +228,7 @@ template <typename T, int NT, int LGM, int LGC> struct TileStage {           // 
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const int e = threadIdx.x + i * NT;
-      if (e < TOT) v[i] = at32(tg, tile_off<C>(e >> LGC, e & (C - 1), x0, mixed_rows(M + 1)));
+      if (e < TOT) v[i] = at32(tg, tile_off<T, C>(e >> LGC, e & (C - 1), x0, mixed_rows(M + 1)));
     }
   }
   template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
@@ -230,7 +245,7 @@ __device__ __forceinline__ void tile_store_mixed(const cx<T>* __restrict__ s, cx
   cx<T>* tg = tile_base(g, x0, mixed_rows(M + 1));
   for (int e = threadIdx.x; e < (C * (M + 1)); e += NT) {
     const int c = e & (C - 1), k = e >> LGC;
-    at32(tg, tile_off<C>(k, c, x0, mixed_rows(M + 1))) = s[c * LD + hslot<LGM>(k)];
+    at32(tg, tile_off<T, C>(k, c, x0, mixed_rows(M + 1))) = s[c * LD + hslot<LGM>(k)];
   }
 }
 
@@ -271,7 +286,7 @@ template <typename T, int NT, int LGM, int LGC> struct HalfStage {
       const int u = threadIdx.x + i * NT;
       if (TOT % NT == 0 || u < TOT) {
         const int k = u >> LGC, c = u & (C - 1);
-        a[i] = at32(tg, tile_off<C>(k, c, x0, NyhP)); b[i] = at32(tg, tile_off<C>(M - k, c, x0, NyhP)); w[i] = at32(twg, (unsigned)k);
+        a[i] = at32(tg, tile_off<T, C>(k, c, x0, NyhP)); b[i] = at32(tg, tile_off<T, C>(M - k, c, x0, NyhP)); w[i] = at32(twg, (unsigned)k);
       }
     }
   }
@@ -303,13 +318,13 @@ __device__ __forceinline__ void half_store(const cx<T>* __restrict__ s, cx<T>* _
     const cx<T>* p = s + c * LD;
     if (k == 0) {
       const cx<T> z = p[0];
-      handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<C>(0, c, x0, NyhP), mk<T>(z.x + z.y, 0)); handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<C>(M, c, x0, NyhP), mk<T>(z.x - z.y, 0));
+      handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<T, C>(0, c, x0, NyhP), mk<T>(z.x + z.y, 0)); handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<T, C>(M, c, x0, NyhP), mk<T>(z.x - z.y, 0));
     } else {
       const cx<T> a = p[pad(brevc<LGM>(k))], b = p[pad(brevc<LGM>(k2))];
       const cx<T> e = mk<T>(T(0.5) * (a.x + b.x), T(0.5) * (a.y - b.y)), o = mk<T>(T(0.5) * (a.x - b.x), T(0.5) * (a.y + b.y));
       const cx<T> wo = mul_mi(o * tw[k]);
-      handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<C>(k, c, x0, NyhP), e + wo);
-      if (k2 != k) handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<C>(k2, c, x0, NyhP), conj(e - wo));
+      handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<T, C>(k, c, x0, NyhP), e + wo);
+      if (k2 != k) handoff_store<T, wt_cols<T>(C, M)>(tg, tile_off<T, C>(k2, c, x0, NyhP), conj(e - wo));
     }
   }
 }
@@ -385,7 +400,7 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
       const int e = threadIdx.x + i * NT;
       if (e < TOT) {
         const int k = e >> LGC;
-        const unsigned gi = tile_off<C>(k, e & (C - 1), x0, mixed_rows(M + 1));
+        const unsigned gi = tile_off<T, C>(k, e & (C - 1), x0, mixed_rows(M + 1));
         X[i] = at32(tX, gi); Y[i] = at32(tY, gi); l[i] = at32(ly, (unsigned)k);
       }
     }
@@ -398,7 +413,7 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
     for (int i = 0; i < K; ++i) {
       const int e = threadIdx.x + i * NT;
       if (e < TOT) {
-        const unsigned gi = tile_off<C>(e >> LGC, e & (C - 1), x0, mixed_rows(M + 1));
+        const unsigned gi = tile_off<T, C>(e >> LGC, e & (C - 1), x0, mixed_rows(M + 1));
         X[i] = at32(tX, gi); Y[i] = at32(tY, gi);
       }
     }
@@ -513,7 +528,7 @@ template <typename T> __device__ __forceinline__ CxVec<T>& vec32(cx<T>* base, un
 // 16 KB window at the same moment; measured on MI355X: no difference, the default is no rotation)
 template <typename T, int LGNX, int RPW, int NA> struct RowsMixedStage {
   using V = typename vreg<T>::type;
-  static constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW);
+  static constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = mixw<T>() / VE, NT = row_nt(RPW);
   static constexpr int TOT = RPW * NH / VE, K = (TOT + NT - 1) / NT;
   CxVec<T> va[NA][K] = {}, vb[NA][K] = {}, w[K] = {};
   // tid: index of the thread among the NT that share this load (threadIdx.x unless several row sets are loaded side by side)
@@ -521,13 +536,13 @@ template <typename T, int LGNX, int RPW, int NA> struct RowsMixedStage {
     const int rot = CMBL_ROW_ROT(ky0);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int u = tid + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+      const int u = tid + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / mixw<T>() - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
       if ((TOT % NT == 0 || u < TOT) && r < nr) {
-        vload32(w[i], twg, (unsigned)(xt * MIXW + c));
-        const unsigned o = (unsigned)((xt * NyhP + r) * MIXW + c), ob = (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c);
+        vload32(w[i], twg, (unsigned)(xt * mixw<T>() + c));
+        const unsigned o = (unsigned)((xt * NyhP + r) * mixw<T>() + c), ob = (unsigned)(((xt + NH / mixw<T>()) * NyhP + r) * mixw<T>() + c);
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-          const cx<T>* ga = g[a] + (size_t)ky0 * MIXW;                    // uniform part of the address
+          const cx<T>* ga = g[a] + (size_t)ky0 * mixw<T>();                    // uniform part of the address
           vload32(va[a][i], ga, o);
           vload32(vb[a][i], ga, ob);
         }
@@ -539,12 +554,12 @@ template <typename T, int LGNX, int RPW, int NA> struct RowsMixedStage {
     const int rot = CMBL_ROW_ROT(ky0);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int u = tid + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+      const int u = tid + i * NT, xt = (u / (UPG * RPW) + rot) & (NH / mixw<T>() - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
       if ((TOT % NT == 0 || u < TOT) && r < nr) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
           const V xa = vfrom(va[a][i].v[e]), xb = vfrom(vb[a][i].v[e]);
-          cx<T>* p = s + r * LD + pad(xt * MIXW + c) + e;                 // c even: pad(x + 1) == pad(x) + 1; pad(x + N/2) == pad(x) + pad(N/2)
+          cx<T>* p = s + r * LD + pad(xt * mixw<T>() + c) + e;                 // c even: pad(x + 1) == pad(x) + 1; pad(x + N/2) == pad(x) + pad(N/2)
           vstore(p, vadd(xa, xb));
           vstore(p + pad(NH), vmul(vsub(xa, xb), vfrom(w[i].v[e])));
         }
@@ -565,21 +580,21 @@ template <typename T, int LGNX, int RPW>
 __device__ __forceinline__ void rows_store_mixed_dit(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, const cx<T>* __restrict__ tw, int NyhP, int ky0, int nr, T scale,
                                                      int nyq = -1 /* >= 0: drop Im of the ky = 0 and ky = nyq rows (what c2r ignores) */, int tid = threadIdx.x) {
   using V = typename vreg<T>::type;
-  constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = MIXW / VE, NT = row_nt(RPW), TOT = RPW * NH / VE;
+  constexpr int Nx = 1 << LGNX, NH = Nx >> 1, LD = row_ld(Nx), VE = 16 / (int)sizeof(cx<T>), UPG = mixw<T>() / VE, NT = row_nt(RPW), TOT = RPW * NH / VE;
   const int rot = CMBL_ROW_ROT(ky0);
   for (int u = tid; u < TOT; u += NT) {
-    const int xt = (u / (UPG * RPW) + rot) & (NH / MIXW - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
+    const int xt = (u / (UPG * RPW) + rot) & (NH / mixw<T>() - 1), r = (u / UPG) % RPW, c = (u % UPG) * VE;
     if (r < nr) {
       CxVec<T> oa, ob;
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
-        const cx<T>* p = s + r * LD + pad(xt * MIXW + c) + e;
-        const V uu = vload(p), t = vmulc(vload(p + pad(NH)), tw_read<T, row_qlg<T, LGNX>()>(tw, xt * MIXW + c + e));
+        const cx<T>* p = s + r * LD + pad(xt * mixw<T>() + c) + e;
+        const V uu = vload(p), t = vmulc(vload(p + pad(NH)), tw_read<T, row_qlg<T, LGNX>()>(tw, xt * mixw<T>() + c + e));
         oa.v[e] = vcx(vscale(vadd(uu, t), scale)); ob.v[e] = vcx(vscale(vsub(uu, t), scale));
         if (nyq >= 0 && (ky0 + r == 0 || ky0 + r == nyq)) { oa.v[e].y = T(0); ob.v[e].y = T(0); }
       }
-      cx<T>* gk = g + (size_t)ky0 * MIXW;                                  // uniform part of the address
-      const unsigned ia = (unsigned)((xt * NyhP + r) * MIXW + c), ib = (unsigned)(((xt + NH / MIXW) * NyhP + r) * MIXW + c);
+      cx<T>* gk = g + (size_t)ky0 * mixw<T>();                                  // uniform part of the address
+      const unsigned ia = (unsigned)((xt * NyhP + r) * mixw<T>() + c), ib = (unsigned)(((xt + NH / mixw<T>()) * NyhP + r) * mixw<T>() + c);
       if constexpr (wt_line<T>(Nx)) {                                   // hand-off: see handoff_store
         store_wt<16>(reinterpret_cast<char*>(gk) + ia * (unsigned)sizeof(cx<T>), &oa);
         store_wt<16>(reinterpret_cast<char*>(gk) + ib * (unsigned)sizeof(cx<T>), &ob);

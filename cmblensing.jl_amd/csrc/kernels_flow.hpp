@@ -199,8 +199,8 @@ __device__ __forceinline__ void npt_write_forward(cx<T>* s, const cx<T>* tw, XY&
 // compiler's s_waitcnt bookkeeping: nothing waits for them; they return during the transforms that follow, and `drain()` -- one s_waitcnt before the
 // workgroup's last stores -- makes sure that none can land in LDS that already belongs to another workgroup.
 template <typename T, int NT, int LGM, int C, int NARR> struct TouchTiles {
-  static constexpr int M = 1 << LGM, NyhP = mixed_rows(M + 1), RPL = 128 / (MIXW * (int)sizeof(cx<T>)), NL = (M + 1 + RPL - 1) / RPL;
-  static constexpr int NB = (C + MIXW - 1) / MIXW, K = (NL * NB + NT - 1) / NT;
+  static constexpr int M = 1 << LGM, NyhP = mixed_rows(M + 1), RPL = 128 / (mixw<T>() * (int)sizeof(cx<T>)), NL = (M + 1 + RPL - 1) / RPL;
+  static constexpr int NB = (C + mixw<T>() - 1) / mixw<T>(), K = (NL * NB + NT - 1) / NT;
   static constexpr int PAD_BYTES = 256;                                   // one wave-instruction of 64 lanes x 4 bytes; every wave uses the same pad
   // pad: LDS byte address of the pad (wave-uniform)
   __device__ __forceinline__ static void issue(const cx<T>* const (&g)[NARR > 0 ? NARR : 1] /*slice bases*/, int x0, unsigned pad) {
@@ -213,7 +213,7 @@ template <typename T, int NT, int LGM, int C, int NARR> struct TouchTiles {
         int i = threadIdx.x + k * NT;
         if (i >= NL * NB) i = NL * NB - 1;                                  // the spare lanes of the last round re-touch the last line
         const int blk = i / NL, ln = i - blk * NL;
-        const void* q = tg + ((size_t)blk * NyhP + (size_t)ln * RPL) * MIXW;
+        const void* q = tg + ((size_t)blk * NyhP + (size_t)ln * RPL) * mixw<T>();
         unsigned keep;
         // M0 (the LDS-DMA destination base) is compiler-reserved: set and restored inside the statement (cdna_hip_programming.md, LDS-DMA recipe)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(q), "s"(m0v) : "memory");
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NT, col_min_waves<T>(R, NT)) void k_adj_y(AdjYArgs<
   if constexpr (col_touch<T>(LGM)) { if (do_touch) Touch::drain(); }
   cx<T>* Wx = tile_base(a.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(a.Wy + moff, x0, NyhP);
   pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
-    const unsigned gi = tile_off<C>(k, c, x0, NyhP);
+    const unsigned gi = tile_off<T, C>(k, c, x0, NyhP);
     handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, lyr[i]));
   });
 }
@@ -616,7 +616,7 @@ __device__ __forceinline__ void delta_y_body(const DeltaYArgs<T>& d, unsigned ch
   {
     cx<T>* Wx = tile_base(d.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(d.Wy + moff, x0, NyhP);
     pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int k, int c, cx<T> A, cx<T> B) {
-      const unsigned gi = tile_off<C>(k, c, x0, NyhP);
+      const unsigned gi = tile_off<T, C>(k, c, x0, NyhP);
       handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, ps.l[i]));    // ly[k] is still in registers from the pair load (same entry mapping)
     });
   }
@@ -721,7 +721,7 @@ __device__ __forceinline__ void delta_y_body_pipelined(const DeltaYArgs<T>& d, u
     {
       cx<T>* Wx = tile_base(d.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(d.Wy + moff, x0, NyhP);
       pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int kk, int c, cx<T> A, cx<T> B) {
-        const unsigned gi = tile_off<C>(kk, c, x0, NyhP);
+        const unsigned gi = tile_off<T, C>(kk, c, x0, NyhP);
         handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, ps.l[i]));
       });
     }

@@ -85,6 +85,10 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *        "gen_separable", "gen_prologue", "gen_xderiv_fused"       any-size path stage fusions (CMBL_GEN_SEPARABLE / _PROLOGUE / _XDERIV_FUSED, all 1)
  *        "gen_ct"                                                   any-size path: compile-time-plan transforms for the lengths 2^a 3^b 5^c of
  *                                                                   CMBL_CT_LIST (CMBL_GEN_CT, 1; 0 = the run-time-planned kernel for every length)
+ *        "gen_ct_rows"                                              any-size path: x-pass launches with fewer row groups than CUs take groups of 4 / 2 rows instead
+ *                                                                   of 8 (CMBL_GEN_CT_ROWS, 1; results bit-identical either way)
+ *        "gen_xmerge"                                               any-size flows: the row update that closes an adjoint-type stage also runs the x passes that open the
+ *                                                                   next stage (CMBL_GEN_XMERGE, 1: 2 instead of 3 launches per stage; results bit-identical either way)
  *        "gen_yy"                                                   any-size flows: the passes of a stage that can share a launch do, where the axes have
  *                                                                   compile-time plans (CMBL_GEN_YY, 1; results bit-identical either way)
  *        "gen_slice_streams", "gen_streams_min_pix"                 any-size flows: one launch chain per group of slices from this many pixels

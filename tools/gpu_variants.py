@@ -1,4 +1,4 @@
-"""Time ∇lnP / (∇L)† at 1024² QU fp32 for each experiment build: python tools/gpu_variants.py lib1.so lib2.so ..."""
+"""Time ∇lnP / (∇L)† for each experiment build, interleaved: [N=1024 DTYPE=f32 NRK=7 POL=P] python tools/gpu_variants.py lib1.so lib2.so ..."""
 import os, subprocess, sys
 code = r'''
 import sys, os, time
@@ -6,11 +6,12 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import cmblensing_jl_amd as C
 from bench import synthetic_cls
-s = C.load_sim(2.0, 1024, "P", synthetic_cls(), T=torch.float32, pixel_mask=dict(pad_deg=1.0, apod_deg=1.0))
+s = C.load_sim(2.0, int(os.environ.get("N", 1024)), os.environ.get("POL", "P"), synthetic_cls(), T=torch.float64 if os.environ.get("DTYPE") == "f64" else torch.float32,
+               pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=int(os.environ.get("NRK", 7)))
 ds, f, phi = s["ds"], s["f"], s["phi"]
 fm = f.to(C.MAP); L = ds.L(phi); gl = fm.to(C.FOURIER); ft = L * fm
 fo, po = ds.mix(f, phi)
-def timeit(fn, n=20):
+def timeit(fn, n=int(os.environ.get("NT", 20))):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t = time.time()
     for _ in range(n): fn()
