@@ -2,7 +2,8 @@
 // bodies behind the entry points.  The build is split by explicit instantiation (lib.py builds the objects in parallel):
 //   api.hip                 extern "C" entry points, argument checks, error plumbing -- instantiates NO kernel
 //   tu_main_{f32,f64}.hip   every do_*<T> below (api_body.hpp) and with them Ctx<T>, Flow<T>, Dataset<T>, Drivers<T> and their kernels
-//   tu_gen_{f32,f64}.hip    the any-size transform launches (engine_gen.hpp: k_ct_*, k_gen_dft*)
+//   tu_gen_{f32,f64}.hip    the any-size transform launches (engine_gen.hpp: k_ct_dft*, k_ct_*_y, k_gen_dft*)
+//   tu_genx_{f32,f64}.hip   ... and their x-side stage launches (k_ct_dft2, k_ct_adj_x, k_ct_adj_x_dx)
 //   tu_small_{f32,f64}.hip  the one-launch flows of small maps (engine_small.hpp: k_small_flow, k_small_adj)
 // Rule that keeps api.hip free of kernels: it must not ODR-use a member function that launches (members defined in class are inline, and
 // an explicit instantiation DECLARATION does not stop inline functions from being instantiated -- [temp.explicit]/10); it calls do_*<T>

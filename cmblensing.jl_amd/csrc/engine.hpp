@@ -93,9 +93,10 @@ struct CtxBase {
     int gen_prologue = env_int("CMBL_GEN_PROLOGUE", 1) != 0;              //   pointwise work in the fetch of the consuming transform
     int gen_xderiv_fused = env_int("CMBL_GEN_XDERIV_FUSED", 1) != 0;      //   d/dx pass as one launch
     int gen_slice_streams = env_int("CMBL_GEN_SLICE_STREAMS", 1) != 0;    //   one launch chain per group of slices (Flow::gen_groups)
-    int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 1 << 21);   //   ... from this many pixels on (a quarter of it for >= 3 slices)
+    int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 1 << 19);   //   ... from this many pixels on (a quarter of it for >= 3 slices)
     int gen_yy = env_int("CMBL_GEN_YY", 1) != 0;                          //   the y passes of a forward stage in one launch (GenDft::yy; needs gen_ct)
     int gen_xmerge = env_int("CMBL_GEN_XMERGE", 1) != 0;                  //   the row update of an adjoint-type stage also opens the next stage (gen_x_adj_next): one launch less per stage
+    int gen_ct_cols = env_int("CMBL_GEN_CT_COLS", 1);                     //   half-width column groups in the fused y passes: 0 never, 1 for small launches (Ctx::ct_cols_per_group), 2 always
     int gen_ct_rows = env_int("CMBL_GEN_CT_ROWS", 1) != 0;                //   shorter row groups in x-pass launches with fewer groups than CUs (Ctx::ct_rows_per_group)
     int gen_ct = env_int("CMBL_GEN_CT", 1) != 0;                          //   compile-time plans for the lengths of CMBL_CT_LIST (kernels_ct.hpp)
     // launch geometry that fills the chip on small maps (profiles/r05_ab_occupancy_tiles.txt): narrower column tiles while a launch has
@@ -119,6 +120,7 @@ struct CtxBase {
     if (k == "gen_xderiv_fused") return &opts.gen_xderiv_fused;
     if (k == "gen_ct") return &opts.gen_ct;
     if (k == "gen_ct_rows") return &opts.gen_ct_rows;
+    if (k == "gen_ct_cols") return &opts.gen_ct_cols;
     if (k == "gen_xmerge") return &opts.gen_xmerge;
     if (k == "gen_yy") return &opts.gen_yy;
     if (k == "gen_slice_streams") return &opts.gen_slice_streams;
@@ -309,6 +311,15 @@ struct Ctx : CtxBase {
     if (!opts.gen_ct_rows) return S;
     while (S > std::max(per, ct_S<T>() / 4) && (rows * per + S - 1) / S < num_cus / 2) S >>= 1;
     return S;
+  }
+  // columns per workgroup of a fused y-pass launch over `cols` columns of `slices` slices: the full group `S` (64-byte pieces on the transposed
+  // side) unless the launch would then have fewer than 0.4 workgroups per CU -- then half (32-byte pieces, but transform phases with half the
+  // wavefronts per SIMD).  Measured (profiles/r06_ab_anysize_col_groups.txt): 768^2 QU, 96 groups per slice chain: (grad L)' -6 %, grad lnP -3 %;
+  // 1000^2 QU, 125 groups: +5 % -- hence the 0.4.  Option gen_ct_rows switches it off with the row groups.
+  int ct_cols_per_group(long cols, long slices, int S) const {
+    if (!opts.gen_ct_rows || S != ct_S<T>() || opts.gen_ct_cols == 0) return S;
+    if (opts.gen_ct_cols == 2) return S / 2;
+    return ((cols + S - 1) / S) * slices * 5 < 2L * num_cus ? S / 2 : S;
   }
   bool gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   void gen_dft(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
@@ -956,6 +967,8 @@ struct Flow {
   bool small_ok() const;
   void small_flow_map(const T* in, T* out, int P, int B, bool inverse);
   void small_flow_adj(const cx<T>* in, cx<T>* out, int P, int B, bool inverse);
+  bool small_delta_ok() const;
+  void small_flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk, const DphiTail<T>* tail);
 
   void check_ready(int B) const {
     CMBL_REQUIRE(Bphi >= 1, ERR_STATE, "cmbl_lenseflow_set_phi has not been called");
@@ -1319,6 +1332,7 @@ struct Flow {
                   bool h_ready = false, const DphiTail<T>* tail = nullptr) {
     check_ready(B);
     if (c->generic) { CMBL_REQUIRE(!tail, ERR_STATE, "fused tail on the any-size path"); return gen_flow_delta(f, df, dphi, P, B, forward_primal, alias_quirk); }
+    if (small_delta_ok()) return small_flow_delta(f, df, dphi, P, B, forward_primal, alias_quirk, tail);   // (a_ready / h_ready: f and df themselves are still the state)
     const long slices = (long)P * B, pl = c->plane(), mpl = c->mplane(), np = c->npix();
     const int nst = 4 * n;
     DevBuf& Ab = abuf ? *abuf : A;

@@ -84,10 +84,13 @@ void Ctx<T>::gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, 
   a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
   a.yy = 1; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext;
   slices = gen_window(a, slices);
-  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S<T>();
+  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S<T>());
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   switch (Ny) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_flow_y<T, n>), grid, ct_lds<T>(n), stream, a); return;
+#define CMBL_X(n) case n: \
+      if (a.S == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_flow_y<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
+      else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_flow_y<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
+      return;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
@@ -103,10 +106,13 @@ void Ctx<T>::gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<
   a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
   a.yy = 2; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext; a.yy_in3 = T3; a.yy_scale3 = s3; a.yy_out2 = W2a; a.yy_out3 = W2b;
   slices = gen_window(a, slices);
-  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S2<T>(Ny);
+  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S2<T>(Ny));
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   switch (Ny) {
-#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2, ct_S2<T>(n)) <= 160 * 1024) { CMBL_LAUNCH_NT(this, K_GEN_DFT, 128 * ct_S2<T>(n), (k_ct_delta_y<T, n>), grid, ct_lds<T>(n, 2, ct_S2<T>(n)), stream, a); return; } break;
+#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2, ct_S2<T>(n)) <= 160 * 1024) { \
+      if (a.S == ct_S2<T>(n)) CMBL_LAUNCH_NT(this, K_GEN_DFT, 128 * ct_S2<T>(n), (k_ct_delta_y<T, n, ct_S2<T>(n)>), grid, ct_lds<T>(n, 2, ct_S2<T>(n)), stream, a); \
+      else if constexpr (ct_S2<T>(n) == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_delta_y<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 2, ct_S<T>() / 2)), stream, a); \
+      return; } break;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: break;
@@ -216,10 +222,13 @@ void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, 
   a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
   a.yy = 3; a.yy_nout = Nyh; a.yy_out2 = W2a; a.yy_out3 = W2b;
   slices = gen_window(a, slices);
-  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_S<T>();
+  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S<T>());
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   switch (Ny) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_y<T, n>), grid, ct_lds<T>(n), stream, a); return;
+#define CMBL_X(n) case n: \
+      if (a.S == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_y<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
+      else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_adj_y<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
+      return;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
@@ -231,9 +240,11 @@ void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, 
   template void Ctx<T>::gen_dft(const GenAxis& ax, GenDft<T> a, long slices); \
   template void Ctx<T>::gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, bool last, long slices); \
   template void Ctx<T>::gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, cx<T>* W2a, cx<T>* W2b, bool last, long slices); \
+  template void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, int P, cx<T>* W2a, cx<T>* W2b, long slices);
+// (the x-side launches are compiled by a translation unit of their own, tu_genx_*.hip: the build is as long as its longest unit)
+#define CMBL_INSTANTIATE_GENX(T) \
   template bool Ctx<T>::gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices); \
   template void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, const RKCoef<T>& rk, cx<T>* t3, const cx<T>* A_next, cx<T>* gx, long slices); \
-  template void Ctx<T>::gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices); \
-  template void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, int P, cx<T>* W2a, cx<T>* W2b, long slices);
+  template void Ctx<T>::gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices);
 
 }  // namespace cmbl

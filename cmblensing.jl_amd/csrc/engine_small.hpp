@@ -63,9 +63,43 @@ void Flow<T>::small_flow_adj(const cx<T>* in, cx<T>* out, int P, int B, bool inv
   fail(ERR_STATE, "no small-map kernel for this shape");
 }
 
+// the delta flow in one launch: up to 64 x 64 pixels in single, 32 x 64 in double precision (the register state of both parts; SmallGeom::delta_fits)
+template <typename T>
+bool Flow<T>::small_delta_ok() const { return small_ok() && c->npix() * (long)sizeof(T) <= 4096 * 4; }
+
+template <typename T>
+void Flow<T>::small_flow_delta(T* f, cx<T>* df, cx<T>* dphi, int P, int B, bool forward_primal, bool alias_quirk, const DphiTail<T>* tail) {
+  const long slices = (long)P * B, pl = c->plane(), np = c->npix();
+  const int nst = 4 * n;
+  Wst.ensure(sizeof(T) * (size_t)nst * 2 * slices * np);
+  U5.ensure(sizeof(T) * 5 * B * np); F5.ensure(sizeof(cx<T>) * 5 * B * pl); tcbuf.ensure(sizeof(T) * 2 * nst);
+  const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
+  tc_host.resize(2 * (size_t)nst);
+  int it = 0;
+  for (int step = 0; step < n; ++step)
+    for (int stage = 1; stage <= 4; ++stage, ++it) {                      // the (t_s, c_s) table of the quadrature, as Flow::flow_delta fills it
+      const RKCoef<T> rk = coef(step, stage, t0, h, step == n - 1 && stage == 4);
+      tc_host[2 * it] = rk.t;
+      tc_host[2 * it + 1] = (T)((stage == 1 || stage == 4 ? 1.0 : 2.0) * h / 6);
+    }
+  SmallDeltaArgs<T> d{};
+  d.a = small_args(*this, f, f, P, forward_primal ? 2 * n : 0, forward_primal ? -1 : 1);
+  d.df = df; d.wst = Wst.as<T>(); d.slices = slices;
+  const int lgny = c->lgM + 1, lgnx = c->lgNx;
+  bool done = false;
+#define CMBL_X(ly_, lx_) if (!done && lgny == ly_ && lgnx == lx_) { using G = SmallGeom<T, ly_, lx_>; if constexpr (G::fits && G::delta_fits) { \
+    CMBL_LAUNCH_NT(c, K_DELTA_Y, G::NT, (k_small_delta<T, ly_, lx_>), dim3((unsigned)slices), G::lds, c->stream, d); done = true; } }
+  CMBL_SMALL_LIST(CMBL_X)
+#undef CMBL_X
+  if (!done) fail(ERR_STATE, "no small-map delta kernel for this shape");
+  dphi_finish(dphi, P, B, nst, alias_quirk, tail);
+}
+
 #define CMBL_INSTANTIATE_SMALL(T)                                                     \
   template bool Flow<T>::small_ok() const;                                            \
   template void Flow<T>::small_flow_map(const T*, T*, int, int, bool);                \
-  template void Flow<T>::small_flow_adj(const cx<T>*, cx<T>*, int, int, bool);
+  template void Flow<T>::small_flow_adj(const cx<T>*, cx<T>*, int, int, bool);       \
+  template bool Flow<T>::small_delta_ok() const;                                      \
+  template void Flow<T>::small_flow_delta(T*, cx<T>*, cx<T>*, int, int, bool, bool, const DphiTail<T>*);
 
 }  // namespace cmbl

@@ -18,7 +18,7 @@
 #include "kernels_generic.hpp"
 
 #ifndef CMBL_CT_LIST
-#define CMBL_CT_LIST(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(640) X(720) X(768) X(960) X(1000) X(1280) X(1536)
+#define CMBL_CT_LIST(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(640) X(720) X(768) X(960) X(1000) X(1280) X(1536) X(1920)
 #endif
 
 namespace cmbl {
@@ -36,7 +36,10 @@ template <typename T> constexpr int ct_S() { return 64 / (int)sizeof(cx<T>); }  
 template <typename T> constexpr size_t ct_lds(int N, int rowsets = 1, int S = ct_S<T>()) { return ((size_t)(N / 2) + (size_t)rowsets * S * ct_ld(N)) * sizeof(cx<T>); }
 // columns per workgroup of the delta-stage kernel (two LDS rows per column): the usual count, or half of it where that does not fit (Ny > ~1150;
 // the transposed side then moves 32-byte pieces)
-template <typename T> constexpr int ct_S2(int N) { return ct_lds<T>(N, 2) <= 160 * 1024 ? ct_S<T>() : ct_S<T>() / 2; }
+#ifndef CMBL_CT_S2_HALF
+#define CMBL_CT_S2_HALF 0      // 1: always half (A/B: shorter transform phases, 32-byte pieces on the transposed side)
+#endif
+template <typename T> constexpr int ct_S2(int N) { return (!CMBL_CT_S2_HALF && ct_lds<T>(N, 2) <= 160 * 1024) ? ct_S<T>() : ct_S<T>() / 2; }
 
 // fetch variants
 enum { CT_C = 0, CT_R1, CT_R2, CT_H1, CT_H2, CT_P1, CT_P2, CT_P3 };
@@ -361,7 +364,8 @@ __device__ __forceinline__ void ct_flow_stage(const GenDft<T>& a, cx<T>* __restr
   // the pixels' operands: requested before the transform so that they arrive under it (up to 12 pixels per lane, p(t) from the cache;
   // longer columns and the five-map form request them after it: the registers are the transform's)
   constexpr bool EARLY = E <= 12;
-  T px[E], py[E], y0v[E], acv[E];
+  constexpr int CHP = EARLY ? E : 8, NCP = (E + CHP - 1) / CHP;            // pixels per chunk of the late form (the operands of a chunk in flight together)
+  T px[CHP], py[CHP], y0v[CHP], acv[CHP];
   if constexpr (EARLY) {
 #pragma unroll
     for (int i = 0; i < E; ++i) {
@@ -372,31 +376,39 @@ __device__ __forceinline__ void ct_flow_stage(const GenDft<T>& a, cx<T>* __restr
     }
   }
   ct_transform<T, N>(row, tw, lane);
-  if constexpr (!EARLY) {
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-      const int n = min(lane + 64 * i, N - 1);
-      const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
-      y0v[i] = at32(e.y0 + mb, o); acv[i] = at32(e.acc + mb, o);
-      if (pc) { px[i] = at32(e.ph.pcx + pb, o); py[i] = at32(e.ph.pcy + pb, o); }
-    }
-  }
+  for (int c = 0; c < NCP; ++c) {
+    if constexpr (!EARLY) {
+      // long columns (> 12 pixels per lane; 30 at 1920 points): the operands of ALL pixels held at once spilled 100+ registers -- chunks of 8,
+      // kept apart by a scheduling fence
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < E; ++i) {
-    const int n0 = lane + 64 * i, n = min(n0, N - 1);
-    const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
-    if (!pc) {
-      T m11, m12, m22;
-      flow_pm(e.rk.t, at32(e.ph.gx + pb, o), at32(e.ph.gy + pb, o), at32(e.ph.hxx + pb, o), at32(e.ph.hyx + pb, o), at32(e.ph.hyy + pb, o), px[i], py[i], m11, m12, m22);
+      for (int ii = 0; ii < CHP; ++ii) {
+        const int n = min(lane + 64 * (c * CHP + ii), N - 1);
+        const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+        y0v[ii] = at32(e.y0 + mb, o); acv[ii] = at32(e.acc + mb, o);
+        if (pc) { px[ii] = at32(e.ph.pcx + pb, o); py[ii] = at32(e.ph.pcy + pb, o); }
+      }
     }
-    const cx<T> z = row[pad(n)];                                         // the e^{+i} transform is conj(forward(conj .)): y = conj(z)
-    const T gx = a.scale * z.x, gy = -a.scale2 * z.y;
-    const T k = px[i] * gx + py[i] * gy;
-    T y = y0v[i], ac = e.rk.stage == 1 ? T(0) : acv[i];
-    const T nxt = rk_update(e.rk, k, y, ac);
-    if (N % 64 == 0 || n0 < N) {
-      if (e.rk.stage == 4) at32(e.y0 + mb, o) = y; else at32(e.acc + mb, o) = ac;
-      row[pad(n)] = mk<T>(nxt, T(0));
+#pragma unroll
+    for (int ii = 0; ii < CHP; ++ii) {
+      const int i = c * CHP + ii, n0 = lane + 64 * i, n = min(n0, N - 1);
+      if (i < E) {
+        const unsigned o = (unsigned)seq * (unsigned)N + (unsigned)n;
+        if (!pc) {
+          T m11, m12, m22;
+          flow_pm(e.rk.t, at32(e.ph.gx + pb, o), at32(e.ph.gy + pb, o), at32(e.ph.hxx + pb, o), at32(e.ph.hyx + pb, o), at32(e.ph.hyy + pb, o), px[ii], py[ii], m11, m12, m22);
+        }
+        const cx<T> z = row[pad(n)];                                       // the e^{+i} transform is conj(forward(conj .)): y = conj(z)
+        const T gx = a.scale * z.x, gy = -a.scale2 * z.y;
+        const T k = px[ii] * gx + py[ii] * gy;
+        T y = y0v[ii], ac = e.rk.stage == 1 ? T(0) : acv[ii];
+        const T nxt = rk_update(e.rk, k, y, ac);
+        if (N % 64 == 0 || n0 < N) {
+          if (e.rk.stage == 4) at32(e.y0 + mb, o) = y; else at32(e.acc + mb, o) = ac;
+          row[pad(n)] = mk<T>(nxt, T(0));
+        }
+      }
     }
   }
   if (a.yy_last) return;
@@ -497,9 +509,10 @@ __global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_dftx
 // rfft_y(f_next) stored as a half spectrum in the layout of the inputs.  A kernel of its own: its register needs are not k_ct_dft's.
 // (register budget: ONE workgroup per CU -- the operands of the pixels are held across a transform; at the sizes where a second resident
 // workgroup would matter the launch has more workgroups than CUs anyway and the slice streams overlap the chains)
-template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_flow_y(GenDft<T> a) {
-  constexpr int S = ct_S<T>(), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
+// (S: columns per workgroup -- the full 64-byte group, or half of it for launches that would otherwise leave most CUs idle: Ctx::ct_cols_per_group)
+template <typename T, int N, int S = ct_S<T>()>
+__global__ __launch_bounds__(64 * S, 1) void k_ct_flow_y(GenDft<T> a) {
+  constexpr int NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_fl
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   TwStage<T, NT, NTW> twr;
   twr.issue(a.tw);
-  ct_fetch<T, N, CT_H2, true>(a, s, sl, seq0, true);
+  ct_fetch<T, N, CT_H2, true, S>(a, s, sl, seq0, true);
   twr.commit(tw);
   __syncthreads();
   if (seq0 + wave < a.nseq) ct_flow_stage<T, N>(a, s + wave * LD, tw, sl, seq0 + wave, lane);
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_fl
   GenDft<T> b{};                                                         // the store side: rfft_y(f_next) as a half spectrum, [ky][x]
   b.out = a.yy_out; b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1);
   b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
-  ct_store_rows<T, N>(b, s, sl, seq0, true, wave, lane, false);
+  ct_store_rows<T, N, S>(b, s, sl, seq0, true, wave, lane, false);
 }
 
 // The four y passes of a delta-flow stage in one launch (GenDft::yy = 2; Ctx::gen_y_delta_stage): the c2r of ifft_x(delta f) -> L(df), the pair
@@ -527,9 +540,9 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_fl
 // fetches, the two inverse transforms, the two forward transforms and the two stores each run side by side (the first version ran a
 // column's four transforms on one wavefront: 23.4 us per launch at 768^2, profiles/r05_kernel_stats_768QU_f32_anysize_pre2w.csv); the
 // pointwise part is split between them in alternating 64-pixel pieces.  Four workgroup barriers.
-template <typename T, int N>
-__global__ __launch_bounds__(128 * ct_S2<T>(N)) void k_ct_delta_y(GenDft<T> a) {
-  constexpr int S = ct_S2<T>(N), NTH = 64 * S, NT = 2 * NTH, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64, EH = (E + 1) / 2;
+template <typename T, int N, int S = ct_S2<T>(N)>
+__global__ __launch_bounds__(128 * S) void k_ct_delta_y(GenDft<T> a) {
+  constexpr int NTH = 64 * S, NT = 2 * NTH, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64, EH = (E + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
@@ -602,9 +615,9 @@ __global__ __launch_bounds__(128 * ct_S2<T>(N)) void k_ct_delta_y(GenDft<T> a) {
 
 // The y passes of an adjoint flow stage in one launch (GenDft::yy = 3; Ctx::gen_y_adj_stage): c2r of yy_in3 = ifft_x(y) -> the map y, the
 // pair (p_x y, p_y y) (src/lenseflow.jl:166-170), its pair r2c split into yy_out2 / yy_out3.  One LDS row per column.
-template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_adj_y(GenDft<T> a) {
-  constexpr int S = ct_S<T>(), NT = 64 * S, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64;
+template <typename T, int N, int S = ct_S<T>()>
+__global__ __launch_bounds__(64 * S, 1) void k_ct_adj_y(GenDft<T> a) {
+  constexpr int NT = 64 * S, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64;
   constexpr int PCH = E <= 12 ? E : (E + ((E + 11) / 12) - 1) / ((E + 11) / 12), NPC = (E + PCH - 1) / PCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_ad
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   TwStage<T, NT, NTW> twr;
   twr.issue(a.tw);
-  ct_fetch<T, N, CT_H1, false>(a, s, sl, seq0, true);
+  ct_fetch<T, N, CT_H1, false, S>(a, s, sl, seq0, true);
   twr.commit(tw);
   __syncthreads();
   const int seq = seq0 + wave;
@@ -653,7 +666,7 @@ __global__ __launch_bounds__(64 * ct_S<T>(), ct_min_waves<T>() / 2) void k_ct_ad
   b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1); b.scale2 = T(1);
   b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
   b.out = a.yy_out2; b.out2 = a.yy_out3; b.in2 = a.yy_out3;              // in2 != nullptr marks the pair split (ct_put)
-  ct_store_rows<T, N>(b, s, sl, seq0, true, wave, lane, false);
+  ct_store_rows<T, N, S>(b, s, sl, seq0, true, wave, lane, false);
 }
 
 // The x pass that closes an adjoint-type stage in one launch (Ctx::gen_x_adj_update): fft_x of both members of the velocity pair and the RK

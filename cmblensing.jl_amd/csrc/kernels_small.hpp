@@ -34,6 +34,13 @@ template <typename T, int LGNY, int LGNX> struct SmallGeom {
   static constexpr int NT = NPIX / 4 < NTMAX ? NPIX / 4 : NTMAX;
   static constexpr int PPT = NPIX / NT, FPT = (NF + NT - 1) / NT;          // pixels / Fourier modes per thread
   static constexpr int MAXLG = (sizeof(T) == 8 || WORDS > 8192) ? 3 : 4;   //                    // largest radix of a stage: 16 (8 in double precision: 64 registers of operands)
+  // per-stage address recomputation (see the kernels) from 8 pixels per thread on; below that the registers have room for the hoisted
+  // addresses and the stage saves their arithmetic: 64^2 L*f 0.146 -> 0.119 ms, L'g 0.167 -> 0.146 ms (profiles/r06_ab_small_flow.txt)
+#ifndef CMBL_SMALL_LAUNDER_PPT
+#define CMBL_SMALL_LAUNDER_PPT 8
+#endif
+  static constexpr bool LAUNDER = PPT >= CMBL_SMALL_LAUNDER_PPT;
+  static constexpr bool delta_fits = NPIX * (int)sizeof(T) <= 4096 * 4;     // the one-launch delta flow: 64 x 64 in single, 32 x 64 in double precision
   static constexpr size_t lds = ((size_t)NTW + (size_t)Nx * LDY) * sizeof(cx<T>);
   // (double precision up to 64 x 64: beyond that the adjoint kernel's state does not fit the register file of a 512-thread workgroup)
   static constexpr bool fits = lds <= 160 * 1024 && LGNY >= 5 && LGNX >= 5 && LGNY <= 7 && LGNX <= 7 && (sizeof(T) == 4 || NPIX <= 4096);
@@ -204,7 +211,7 @@ __global__ __launch_bounds__((SmallGeom<T, LGNY, LGNX>::NT)) void k_small_flow(S
       // the thread index as a value the compiler cannot see through: every address below is recomputed per stage.  With the plain index all of
       // them are invariants of the 4n-stage loop, get hoisted out of it and are kept live across it (65-126 spilled registers at 128^2)
       int tid = tid0;
-      asm volatile("" : "+v"(tid));
+      if constexpr (G::LAUNDER) asm volatile("" : "+v"(tid));
       // A = rfft_y(f) by columns: M-point DIF + post -> W[x][hslot(ky)]
       sm_dif<T, NT, Nx, LDY, 1, LGM, LGNTW, G::MAXLG>(W, W, tw, tid);
       sm_r2c_post<T, G>(W, tw, tid);
@@ -316,7 +323,7 @@ __global__ __launch_bounds__((SmallGeom<T, LGNY, LGNX>::NT)) void k_small_adj(Sm
       // the thread index as a value the compiler cannot see through: every address below is recomputed per stage.  With the plain index all of
       // them are invariants of the 4n-stage loop, get hoisted out of it and are kept live across it (65-126 spilled registers at 128^2)
       int tid = tid0;
-      asm volatile("" : "+v"(tid));
+      if constexpr (G::LAUNDER) asm volatile("" : "+v"(tid));
       // y = irfft2(Y): inverse x transform by ky slots, c2r by columns (packed: pixel (x, y) at the real view)
       sm_dit<T, NT, Nyh, 1, LDY, LGNX, LGNTW, G::MAXLG>(W, tw, tid);
       sm_c2r_pre<T, G>(W, tw, tid);
@@ -397,6 +404,173 @@ __global__ __launch_bounds__((SmallGeom<T, LGNY, LGNX>::NT)) void k_small_adj(Sm
     }
 #pragma unroll
   for (int i = 0; i < FPT; ++i) { const int e = tid0 + i * NT; if (e < G::NF) out[e] = mk<T>(Y0r[i], Y0i[i]); SM_FENCE(i); }
+}
+
+// ---- (grad L)': the delta flow (src/lenseflow.jl:176-214, src/flowops.jl:40-68) on (f [map], delta f [Fourier half plane]) -- both parts of a stage
+// with the half plane pair of W used twice: the f part as in k_small_flow (its gradient stays in registers), then the delta-f part as in
+// k_small_adj.  The stage's products L(delta f) grad f go to the per-stage buffer of the staged path (Flow::Wst), so that delta-phi is formed
+// by the same end-of-flow quadrature (Flow::dphi_finish: k_dphi_reduce, five transforms, the l-multipliers).  Up to 64 x 64 pixels.
+template <typename T> struct SmallDeltaArgs {
+  SmallArgs<T> a;                         // a.in / a.out: the map f (may alias); the rest as for the flows
+  cx<T>* df;                              // delta f, F layout, updated in place
+  T* wst;                                 // [4n][2][slices][npix] products
+  long slices;
+};
+template <typename T, int LGNY, int LGNX>
+__global__ __launch_bounds__((SmallGeom<T, LGNY, LGNX>::NT)) void k_small_delta(SmallDeltaArgs<T> d) {
+  using G = SmallGeom<T, LGNY, LGNX>;
+  constexpr int NT = G::NT, Ny = G::Ny, Nx = G::Nx, M = G::M, Nyh = G::Nyh, LDY = G::LDY, PPT = G::PPT, FPT = G::FPT, LGM = G::LGM, LGNTW = G::LGNTW;
+  const SmallArgs<T>& a = d.a;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
+  cx<T>* W = tw + G::NTW;
+  T* Wf = reinterpret_cast<T*>(W);
+  const int tid0 = threadIdx.x;
+  const size_t sl = blockIdx.x, mb = sl * (size_t)G::NPIX, fb = sl * (size_t)G::NF;
+  const size_t ps = (size_t)a.Bphi * G::NPIX, pb = (size_t)(a.Bphi == 1 ? 0 : sl / a.P) * G::NPIX;
+  cx<T>* dfp = d.df + fb;
+  for (int i = tid0; i < G::NTW; i += NT) tw[i] = a.tw[i];
+  T y0[PPT], acc[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int p = tid0 + i * NT;
+    y0[i] = a.in[mb + p]; acc[i] = T(0);
+    Wf[(p >> LGNY) * (2 * LDY) + (p & (Ny - 1))] = y0[i];
+  }
+  T Y0r[FPT], Y0i[FPT], Yar[FPT], Yai[FPT], nr[FPT], ni[FPT];               // (separate real / imaginary arrays: see k_small_adj)
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    const cx<T> v = dfp[min(tid0 + i * NT, G::NF - 1)];
+    Y0r[i] = v.x; Y0i[i] = v.y; Yar[i] = T(0); Yai[i] = T(0); nr[i] = v.x; ni[i] = v.y;
+  }
+  __syncthreads();
+  const T sx = T(1) / (T(Nx) * T(Ny)), sy = T(1) / T(Ny), sc = sx;
+  int kt = a.k0, it = 0;
+  for (int step = 0; step < a.n; ++step)
+    for (int stage = 1; stage <= 4; ++stage, ++it) {
+      int tid = tid0;
+      if constexpr (PPT >= 4) asm volatile("" : "+v"(tid));               // (both parts of a stage hold state: the addresses are recomputed from 4 pixels per thread on)
+      // ---- f part: (d/dx f, d/dy f) of the stage input at this thread's pixels
+      sm_dif<T, NT, Nx, LDY, 1, LGM, LGNTW, G::MAXLG>(W, W, tw, tid);
+      sm_r2c_post<T, G>(W, tw, tid);
+      sm_dif<T, NT, Nyh, 1, LDY, LGNX, LGNTW, G::MAXLG>(W, W + Nyh, tw, tid);
+      sm_dit<T, NT, Nyh, 1, LDY, LGNX, LGNTW, G::MAXLG>(W + Nyh, tw, tid, [&](cx<T> v, int, int xs) { return mul_il(v, a.lx_r[xs]); });
+      {
+        constexpr int NIT = (Nx * Nyh + NT - 1) / NT;
+        cx<T> za[NIT], zb[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int q = tid + i * NT, k = q / Nx, x = q - k * Nx;
+          if (q < Nx * Nyh) {
+            const int s = sm_hslot<LGM>(k);
+            const cx<T> A = W[x * LDY + s], Gv = W[x * LDY + Nyh + s];
+            const T l = a.ly[k];
+            if (k == 0 || k == M) { za[i] = mk<T>(Gv.x, -l * A.y); zb[i] = za[i]; }
+            else { za[i] = mk<T>(Gv.x - l * A.x, Gv.y - l * A.y); zb[i] = mk<T>(Gv.x + l * A.x, -Gv.y - l * A.y); }
+          }
+          SM_FENCE(i);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int q = tid + i * NT, k = q / Nx, x = q - k * Nx;
+          if (q < Nx * Nyh) {
+            W[x * LDY + brevc<LGNY>(k)] = za[i];
+            if (k != 0 && k != M) W[x * LDY + brevc<LGNY>(Ny - k)] = zb[i];
+          }
+          SM_FENCE(i);
+        }
+        __syncthreads();
+      }
+      T px[PPT], py[PPT];
+      {
+        const T* pc = a.pcache + (size_t)(2 * kt) * ps + pb;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) { px[i] = pc[tid + i * NT]; py[i] = pc[ps + tid + i * NT]; }
+      }
+      sm_dit<T, NT, Nx, LDY, 1, LGNY, LGNTW, G::MAXLG>(W, tw, tid);
+      T gx[PPT], gy[PPT];
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * NT;
+        const cx<T> z = W[(p >> LGNY) * LDY + (p & (Ny - 1))];
+        gx[i] = sx * z.x; gy[i] = sy * z.y;
+      }
+      __syncthreads();
+      // ---- delta f part: L(delta f) = irfft2 of the stage input (registers nr / ni) at this thread's pixels
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) {
+        const int e = tid + i * NT;
+        if (e < G::NF) W[(e & (Nx - 1)) * LDY + sm_hslot<LGM>(e >> LGNX)] = mk<T>(nr[i], ni[i]);
+      }
+      __syncthreads();
+      sm_dit<T, NT, Nyh, 1, LDY, LGNX, LGNTW, G::MAXLG>(W, tw, tid);
+      sm_c2r_pre<T, G>(W, tw, tid);
+      sm_dit<T, NT, Nx, LDY, 1, LGM, LGNTW, G::MAXLG>(W, tw, tid);
+      T l[PPT];
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) { const int p = tid + i * NT; l[i] = sc * Wf[(p >> LGNY) * (2 * LDY) + (p & (Ny - 1))]; }
+      __syncthreads();
+      // products for the delta-phi quadrature, the f velocity with its RK update, the delta-f velocity pair as one complex column per x
+      const bool last = step == a.n - 1 && stage == 4;
+      const RKCoef<T> rk = sm_coef(a, stage, last);
+      T* w1 = d.wst + ((size_t)(2 * it) * d.slices + sl) * G::NPIX;
+      T* w2 = w1 + (size_t)d.slices * G::NPIX;
+      T nf[PPT];
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * NT;
+        __builtin_nontemporal_store(l[i] * gx[i], w1 + p);
+        __builtin_nontemporal_store(l[i] * gy[i], w2 + p);
+        const T k = px[i] * gx[i] + py[i] * gy[i];
+        nf[i] = rk_update(rk, k, y0[i], acc[i]);
+        W[(p >> LGNY) * LDY + (p & (Ny - 1))] = mk<T>(px[i] * l[i], py[i] * l[i]);
+      }
+      __syncthreads();
+      sm_dif<T, NT, Nx, LDY, 1, LGNY, LGNTW, G::MAXLG>(W, W, tw, tid);
+      {
+        constexpr int NIT = (Nx * Nyh + NT - 1) / NT;
+        cx<T> wa[NIT], wb[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int q = tid + i * NT, k = q / Nx, x = q - k * Nx;
+          if (q < Nx * Nyh) {
+            const cx<T> z = W[x * LDY + brevc<LGNY>(k)], zr = conj(W[x * LDY + brevc<LGNY>((Ny - k) & (Ny - 1))]);
+            wa[i] = mk<T>(T(0.5) * (z.x + zr.x), T(0.5) * (z.y + zr.y));
+            const cx<T> dd = mk<T>(T(0.5) * (z.x - zr.x), T(0.5) * (z.y - zr.y));
+            wb[i] = mk<T>(dd.y, -dd.x);
+          }
+          SM_FENCE(i);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int q = tid + i * NT, k = q / Nx, x = q - k * Nx;
+          if (q < Nx * Nyh) { W[x * LDY + k] = wa[i]; W[x * LDY + Nyh + k] = wb[i]; }
+          SM_FENCE(i);
+        }
+        __syncthreads();
+      }
+      sm_dif<T, NT, 2 * Nyh, 1, LDY, LGNX, LGNTW, G::MAXLG>(W, W, tw, tid);
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) {
+        const int e = min(tid + i * NT, G::NF - 1);
+        const int ky = e >> LGNX, xr = e & (Nx - 1);
+        const cx<T> kv = mul_il(W[xr * LDY + ky], a.lx_r[xr]) + mul_il(W[xr * LDY + Nyh + ky], a.ly[ky]);
+        nr[i] = rk_update(rk, kv.x, Y0r[i], Yar[i]);
+        ni[i] = rk_update(rk, kv.y, Y0i[i], Yai[i]);
+      }
+      if (last) break;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) { const int p = tid + i * NT; Wf[(p >> LGNY) * (2 * LDY) + (p & (Ny - 1))] = nf[i]; }
+      __syncthreads();
+      kt += a.dir * (stage == 1 || stage == 3 ? 1 : 0);
+    }
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) a.out[mb + tid0 + i * NT] = y0[i];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) { const int e = tid0 + i * NT; if (e < G::NF) dfp[e] = mk<T>(Y0r[i], Y0i[i]); }
 }
 
 }  // namespace cmbl

@@ -35,7 +35,7 @@ def library_path():
 
 # translation units of the library (csrc/api_decl.hpp has the map): the entry points, and per precision the typed bodies with the
 # power-of-two kernels and the any-size transform launches.  Built in parallel, one object each, then linked.
-UNITS = ["api", "tu_main_f32", "tu_main_f64", "tu_gen_f32", "tu_gen_f64", "tu_small_f32", "tu_small_f64"]
+UNITS = ["tu_gen_f32", "tu_gen_f64", "tu_genx_f32", "tu_genx_f64", "tu_main_f32", "tu_main_f64", "tu_small_f32", "tu_small_f64", "api"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

@@ -87,6 +87,9 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *                                                                   CMBL_CT_LIST (CMBL_GEN_CT, 1; 0 = the run-time-planned kernel for every length)
  *        "gen_ct_rows"                                              any-size path: x-pass launches with fewer row groups than CUs take groups of 4 / 2 rows instead
  *                                                                   of 8 (CMBL_GEN_CT_ROWS, 1; results bit-identical either way)
+ *        "gen_ct_cols"                                              any-size flows: half-width column groups (4 instead of 8 columns in single precision) in the fused y
+ *                                                                   launches: 0 never, 1 (default) for launches below 0.4 workgroups per CU, 2 always (CMBL_GEN_CT_COLS;
+ *                                                                   results bit-identical)
  *        "gen_xmerge"                                               any-size flows: the row update that closes an adjoint-type stage also runs the x passes that open the
  *                                                                   next stage (CMBL_GEN_XMERGE, 1: 2 instead of 3 launches per stage; results bit-identical either way)
  *        "gen_yy"                                                   any-size flows: the passes of a stage that can share a launch do, where the axes have

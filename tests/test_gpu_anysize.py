@@ -80,6 +80,54 @@ def test_compile_time_plans_posterior_gradient_768():
     TP.test_logpdf_mixed_and_gradient("f32", "P", (768, 768), scale32=10.0)
 
 
+CT_LIST = (96, 160, 192, 320, 360, 384, 480, 640, 720, 768, 960, 1000, 1280, 1536, 1920)     # CMBL_CT_LIST of csrc/kernels_ct.hpp
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("N", CT_LIST)
+def test_every_compile_time_plan_against_numpy_and_the_run_time_plans(prec, N):
+    """every length of CMBL_CT_LIST, on either axis (N x 96 and 96 x N): rfft2 against NumPy's pocketfft, the round trip, and the compile-time-plan
+    kernel against the run-time-plan kernel behind the same launch (that comparison covered 96 and 160 only)"""
+    C = _pkg()
+    tT, nT = DT[prec]
+    rng = np.random.default_rng(N)
+    for Ny, Nx in ((N, 96), (96, N)):
+        p = C.ProjLambert(Ny, Nx, 2.0, tT, 0)
+        x = rng.standard_normal((1, 2, Nx, Ny)).astype(nT)
+        want = np.fft.rfft2(x.astype(np.float64), axes=(-2, -1))
+        res = {}
+        for ct in (1, 0):
+            p.set_option("gen_ct", ct)
+            F = p.rfft(p.tensor(x))
+            res[ct] = (F.cpu().numpy(), p.irfft(F).cpu().numpy())
+        close(f"rfft2 {Ny}x{Nx}", res[1][0], want, 1.5e-6 if prec == "f32" else 1e-12)
+        close(f"irfft2(rfft2) {Ny}x{Nx}", res[1][1], x, 1.5e-6 if prec == "f32" else 1e-12)
+        close(f"compile-time vs run-time plan rfft2 {Ny}x{Nx}", res[1][0], res[0][0], 1.5e-6 if prec == "f32" else 1e-12)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_longest_compile_time_plan_in_the_flows(camb, prec, monkeypatch):
+    """1920 points (30 elements per lane: chunked operand loads, one workgroup per CU) on the column side and on the row side of the fused any-size
+    stage kernels: flows and the delta-flow gradient against the oracle at 1920 x 96 and 96 x 1920"""
+    monkeypatch.setitem(TP.TOL, "f32", TOL32_PATCH)
+    C = _pkg()
+    tT, nT = DT[prec]
+    for Ny, Nx in ((1920, 96), (96, 1920)):
+        oproj, simf, simp = sims(camb, Ny, Nx, 2, 1)
+        f, g, phi = simf(1).astype(nT).astype(np.float64), simf(11).astype(nT).astype(np.float64), simp(2, 1).astype(nT).astype(np.float64)
+        OL = TP.OLenseFlow(oproj, phi, 7)
+        p = C.ProjLambert(Ny, Nx, 2.0, tT)
+        F = lambda a, b: C.Field(p, p.tensor(a), b)
+        L = C.LenseFlow(p, 7)(F(phi, C.MAP))
+        gl = O.rfft2(g)
+        tol = TP.TOL[prec]
+        close(f"L*f {Ny}x{Nx}", (L * F(f, C.MAP)).arr.cpu().numpy(), OL.apply(f), tol["flow"])
+        close(f"L\\f {Ny}x{Nx}", L.ldiv(F(f, C.MAP)).arr.cpu().numpy(), OL.inv(f), tol["flow"])
+        close(f"L'g {Ny}x{Nx}", (L.adjoint * F(gl, C.FOURIER)).arr.cpu().numpy(), OL.adj(gl), tol["adj"])
+        close(f"L'\\g {Ny}x{Nx}", L.adjoint.ldiv(F(gl, C.FOURIER)).arr.cpu().numpy(), OL.invadj(gl), tol["adj"])
+        TP.test_lenseflow_gradient(camb, prec, Ny, Nx, 2, 1, 1, "fwd", 7)
+
+
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_compile_time_plans_equal_run_time_plans(camb, prec):
     """the two any-size transform kernels (compile-time plans, kernels_ct.hpp; run-time plans, kernels_generic.hpp) behind the same
@@ -168,6 +216,7 @@ def test_anysize_row_group_height_changes_no_result(camb, prec, Ny, Nx, P):
     res = {}
     for on in (0, 1):
         p.set_option("gen_ct_rows", on)
+        p.set_option("gen_ct_cols", 2 * on)                                 # 2: half-width column groups in every fused y launch
         p.set_option("gen_xmerge", on)
         L = C.LenseFlow(p, 7)(C.Field(p, p.tensor(phi), C.MAP))
         ft = L * C.Field(p, p.tensor(f), C.MAP)

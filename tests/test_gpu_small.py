@@ -72,3 +72,52 @@ def test_small_flow_result_does_not_depend_on_the_batch(camb, prec):
         one = _flows(C, C.LenseFlow(p, 7)(F(phi[b:b + 1], C.MAP)), F, f[b:b + 1], gl[b:b + 1])
         for k in allb:
             assert torch.equal(allb[k][b:b + 1], one[k]), (k, b)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("Ny,Nx,P,B,Bphi", [(64, 64, 2, 2, 2), (32, 64, 3, 1, 1), (64, 32, 1, 3, 1), (32, 32, 2, 1, 1)])
+@pytest.mark.parametrize("mode", ["fwd", "inv"])
+def test_small_delta_flow_vs_oracle_and_vs_the_staged_path(camb, prec, Ny, Nx, P, B, Bphi, mode):
+    """the pullback of L*f / L\\f (the delta flow: f, delta f and the delta-phi quadrature) as ONE launch per flow (k_small_delta + the shared
+    end-of-flow quadrature), both settings of the alias quirk"""
+    import cmblensing_jl_amd as C
+    tT, nT = DT[prec]
+    n = 7
+    oproj, simf, simp = sims(camb, Ny, Nx, P, B)
+    f = simf(1).astype(nT).astype(np.float64)
+    phi = simp(2, Bphi).astype(nT).astype(np.float64)
+    OL = OLenseFlow(oproj, phi, n)
+    fe = (OL.apply(f) if mode == "fwd" else OL.inv(f)).astype(nT).astype(np.float64)
+    delta = O.rfft2(simf(7)).astype(np.complex64 if prec == "f32" else np.complex128).astype(np.complex128)
+    p = C.ProjLambert(Ny, Nx, 2.0, tT)
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    L = C.LenseFlow(p, n)(F(phi, C.MAP))
+    fm = C.FLOW_FWD if mode == "fwd" else C.FLOW_INV
+    has_kernel = Ny * Nx * (4 if prec == "f32" else 8) <= 4096 * 4              # SmallGeom::delta_fits
+    for quirk in (False, True):
+        f0, df, dp = (OL.grad_apply if mode == "fwd" else OL.grad_inv)(fe, delta, alias_quirk=quirk)
+        p.set_option("small_flow", 0)
+        sdp, sdf, sf0 = L.gradient(fm, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=quirk)
+        p.set_option("small_flow", 1)
+        gdp, gdf, gf0 = L.gradient(fm, F(fe, C.MAP), F(delta, C.FOURIER), alias_quirk=quirk)
+        close(("small f", quirk), gf0.arr.cpu().numpy(), f0, TOL[prec]["flow"])
+        close(("small df", quirk), gdf.arr.cpu().numpy(), df, TOL[prec]["adj"])
+        close(("small dphi", quirk), gdp.arr.cpu().numpy(), dp, TOL[prec]["grad"])
+        close(("small vs staged dphi", quirk), gdp.arr.cpu().numpy(), sdp.arr.cpu().numpy(), TOL[prec]["grad"])
+        assert bool(torch.equal(gdp.arr, sdp.arr)) == (not has_kernel)
+
+
+def test_small_delta_flow_result_does_not_depend_on_the_batch(camb):
+    import cmblensing_jl_amd as C
+    Ny, Nx, P, B = 64, 64, 2, 4
+    oproj, simf, simp = sims(camb, Ny, Nx, P, B)
+    f = simf(1).astype(np.float32)
+    phi = simp(2, B).astype(np.float32)
+    delta = O.rfft2(simf(7)).astype(np.complex64)
+    p = C.ProjLambert(Ny, Nx, 2.0, torch.float32)
+    F = lambda a, b: C.Field(p, p.tensor(a), b)
+    allb = C.LenseFlow(p, 7)(F(phi, C.MAP)).gradient(C.FLOW_FWD, F(f, C.MAP), F(delta, C.FOURIER))
+    for b in (1, 3):
+        one = C.LenseFlow(p, 7)(F(phi[b:b + 1], C.MAP)).gradient(C.FLOW_FWD, F(f[b:b + 1], C.MAP), F(delta[b:b + 1], C.FOURIER))
+        for x, y in zip(allb, one):
+            assert torch.equal(x.arr[b:b + 1], y.arr)

@@ -1,1 +1,2 @@
-for s in 8 4; do for cfg in "768 P f32" "1000 P f32" "768 IP f32"; do echo "# CMBL_XMERGE_S=$s $cfg"; CMBL_XMERGE_S=$s python tools/gpu_time.py $cfg 2>&1 | grep "L'\*g\|∇L\|∇lnP"; done; done | tee gpurun_out/r06_xmerge_s.txt
+python -m pytest tests/test_gpu_small.py -q -x 2>&1 | tail -5
+bash tools/run_small_ab.sh; cat gpurun_out/r06_small_ab.txt

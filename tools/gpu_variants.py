@@ -7,7 +7,7 @@ import numpy as np, torch
 import cmblensing_jl_amd as C
 from bench import synthetic_cls
 s = C.load_sim(2.0, int(os.environ.get("N", 1024)), os.environ.get("POL", "P"), synthetic_cls(), T=torch.float64 if os.environ.get("DTYPE") == "f64" else torch.float32,
-               pixel_mask=dict(pad_deg=1.0, apod_deg=1.0), nsteps=int(os.environ.get("NRK", 7)))
+               pixel_mask=dict(pad_deg=1.0, apod_deg=1.0) if int(os.environ.get("N", 1024)) >= 256 else dict(pad_deg=0.2, apod_deg=0.2), nsteps=int(os.environ.get("NRK", 7)))
 ds, f, phi = s["ds"], s["f"], s["phi"]
 fm = f.to(C.MAP); L = ds.L(phi); gl = fm.to(C.FOURIER); ft = L * fm
 fo, po = ds.mix(f, phi)
