@@ -627,7 +627,7 @@ def main():
                 ms_rt = timeit(lambda: sima["ds"].gradient_logpdf_mixed(foa, poa), n=5)
                 sima["proj"].set_option("gen_ct", 1)
                 ex["any_size_768"] = {"ms_per_step": ms_ct, "ms_per_step_run_time_plans": ms_rt,
-                                      "note": f"{Na}² {pol} fp32, the same ∇logpdf(Mixed) step through the any-size path (DESIGN.md §2, profiles/r05_anysize_times.txt)"}
+                                      "note": f"{Na}² {pol} fp32, the same ∇logpdf(Mixed) step through the any-size path (DESIGN.md §4.3, profiles/r06_anysize_times.txt)"}
                 del sima, foa, poa
             out["extras"] = ex
     dev_exact = None
