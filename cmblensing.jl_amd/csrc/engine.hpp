@@ -486,7 +486,7 @@ struct Ctx : CtxBase {
 #undef CMBL_X
       };
       for (const auto& e : list)
-        if (e[0] == lgM && e[2] == 512 && (((long)e[1] * e[2]) >> lgM) == 2 && ldsY(2, true) <= 160 * 1024) return TileY{2, e[2], e[1]};
+        if (e[0] == lgM && e[2] == (opts.col_pipeline >= 2 ? 256 : 512) && (((long)e[1] * e[2]) >> lgM) == 2 && ldsY(2, true) <= 160 * 1024) return TileY{2, e[2], e[1]};   // (col_pipeline = 2, experiment builds: the 256-thread tile, whose 512 registers per thread hold a prefetched head tile)
       return t;
     }
     return tileY(slices, true);

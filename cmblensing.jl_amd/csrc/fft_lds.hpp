@@ -74,10 +74,11 @@ template <int NT> struct WorkCoop {
 // quarter is -i times the first (stage_twiddles)
 template <int RT, int RPW, bool TWQ = false> struct WorkRows {
   int NA, nr;
+  int tid = (int)threadIdx.x;             // (a member so that a kernel that walks several tiles can pass an opaque copy per tile: kernels_flow.hpp delta_y_body_pipelined)
   static constexpr bool twq = TWQ;
   static constexpr bool wave_private = RT <= 128;
   template <int LGNB, typename F> __device__ __forceinline__ void each(F&& f) const {
-    const int row = threadIdx.x / RT, t = threadIdx.x % RT;
+    const int row = tid / RT, t = tid % RT;
     if (row >= nr) return;
     if constexpr (RT == 128) {
       constexpr int I = 1 << LGNB, HI = I >> 1;                       // items of the stage, items per half

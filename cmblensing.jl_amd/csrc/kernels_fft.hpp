@@ -263,11 +263,11 @@ template <int R, int NT, int LGM> struct PairMap {
   static constexpr int M = 1 << LGM, MH = M >> 1, C = (R * NT) >> LGM;
   static constexpr bool split = CMBL_COL_SPLIT && (R % 2 == 0) && (NT % MH == 0) && (NT % C == 0) && (NT / C == 64 || NT / C == 128) && M >= 32;
   static constexpr int XLG = LGM + 1 >= 11 ? 4 : 3;            // sub-stage radix of the split N-point transforms
-  __device__ static __forceinline__ int e(int i) {
+  __device__ static __forceinline__ int e(int i, int tid = (int)threadIdx.x) {
     if constexpr (split) {
-      const int g = threadIdx.x / MH, q = threadIdx.x % MH;
+      const int g = tid / MH, q = tid % MH;
       return ((g * (R / 2) + (i >> 1)) << LGM) + q + MH * (i & 1);
-    } else return threadIdx.x + i * NT;
+    } else return tid + i * NT;
   }
 };
 
@@ -279,21 +279,21 @@ template <int R, int NT, int LGM> struct PairMap {
 template <typename T, int NT, int LGM, int LGC> struct HalfStage {
   static constexpr int M = 1 << LGM, C = 1 << LGC, NP = (M >> 1) + 1, TOT = C * NP, K = (TOT + NT - 1) / NT, NyhP = mixed_rows(M + 1);
   cx<T> a[K] = {}, b[K] = {}, w[K] = {};
-  __device__ __forceinline__ void issue(const cx<T>* __restrict__ g /*slice base*/, const cx<T>* __restrict__ twg, int x0) {
+  __device__ __forceinline__ void issue(const cx<T>* __restrict__ g /*slice base*/, const cx<T>* __restrict__ twg, int x0, int tid = (int)threadIdx.x) {
     const cx<T>* tg = tile_base(g, x0, NyhP);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int u = threadIdx.x + i * NT;
+      const int u = tid + i * NT;
       if (TOT % NT == 0 || u < TOT) {
         const int k = u >> LGC, c = u & (C - 1);
         a[i] = at32(tg, tile_off<T, C>(k, c, x0, NyhP)); b[i] = at32(tg, tile_off<T, C>(M - k, c, x0, NyhP)); w[i] = at32(twg, (unsigned)k);
       }
     }
   }
-  template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
+  template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s, int tid = (int)threadIdx.x) const {
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int u = threadIdx.x + i * NT;
+      const int u = tid + i * NT;
       if (TOT % NT == 0 || u < TOT) {
         const int k = u >> LGC, k2 = M - k;
         cx<T>* p = s + (u & (C - 1)) * LD;
@@ -310,10 +310,10 @@ template <typename T, int NT, int LGM, int LGC> struct HalfStage {
 };
 // the r2c finish fused into the store: Z (bit-reversed slots, after the M-point forward transform) -> A[k], A[M-k] -> mixed layout
 template <typename T, int NT, int LD, int LGM, int LGC>
-__device__ __forceinline__ void half_store(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, const cx<T>* __restrict__ tw, int x0) {
+__device__ __forceinline__ void half_store(const cx<T>* __restrict__ s, cx<T>* __restrict__ g, const cx<T>* __restrict__ tw, int x0, int tid = (int)threadIdx.x) {
   constexpr int M = 1 << LGM, C = 1 << LGC, NP = (M >> 1) + 1, NyhP = mixed_rows(M + 1);
   cx<T>* tg = tile_base(g, x0, NyhP);
-  for (int u = threadIdx.x; u < C * NP; u += NT) {
+  for (int u = tid; u < C * NP; u += NT) {
     const int k = u >> LGC, k2 = M - k, c = u & (C - 1);
     const cx<T>* p = s + c * LD;
     if (k == 0) {
@@ -332,16 +332,16 @@ __device__ __forceinline__ void half_store(const cx<T>* __restrict__ s, cx<T>* _
 // scaled.  Split tiles: sub-stages per half-column (WorkRows, no barriers) and the last level while reading:
 //   z[jj] = u[jj] + conj(W_M^jj) v[jj],  z[jj + M/2] = u[jj] - conj(W_M^jj) v[jj]         (W_M^jj = tw[2 jj], tw = exp(-2 pi i k / N))
 template <typename T, int R, int NT, int LGM, int LD>
-__device__ __forceinline__ void mpt_inverse_read(cx<T>* s, const cx<T>* tw, T scale, cx<T> (&z)[R]) {
+__device__ __forceinline__ void mpt_inverse_read(cx<T>* s, const cx<T>* tw, T scale, cx<T> (&z)[R], int tid = (int)threadIdx.x) {
   using PM = PairMap<R, NT, LGM>;
   using V = typename vreg<T>::type;
   constexpr int M = 1 << LGM, MH = M >> 1, C = PM::C;
   if constexpr (PM::split) {
-    fft_dit_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<mpt_rt<NT, C>(), C>{1, C}, tw);
+    fft_dit_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<mpt_rt<NT, C>(), C>{1, C, tid}, tw);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < R; i += 2) {
-      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const int e = PM::e(i, tid), c = e >> LGM, jj = e & (M - 1);
       const cx<T>* p = s + c * LD + pad(jj);
       const V u = vload(p), t = vmulc(vload(p + pad(MH)), vload(tw + 2 * jj));
       z[i] = vcx(vscale(vadd(u, t), scale)); z[i + 1] = vcx(vscale(vsub(u, t), scale));
@@ -350,33 +350,33 @@ __device__ __forceinline__ void mpt_inverse_read(cx<T>* s, const cx<T>* tw, T sc
     fft_dit<T, NT, LD, LGM, LGM + 1, CMBL_YLGM>(s, C, tw);
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const int e = PM::e(i, tid), c = e >> LGM, jj = e & (M - 1);
       z[i] = scale * s[c * LD + pad(jj)];
     }
   }
 }
 // packed pairs z(i) of the thread -> M-point forward transform (bit-reversed slots, synchronised); the tile must be free
 template <typename T, int R, int NT, int LGM, int LD, typename ZF>
-__device__ __forceinline__ void mpt_write_forward(cx<T>* s, const cx<T>* tw, ZF&& zf) {
+__device__ __forceinline__ void mpt_write_forward(cx<T>* s, const cx<T>* tw, ZF&& zf, int tid = (int)threadIdx.x) {
   using PM = PairMap<R, NT, LGM>;
   using V = typename vreg<T>::type;
   constexpr int M = 1 << LGM, MH = M >> 1, C = PM::C;
   if constexpr (PM::split) {
 #pragma unroll
     for (int i = 0; i < R; i += 2) {
-      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const int e = PM::e(i, tid), c = e >> LGM, jj = e & (M - 1);
       cx<T>* p = s + c * LD + pad(jj);
       const V za = vfrom(zf(i)), zb = vfrom(zf(i + 1));
       vstore(p, vadd(za, zb));
       vstore(p + pad(MH), vmul(vsub(za, zb), vload(tw + 2 * jj)));
     }
     __syncthreads();
-    fft_dif_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<mpt_rt<NT, C>(), C>{1, C}, tw);
+    fft_dif_w<T, LD, LGM, LGM + 1, 3, 1>(s, WorkRows<mpt_rt<NT, C>(), C>{1, C, tid}, tw);
     __syncthreads();
   } else {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const int e = PM::e(i, tid), c = e >> LGM, jj = e & (M - 1);
       s[c * LD + pad(jj)] = zf(i);
     }
     __syncthreads();
@@ -392,12 +392,12 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
   static constexpr int N = 1 << LGN, M = N >> 1, C = 1 << LGC, TOT = C * (M + 1), K = (TOT + NT - 1) / NT;
   cx<T> X[K] = {}, Y[K] = {};
   T l[K] = {};
-  __device__ __forceinline__ void issue(const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY, const T* __restrict__ ly, int Nx, int x0) {
+  __device__ __forceinline__ void issue(const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY, const T* __restrict__ ly, int Nx, int x0, int tid = (int)threadIdx.x) {
     const cx<T>* tX = tile_base(gX, x0, mixed_rows(M + 1));
     const cx<T>* tY = tile_base(gY, x0, mixed_rows(M + 1));
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int e = threadIdx.x + i * NT;
+      const int e = tid + i * NT;
       if (e < TOT) {
         const int k = e >> LGC;
         const unsigned gi = tile_off<T, C>(k, e & (C - 1), x0, mixed_rows(M + 1));
@@ -406,22 +406,22 @@ template <typename T, int NT, int LGN, int LGC> struct PairStage {
     }
   }
   // the two tiles alone (l = ly[k] depends on the entry index only: a workgroup that walks several tiles keeps it from its first issue)
-  __device__ __forceinline__ void issue_xy(const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY, int x0) {
+  __device__ __forceinline__ void issue_xy(const cx<T>* __restrict__ gX, const cx<T>* __restrict__ gY, int x0, int tid = (int)threadIdx.x) {
     const cx<T>* tX = tile_base(gX, x0, mixed_rows(M + 1));
     const cx<T>* tY = tile_base(gY, x0, mixed_rows(M + 1));
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int e = threadIdx.x + i * NT;
+      const int e = tid + i * NT;
       if (e < TOT) {
         const unsigned gi = tile_off<T, C>(e >> LGC, e & (C - 1), x0, mixed_rows(M + 1));
         X[i] = at32(tX, gi); Y[i] = at32(tY, gi);
       }
     }
   }
-  template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s) const {
+  template <int LD> __device__ __forceinline__ void commit(cx<T>* __restrict__ s, int tid = (int)threadIdx.x) const {
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const int e = threadIdx.x + i * NT;
+      const int e = tid + i * NT;
       if (e < TOT) {
         const int c = e & (C - 1), k = e >> LGC;
         const cx<T> x = X[i], y = mk<T>(-l[i] * Y[i].y, l[i] * Y[i].x);
@@ -650,11 +650,11 @@ template <typename T, int LGNX, int LG> __device__ __forceinline__ cx<T> mul_il_
 // After the N-point DIF of a + i b (a, b real): A[k] = (Z[k] + conj Z[N-k])/2, B[k] = (Z[k] - conj Z[N-k])/(2i), k = 0..M.
 // f(k, c, A, B) consumes the pair (stores it, or combines it with something held in registers).
 template <typename T, int NT, int LD, int LGN, int LGC, int RZ, typename F>
-__device__ __forceinline__ void pair_split(const cx<T>* __restrict__ s, F&& f) {
+__device__ __forceinline__ void pair_split(const cx<T>* __restrict__ s, F&& f, int tid = (int)threadIdx.x) {
   constexpr int N = 1 << LGN, M = N >> 1, C = 1 << LGC;
 #pragma unroll
   for (int i = 0; i < RZ; ++i) {                    // RZ = ceil(C*(M+1)/NT): compile-time trip count keeps f's captures in registers
-    const int e = threadIdx.x + i * NT;
+    const int e = tid + i * NT;
     if (e < C * (M + 1)) {
       const int c = e & (C - 1), k = e >> LGC;
       const cx<T>* p = s + c * LD;

@@ -137,22 +137,22 @@ __device__ __forceinline__ void write_pair_dif(cx<T>* col, int jj, int M, const 
 }
 // inverse N-point transform of the tile (bit-reversed input already committed and synchronised) -> (x, y) pairs, scaled
 template <typename T, int R, int NT, int LGM, int LD>
-__device__ __forceinline__ void npt_inverse_read(cx<T>* s, const cx<T>* tw, T scale, cx<T> (&x)[R], cx<T> (&y)[R]) {
+__device__ __forceinline__ void npt_inverse_read(cx<T>* s, const cx<T>* tw, T scale, cx<T> (&x)[R], cx<T> (&y)[R], int tid = (int)threadIdx.x) {
   using PM = PairMap<R, NT, LGM>;
   constexpr int M = 1 << LGM, LGN = LGM + 1, C = PM::C;
   if constexpr (PM::split) {
-    fft_dit_w<T, LD, LGN, LGN, PM::XLG, 1>(s, WorkRows<NT / C, C>{1, C}, tw);
+    fft_dit_w<T, LD, LGN, LGN, PM::XLG, 1>(s, WorkRows<NT / C, C>{1, C, tid}, tw);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < R; i += 2) {
-      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const int e = PM::e(i, tid), c = e >> LGM, jj = e & (M - 1);
       read_pair_dit(s + c * LD, jj, M, tw, scale, x[i], y[i], x[i + 1], y[i + 1]);
     }
   } else {
     fft_dit<T, NT, LD, LGN, LGN, CMBL_YLGN>(s, C, tw);
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const int e = PM::e(i, tid), c = e >> LGM, jj = e & (M - 1);
       read_pair(s + c * LD, jj, scale, x[i], y[i]);
     }
   }
@@ -160,24 +160,24 @@ __device__ __forceinline__ void npt_inverse_read(cx<T>* s, const cx<T>* tw, T sc
 // (x, y) pairs -> forward N-point transform of the tile (bit-reversed output, synchronised); the tile must be free (sync before)
 // xy(i, x, y) yields pair i of the thread
 template <typename T, int R, int NT, int LGM, int LD, typename XY>
-__device__ __forceinline__ void npt_write_forward(cx<T>* s, const cx<T>* tw, XY&& xy) {
+__device__ __forceinline__ void npt_write_forward(cx<T>* s, const cx<T>* tw, XY&& xy, int tid = (int)threadIdx.x) {
   using PM = PairMap<R, NT, LGM>;
   constexpr int M = 1 << LGM, LGN = LGM + 1, C = PM::C;
   if constexpr (PM::split) {
 #pragma unroll
     for (int i = 0; i < R; i += 2) {
-      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const int e = PM::e(i, tid), c = e >> LGM, jj = e & (M - 1);
       cx<T> x0, y0, x1, y1;
       xy(i, x0, y0); xy(i + 1, x1, y1);
       write_pair_dif(s + c * LD, jj, M, tw, x0, y0, x1, y1);
     }
     __syncthreads();
-    fft_dif_w<T, LD, LGN, LGN, PM::XLG, 1>(s, WorkRows<NT / C, C>{1, C}, tw);
+    fft_dif_w<T, LD, LGN, LGN, PM::XLG, 1>(s, WorkRows<NT / C, C>{1, C, tid}, tw);
     __syncthreads();
   } else {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const int e = PM::e(i), c = e >> LGM, jj = e & (M - 1);
+      const int e = PM::e(i, tid), c = e >> LGM, jj = e & (M - 1);
       cx<T> x, y;
       xy(i, x, y);
       write_pair(s + c * LD, jj, x, y);
@@ -667,47 +667,52 @@ __device__ __forceinline__ void delta_y_body_pipelined(const DeltaYArgs<T>& d, u
 #ifndef CMBL_PL_HEAD
 #define CMBL_PL_HEAD 1
 #endif
-  auto issue_rest = [&](int x0) {
+  // tid: the thread index as a value the compiler cannot see through, a fresh one per tile -- every per-thread address below is then recomputed
+  // per tile instead of being hoisted above the tile loop and kept live across it (round 5's version spilled 228-596 bytes per lane that way;
+  // the trick is kernels_small.hpp's)
+  auto issue_rest = [&](int x0, int tid) {
     const size_t pbase = ((size_t)bphi * Nx + x0) * M;
 #pragma unroll
-    for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase, (unsigned)PM::e(i), a.rk.t, px[i], py[i]);
-    th.issue(d.H + moff, a.twY, x0);
+    for (int i = 0; i < R; ++i) load_p_only(a.ph, pbase, (unsigned)PM::e(i, tid), a.rk.t, px[i], py[i]);
+    th.issue(d.H + moff, a.twY, x0, tid);
   };
-  auto issue_head = [&](int x0) {
-    ps.issue_xy(a.Gx + moff, a.A + moff, x0);
-    if (CMBL_PL_HEAD >= 2) issue_rest(x0);
+  auto issue_head = [&](int x0, int tid) {
+    ps.issue_xy(a.Gx + moff, a.A + moff, x0, tid);
+    if (CMBL_PL_HEAD >= 2) issue_rest(x0, tid);
   };
+  auto fresh_tid = [] { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; };
   twr.issue(a.twY);
-  ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, tile_x0(0));
-  if (CMBL_PL_HEAD >= 2) issue_rest(tile_x0(0));
+  ps.issue(a.Gx + moff, a.A + moff, a.ly, Nx, tile_x0(0), fresh_tid());
+  if (CMBL_PL_HEAD >= 2) issue_rest(tile_x0(0), fresh_tid());
   twr.commit(tw);
 #pragma unroll
   for (int k = 0; k < tpw; ++k) {
     const int x0 = tile_x0(k);
+    const int tid = fresh_tid();
     const size_t mbase = (sl * Nx + x0) * (size_t)M;
-    if (CMBL_PL_HEAD == 0 && k > 0) ps.issue_xy(a.Gx + moff, a.A + moff, x0);          // timing aid: several tiles, nothing prefetched
-    ps.template commit<LD>(s);
-    if (CMBL_PL_HEAD < 2) issue_rest(x0);
+    if (CMBL_PL_HEAD == 0 && k > 0) ps.issue_xy(a.Gx + moff, a.A + moff, x0, tid);          // timing aid: several tiles, nothing prefetched
+    ps.template commit<LD>(s, tid);
+    if (CMBL_PL_HEAD < 2) issue_rest(x0, tid);
     __syncthreads();
     cx<T> dx[R], dy[R];
-    npt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, dx, dy);
+    npt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, dx, dy, tid);
     __syncthreads();
-    th.template commit<LD>(s);
+    th.template commit<LD>(s, tid);
     cx<T>* y0p = reinterpret_cast<cx<T>*>(a.y0) + mbase;
     cx<T>* accp = reinterpret_cast<cx<T>*>(a.acc) + mbase;
     cx<T> fn[R], ldf[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const unsigned e = PM::e(i);
+      const unsigned e = PM::e(i, tid);
       fn[i] = at32(reinterpret_cast<const cx<T>*>(a.y0r) + mbase, e);
       ldf[i] = a.rk.stage == 1 ? mk<T>(0, 0) : at32(accp, e);
     }
     __syncthreads();
     cx<T> lz[R];
-    mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, lz);
+    mpt_inverse_read<T, R, NT, LGM, LD>(s, tw, invNy, lz, tid);
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const unsigned e = PM::e(i);
+      const unsigned e = PM::e(i, tid);
       cx<T> y0 = fn[i], acc = ldf[i];
       ldf[i] = lz[i];
       nt_store(&at32(reinterpret_cast<cx<T>*>(d.w1p) + mbase, e), pmul(ldf[i], dx[i]));
@@ -717,20 +722,20 @@ __device__ __forceinline__ void delta_y_body_pipelined(const DeltaYArgs<T>& d, u
       if (a.rk.stage == 4) at32(y0p, e) = y0; else at32(accp, e) = acc;
     }
     __syncthreads();
-    npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], ldf[i]); y = pmul(py[i], ldf[i]); });
+    npt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i, cx<T>& x, cx<T>& y) { x = pmul(px[i], ldf[i]); y = pmul(py[i], ldf[i]); }, tid);
     {
       cx<T>* Wx = tile_base(d.Wx + moff, x0, NyhP); cx<T>* Wy = tile_base(d.Wy + moff, x0, NyhP);
       pair_split<T, NT, LD, LGN, LGC, G::RZ>(s, [&](int i, int kk, int c, cx<T> A, cx<T> B) {
         const unsigned gi = tile_off<T, C>(kk, c, x0, NyhP);
         handoff_store<T, wt_cols<T>(C, M)>(Wx, gi, A); handoff_store<T, wt_cols<T>(C, M)>(Wy, gi, mul_il(B, ps.l[i]));
-      });
+      }, tid);
     }
     // the next tile's head: everything it waits for first, requested while this tile's last transform runs
-    if (CMBL_PL_HEAD > 0 && k + 1 < tpw) issue_head(tile_x0(k + 1));
+    if (CMBL_PL_HEAD > 0 && k + 1 < tpw) issue_head(tile_x0(k + 1), fresh_tid());
     if (!a.rk.last) {
       __syncthreads();
-      mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; });
-      half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0);
+      mpt_write_forward<T, R, NT, LGM, LD>(s, tw, [&](int i) { return fn[i]; }, tid);
+      half_store<T, NT, LD, LGM, LGC>(s, a.Anext + moff, tw, x0, tid);
     }
     __syncthreads();                                          // the tile is rewritten by the next commit
   }
