@@ -165,8 +165,7 @@ void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>
   // group height: the row-update part has Nyh / (S / 2) workgroups per slice, the d/dx part Nyh / S
   // (half-height groups while the launch has fewer than 1.5 full-height groups per CU: measured at 768^2 / 1000^2 QU -3.5 %, 768^2 T+QU +1.4 %,
   //  profiles/r06_ab_anysize_xmerge.txt)
-  int Sx = (opts.gen_ct_rows && ((A_next ? 3L : 2L) * a.nseq * ws + ct_S<T>() - 1) / ct_S<T>() < 3L * num_cus / 2) ? ct_S<T>() / 2 : ct_S<T>();
-  { static const int force = env_int("CMBL_XMERGE_S", 0); if (force == ct_S<T>() || force == ct_S<T>() / 2) Sx = force; }   // (tuning aid)
+  const int Sx = (opts.gen_ct_rows && ((A_next ? 3L : 2L) * a.nseq * ws + ct_S<T>() - 1) / ct_S<T>() < 3L * num_cus / 2) ? ct_S<T>() / 2 : ct_S<T>();
   a.S = a1.S = Sx;
   const int R = Sx / 2;
   const dim3 grid((unsigned)((a.nseq + R - 1) / R), (unsigned)((A_next ? 2 : 1) * ws));
