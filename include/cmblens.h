@@ -100,6 +100,8 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *        "fill_target"           CMBL_FILL_TARGET (0)              > 0: narrow the column tiles below that many tiles per launch instead of the built-in rule
  *        "row_fill_target"       CMBL_ROW_FILL_TARGET (0 = CUs/2)  shorten the row groups below that many groups per launch
  *        "col_prefetch"          CMBL_COL_PREFETCH (-1)            touch prefetch of the double-precision >= 2048-row column kernels: -1 = built-in distance, 0 = off, > 0 = blocks ahead
+ *        "col_pipeline"          CMBL_COL_PIPELINE (1)             only in -DCMBL_EXPERIMENT_COL_PIPELINE builds (the measured-and-rejected two-tile column workgroup,
+ *                                                                   profiles/r0{5,6}_ab_col_pipeline_rejected.txt): 0 off, 1 on, 2 on the 256-thread tile; no effect in the shipped library
  *        "small_flow"            CMBL_SMALL_FLOW (1)               maps of 32..128 pixels per side: L*f, L\f, L'g, L'\g as ONE launch, one workgroup per (pol, batch) slice with
  *                                                                   the half plane resident in LDS (csrc/kernels_small.hpp): 0 = off, 1 = up to 64 x 64 pixels (faster at every
  *                                                                   batch size), 2 = wherever compiled (up to 128 x 128 in single, 64 x 64 in double precision).  Results agree

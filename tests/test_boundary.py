@@ -87,3 +87,15 @@ def test_host_operator_algebra_matches_oracle():
         np.testing.assert_allclose(C.lowpass(3000)(np.array([x])), O.lowpass(3000)(np.array([x])), equal_nan=True)
     np.testing.assert_allclose(C.noise_cls(3, 100, 3, 4000)["EE"].cl, O.noise_cls(3, 100, 3, 4000)["EE"].cl)
     np.testing.assert_allclose(C.beam_cls(3.0, 4000).cl, O.beam_cls(3.0, 4000).cl)
+
+
+def test_every_context_option_is_documented_in_the_header():
+    """cmbl_ctx_set_option accepts exactly the names Ctx::opt_ptr knows (csrc/engine.hpp); include/cmblens.h must list each of them"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    eng = open(os.path.join(root, "cmblensing.jl_amd", "csrc", "engine.hpp"), encoding="utf-8").read()
+    hdr = open(os.path.join(root, "include", "cmblens.h"), encoding="utf-8").read()
+    names = re.findall(r'if \(k == "(\w+)"\) return &opts\.', eng)
+    assert len(names) >= 20
+    missing = [n for n in names if f'"{n}"' not in hdr]
+    assert not missing, missing
