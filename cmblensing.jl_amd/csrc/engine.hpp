@@ -96,6 +96,7 @@ struct CtxBase {
     int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 1 << 19);   //   ... from this many pixels on (a quarter of it for >= 3 slices)
     int gen_yy = env_int("CMBL_GEN_YY", 1) != 0;                          //   the y passes of a forward stage in one launch (GenDft::yy; needs gen_ct)
     int gen_xmerge = env_int("CMBL_GEN_XMERGE", 1) != 0;                  //   the row update of an adjoint-type stage also opens the next stage (gen_x_adj_next): one launch less per stage
+    int gen_tiled = env_int("CMBL_GEN_TILED", 7);                    //   the half planes the fused any-size stages hand between their column and row launches are TILED ([x / 4][ky][x % 4], GenDft::in_tiled) instead of [ky][x]
     int gen_ct_cols = env_int("CMBL_GEN_CT_COLS", 1);                     //   half-width column groups in the fused y passes: 0 never, 1 for small launches (Ctx::ct_cols_per_group), 2 always
     int gen_ct_rows = env_int("CMBL_GEN_CT_ROWS", 1) != 0;                //   shorter row groups in x-pass launches with fewer groups than CUs (Ctx::ct_rows_per_group)
     int gen_ct = env_int("CMBL_GEN_CT", 1) != 0;                          //   compile-time plans for the lengths of CMBL_CT_LIST (kernels_ct.hpp)
@@ -122,6 +123,7 @@ struct CtxBase {
     if (k == "gen_ct_rows") return &opts.gen_ct_rows;
     if (k == "gen_ct_cols") return &opts.gen_ct_cols;
     if (k == "gen_xmerge") return &opts.gen_xmerge;
+    if (k == "gen_tiled") return &opts.gen_tiled;
     if (k == "gen_yy") return &opts.gen_yy;
     if (k == "gen_slice_streams") return &opts.gen_slice_streams;
     if (k == "gen_streams_min_pix") return &opts.gen_streams_min_pix;
@@ -354,6 +356,7 @@ struct Ctx : CtxBase {
     if (pro) a.pro = *pro;
     a.in = map; a.out = A; a.in2 = map2; a.out2 = A2; a.in_real = 1; a.nin = Ny; a.nout = Nyh; a.nseq = Nx; a.scale = 1; a.scale2 = 1;
     a.in_seq = Ny; a.in_elem = 1; a.in_slice = npix(); a.out_seq = 1; a.out_elem = Nx; a.out_slice = plane();
+    hand_out<1>(a);
     gen_dft(genY, a, slices);
   }
   void gen_y_c2r_pair(const cx<T>* G1, const cx<T>* G2, const T* lmul2, T* o1, T* o2, T s1, T s2, long slices) {
@@ -361,6 +364,7 @@ struct Ctx : CtxBase {
     a.in = G1; a.in2 = G2; a.lmul_in = lmul2; a.out = o1; a.out2 = o2; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx;
     a.scale = s1; a.scale2 = s2;
     a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
+    hand_in<1>(a);
     gen_dft(genY, a, slices);
   }
   // the y axis has a compile-time plan (and they are switched on): the fused y passes of a flow stage exist
@@ -394,6 +398,19 @@ struct Ctx : CtxBase {
       default: return false;
     }
   }
+  // Tiled hand-off arrays (GenDft::in_tiled): every launch that touches them must be a compile-time-plan kernel, i.e. both axes have a plan and
+  // the fused stages are on; 4 | Nx for the blocks.  Returns the rows of a block column (ky padded to a multiple of 4), 0 = [ky][x] arrays.
+  int gen_tile() const {
+    if (!opts.gen_tiled || !opts.gen_separable || !opts.gen_prologue || !opts.gen_xderiv_fused || (Nx & 3) || !gen_ct_x() || !gen_ct_y()) return 0;
+    return (Nyh + 3) & ~3;
+  }
+  // set by a flow around its stages (Flow::HandOff): the layout of gA / gGx / gW2 / the mixed scratch in the launches below; slice stride hplane()
+  int htile = 0;
+  long hplane() const { return htile ? mplane() : plane(); }
+  template <int SIDE /*1: y kernel (sequence = x), 2: x kernel (element = x)*/> void hand_in(GenDft<T>& a) const { if (htile) { a.in_tiled = SIDE; a.tile_np = htile; a.in_slice = mplane(); } }
+  template <int SIDE> void hand_out(GenDft<T>& a) const { if (htile) { a.out_tiled = SIDE; a.tile_np = htile; a.out_slice = mplane(); } }
+  // row groups of an x launch on tiled arrays: a multiple of 8, so that xcd_tile (kernels_fft.hpp) puts the groups that share 128-byte lines on one XCD
+  static long xgroups(long groups, bool tiled) { return tiled ? (groups + 7) & ~7L : groups; }
   void gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, const RKCoef<T>& rk, cx<T>* t3, const cx<T>* A_next, cx<T>* gx, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // t3 = ifft_x(F) (unnormalised) and gx = ifft_x(i lx fft_x(A)) in ONE launch where the x axis has a compile-time plan (else two launches)
   void gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<T>* gx, cx<T>* tmp, const T* lx, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
@@ -409,13 +426,16 @@ struct Ctx : CtxBase {
     GenDft<T> b{};
     b.in = in; b.out = out; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1; b.lmul_mid = lx;
     b.in_seq = Nx; b.in_elem = 1; b.in_slice = plane(); b.out_seq = Nx; b.out_elem = 1; b.out_slice = plane();
+    hand_in<2>(b); hand_out<2>(b);
     gen_dft(genX, b, slices);
     return true;
   }
-  void gen_x(const cx<T>* in, cx<T>* out, bool inverse, const T* lmul_out, long slices) {
+  void gen_x(const cx<T>* in, cx<T>* out, bool inverse, const T* lmul_out, long slices, bool hand_i = false, bool hand_o = false) {
     GenDft<T> b{};
     b.in = in; b.out = out; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1; b.inverse = inverse ? 1 : 0; b.lmul_out = lmul_out;
     b.in_seq = Nx; b.in_elem = 1; b.in_slice = plane(); b.out_seq = Nx; b.out_elem = 1; b.out_slice = plane();
+    if (hand_i) hand_in<2>(b);
+    if (hand_o) hand_out<2>(b);
     gen_dft(genX, b, slices);
   }
   template <typename V> void transpose(const V* in, V* out, int R, int C, long slices) {
@@ -1010,6 +1030,12 @@ struct Flow {
   // rfft2 -> (i lx, i ly) -> 2 x irfft2 (src/lenseflow.jl:155-157) incl. FFTW's c2r rule at ky = 0 / Nyquist, in 3 launches and
   // 3 slice-passes instead of 5 launches and 7.5.  CMBL_GEN_SEPARABLE=0: the reference's own pass structure (kept for A/B).
   DevBuf gA, gGx, gT, gW2;
+  // layout of the hand-off arrays for the launches of one flow (Ctx::htile): tiled when the flow runs its fused stages and Ctx::gen_tile() allows
+  struct HandOff {
+    Ctx<T>* c;
+    HandOff(Ctx<T>* c_, bool fused, int kind /*option gen_tiled: 1 map flows, 2 adjoint flows, 4 delta flows*/) : c(c_) { c->htile = fused && (c->opts.gen_tiled & kind) ? c->gen_tile() : 0; }
+    ~HandOff() { c->htile = 0; }
+  };
   bool gen_sep() const { return c->opts.gen_separable != 0; }
   void gen_grad_sep(const cx<T>* A_, long slices) {
     const long pl = c->plane(), np = c->npix();
@@ -1038,21 +1064,23 @@ struct Flow {
       // pro (mode 3): the pair is formed in the fetch from L(df) and p; `in` / `in2` only mark the launch as a real pair
       if (pro) c->gen_y_r2c(pro->Ldf, gW2.as<cx<T>>(), slices, pro->Ldf, gW2.as<cx<T>>() + slices * pl, pro);
       else c->gen_y_r2c(Wxy, gW2.as<cx<T>>(), slices, Wxy + slices * np, gW2.as<cx<T>>() + slices * pl);
-      c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
+      c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices, true, false);
     } else c->rfft2_F(Wxy, gFxy.as<cx<T>>(), 2 * slices);
     CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
                 c->ly.template as<T>(), c->Nx, Y0, Yacc_, Ys, rk, pl, wsl0());
   }
   void gen_flow_map(const T* in, T* out, int P, int B, bool inverse) {
-    const long slices = (long)P * B, np = c->npix(), pl = c->plane();
+    const long slices = (long)P * B, np = c->npix();
     acc.ensure(sizeof(T) * slices * np); gms.ensure(sizeof(T) * slices * np);
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
     CMBL_HIP(hipMemcpyAsync(gms.p, out, sizeof(T) * slices * np, hipMemcpyDeviceToDevice, c->stream));
     const double t0 = inverse ? 1.0 : 0.0, h = (inverse ? -1.0 : 1.0) / n;
     const bool sep = gen_sep();
+    const bool yy = sep && gen_pro() && c->opts.gen_yy && c->opts.gen_xderiv_fused && c->gen_ct_y();
+    HandOff ho(c, yy, 1);
+    const long pl = c->hplane();
     if (sep) { gA.ensure(sizeof(cx<T>) * slices * pl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
     const int K = gen_groups(slices);
-    const bool yy = sep && gen_pro() && c->opts.gen_yy && c->opts.gen_xderiv_fused && c->gen_ct_y();
     // every scratch buffer a stage can grow is sized BEFORE the chains fork: a growth (hipFree / hipMalloc) inside the multi-stream region
     // would pull a buffer from under a launch of another chain (the separate-launch path used to ensure inside gen_grad_sep / gen_grad)
     if (sep) { gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); if (!yy) gmxy.ensure(sizeof(T) * 2 * slices * np); }
@@ -1093,9 +1121,11 @@ struct Flow {
     if (in != out) CMBL_HIP(hipMemcpyAsync(out, in, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     CMBL_HIP(hipMemcpyAsync(gYs.p, out, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     const double t0 = inverse ? 0.0 : 1.0, h = (inverse ? 1.0 : -1.0) / n;
-    gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gW2.ensure(sizeof(cx<T>) * 2 * slices * pl); (void)c->mixed_scratch(slices);   // before the chains fork
-    const int K = gen_groups(slices);
     const bool yy = gen_sep() && c->opts.gen_yy && c->gen_ct_y();
+    HandOff ho(c, yy, 2);
+    const long hpl = c->hplane();                                          // (the pair W2 and the mixed scratch t3 are hand-off arrays; the Fourier state is not)
+    gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gW2.ensure(sizeof(cx<T>) * 2 * slices * hpl); (void)c->mixed_scratch(slices);   // before the chains fork
+    const int K = gen_groups(slices);
     fork(K);
     for (int step = 0; step < n; ++step)
       for (int stage = 1; stage <= 4; ++stage) {
@@ -1105,11 +1135,11 @@ struct Flow {
           if (yy) {                                                          // ifft_x, every y pass of the stage in one launch, fft_x of the pair, RK update
             cx<T>* t3 = c->mixed_scratch(slices);
             const bool mrg = c->gen_ct_x();                                  // the row update of stage s also writes t3 = ifft_x(Ys) of stage s + 1
-            if (!mrg || (step == 0 && stage == 1)) c->gen_x(gYs.as<cx<T>>(), t3, true, nullptr, slices);
-            c->gen_y_adj_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), ph(rk.t), rk.t, P, gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, slices);
-            if (mrg && !rk.last) { c->gen_x_adj_next(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, out, Yacc.as<cx<T>>(), rk, t3, nullptr, nullptr, slices); continue; }
-            if (c->gen_x_adj_update(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices)) continue;
-            c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
+            if (!mrg || (step == 0 && stage == 1)) c->gen_x(gYs.as<cx<T>>(), t3, true, nullptr, slices, false, true);
+            c->gen_y_adj_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), ph(rk.t), rk.t, P, gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * hpl, slices);
+            if (mrg && !rk.last) { c->gen_x_adj_next(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * hpl, out, Yacc.as<cx<T>>(), rk, t3, nullptr, nullptr, slices); continue; }
+            if (c->gen_x_adj_update(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * hpl, out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices)) continue;
+            c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices, true, false);
             CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
                         c->ly.template as<T>(), c->Nx, out, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, pl, wsl0());
             continue;
@@ -1133,12 +1163,14 @@ struct Flow {
     CMBL_HIP(hipMemcpyAsync(gYs.p, df, sizeof(cx<T>) * slices * pl, hipMemcpyDeviceToDevice, c->stream));
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;
     const bool sep = gen_sep();
-    if (sep) { gA.ensure(sizeof(cx<T>) * slices * pl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
-    tc_host.resize(2 * (size_t)nst);
-    gT.ensure(sizeof(cx<T>) * slices * pl); gGx.ensure(sizeof(cx<T>) * slices * pl); gmxy.ensure(sizeof(T) * 2 * slices * np);   // before the chains fork
-    gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gW2.ensure(sizeof(cx<T>) * 2 * slices * pl); (void)c->mixed_scratch(slices);
-    const int K = gen_groups(slices);
     const bool yy = sep && gen_pro() && c->opts.gen_yy && c->opts.gen_xderiv_fused && c->gen_ct_y2() && c->genX.plan.nf > 0;
+    HandOff ho(c, yy, 4);
+    const long hpl = c->hplane();                                          // (A, Gx, the pair W2 and the mixed scratch t3 are hand-off arrays; the Fourier state is not)
+    if (sep) { gA.ensure(sizeof(cx<T>) * slices * hpl); c->gen_y_r2c(gms.as<T>(), gA.as<cx<T>>(), slices); }
+    tc_host.resize(2 * (size_t)nst);
+    gT.ensure(sizeof(cx<T>) * slices * hpl); gGx.ensure(sizeof(cx<T>) * slices * hpl); gmxy.ensure(sizeof(T) * 2 * slices * np);   // before the chains fork
+    gFxy.ensure(sizeof(cx<T>) * 2 * slices * pl); gW2.ensure(sizeof(cx<T>) * 2 * slices * hpl); (void)c->mixed_scratch(slices);
+    const int K = gen_groups(slices);
     fork(K);
     int it = 0;
     for (int step = 0; step < n; ++step)
@@ -1157,14 +1189,14 @@ struct Flow {
             GenPro<T> e{};
             e.mode = 2; e.ph = ph(rk.t); e.rk = rk; e.y0 = f; e.acc = acc.as<T>(); e.w1p = w1p; e.w2p = w1p + (size_t)slices * np; e.npix = np; e.P = P;
             c->gen_y_delta_stage(t3, (T)(1.0 / ((double)c->Ny * c->Nx)), gGx.as<cx<T>>(), gA.as<cx<T>>(), c->ly.template as<T>(),
-                                 (T)(1.0 / ((double)c->Ny * c->Nx)), (T)(1.0 / (double)c->Ny), e, gA.as<cx<T>>(), gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl,
+                                 (T)(1.0 / ((double)c->Ny * c->Nx)), (T)(1.0 / (double)c->Ny), e, gA.as<cx<T>>(), gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * hpl,
                                  rk.last != 0, slices);
             if (mrg && !rk.last) {
-              c->gen_x_adj_next(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, df, Yacc.as<cx<T>>(), rk, t3, gA.as<cx<T>>(), gGx.as<cx<T>>(), slices);
+              c->gen_x_adj_next(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * hpl, df, Yacc.as<cx<T>>(), rk, t3, gA.as<cx<T>>(), gGx.as<cx<T>>(), slices);
               continue;
             }
-            if (c->gen_x_adj_update(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * pl, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices)) continue;
-            c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices);
+            if (c->gen_x_adj_update(gW2.as<cx<T>>(), gW2.as<cx<T>>() + slices * hpl, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, slices)) continue;
+            c->gen_x(gW2.as<cx<T>>(), gFxy.as<cx<T>>(), false, nullptr, 2 * slices, true, false);
             CMBL_LAUNCH(c, K_GEN_POINT, (k_gen_adj_rk<T>), fgrid(slices), 0, c->stream, gFxy.as<cx<T>>(), gFxy.as<cx<T>>() + slices * pl, c->lx_r.template as<T>(),
                         c->ly.template as<T>(), c->Nx, df, Yacc.as<cx<T>>(), gYs.as<cx<T>>(), rk, pl, wsl0());
             continue;

@@ -18,7 +18,7 @@ bool Ctx<T>::gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
   if (kind == CT_C && a.in_elem == 1 && a.out_elem == 1) {                 // contiguous rows: groups of 8 / 4 / 2 (ct_rows_per_group)
     const int Sx = ct_rows_per_group((long)a.nseq * slices, 1);
     a.S = Sx;
-    const dim3 gx((unsigned)((a.nseq + Sx - 1) / Sx), (unsigned)slices);
+    const dim3 gx((unsigned)xgroups((a.nseq + Sx - 1) / Sx, a.in_tiled || a.out_tiled), (unsigned)slices);
     switch (ax.N) {
 #define CMBL_X(n) case n: \
         if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>()>), gx, ct_lds<T>(n), stream, a); \
@@ -83,6 +83,7 @@ void Ctx<T>::gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, 
   a.scale = s1; a.scale2 = s2;
   a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
   a.yy = 1; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext;
+  hand_in<1>(a);
   slices = gen_window(a, slices);
   a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S<T>());
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
@@ -105,6 +106,7 @@ void Ctx<T>::gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<
   a.scale = s1; a.scale2 = s2;
   a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
   a.yy = 2; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext; a.yy_in3 = T3; a.yy_scale3 = s3; a.yy_out2 = W2a; a.yy_out3 = W2b;
+  hand_in<1>(a);
   slices = gen_window(a, slices);
   a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S2<T>(Ny));
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
@@ -127,12 +129,13 @@ bool Ctx<T>::gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<
   a.in = W2a; a.in2 = W2b; a.nin = Nx; a.nout = Nx; a.nseq = Nyh; a.scale = 1;
   a.in_seq = Nx; a.in_elem = 1; a.in_slice = plane(); a.out_seq = Nx; a.out_elem = 1; a.out_slice = plane();
   a.pro.rk = rk; a.yy_out = Y0; a.out2 = acc_; a.out = Ys; a.lmul_out = lx_r.template as<T>(); a.lmul_in = ly.template as<T>();
+  hand_in<2>(a);
   slices = gen_window(a, slices);
   a.N = Nx; a.tw = genX.twN.template as<cx<T>>();
   const int Sx = std::max(ct_S<T>() / 2, ct_rows_per_group((long)a.nseq * slices, 2));   // S wavefronts = S / 2 rows x the two members of the pair
   a.S = Sx;
   const int R = Sx / 2;
-  const dim3 grid((unsigned)((a.nseq + R - 1) / R), (unsigned)slices);
+  const dim3 grid((unsigned)xgroups((a.nseq + R - 1) / R, a.in_tiled != 0), (unsigned)slices);
   switch (Nx) {
 #define CMBL_X(n) case n: \
       if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
@@ -159,6 +162,8 @@ void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>
     a1.in = A_next; a1.out = gx; a1.nin = Nx; a1.nout = Nx; a1.nseq = Nyh; a1.scale = 1; a1.lmul_mid = lx_r.template as<T>();
     a1.in_seq = Nx; a1.in_elem = 1; a1.in_slice = plane(); a1.out_seq = Nx; a1.out_elem = 1; a1.out_slice = plane();
   }
+  hand_in<2>(a); a.out_tiled = a.in_tiled;                              // the pair in, t3 out (slice stride in_slice); Y0 / acc: the Fourier state [ky][kx] (out_slice)
+  if (A_next) { hand_in<2>(a1); hand_out<2>(a1); }
   const long ws = gen_window(a, slices);
   if (A_next) (void)gen_window(a1, slices);
   a.N = a1.N = Nx; a.tw = a1.tw = genX.twN.template as<cx<T>>();
@@ -168,7 +173,7 @@ void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>
   const int Sx = (opts.gen_ct_rows && ((A_next ? 3L : 2L) * a.nseq * ws + ct_S<T>() - 1) / ct_S<T>() < 3L * num_cus / 2) ? ct_S<T>() / 2 : ct_S<T>();
   a.S = a1.S = Sx;
   const int R = Sx / 2;
-  const dim3 grid((unsigned)((a.nseq + R - 1) / R), (unsigned)((A_next ? 2 : 1) * ws));
+  const dim3 grid((unsigned)xgroups((a.nseq + R - 1) / R, a.in_tiled != 0), (unsigned)((A_next ? 2 : 1) * ws));
   switch (Nx) {
 #define CMBL_X(n) case n: \
       if (A_next) { \
@@ -193,12 +198,13 @@ void Ctx<T>::gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<
     a0.in = F; a0.out = t3; a0.nin = Nx; a0.nout = Nx; a0.nseq = Nyh; a0.scale = 1; a0.inverse = 1;
     a0.in_seq = Nx; a0.in_elem = 1; a0.in_slice = plane(); a0.out_seq = Nx; a0.out_elem = 1; a0.out_slice = plane();
     a1 = a0; a1.in = A_; a1.out = gx; a1.inverse = 0; a1.lmul_mid = lx;
+    hand_out<2>(a0); hand_in<2>(a1); hand_out<2>(a1);
     const long ws = gen_window(a0, slices);
     (void)gen_window(a1, slices);
     a0.N = a1.N = Nx; a0.tw = a1.tw = genX.twN.template as<cx<T>>();
     const int Sx = std::max(ct_S<T>() / 2, ct_rows_per_group(2L * a0.nseq * ws, 1));
     a0.S = a1.S = Sx;
-    const dim3 grid((unsigned)((a0.nseq + a0.S - 1) / a0.S), (unsigned)(2 * ws));
+    const dim3 grid((unsigned)xgroups((a0.nseq + a0.S - 1) / a0.S, a0.out_tiled != 0), (unsigned)(2 * ws));
     switch (Nx) {
 #define CMBL_X(n) case n: \
         if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft2<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a0, ct_kind(a0), (int)ws, a1, ct_kind(a1)); \
@@ -209,7 +215,7 @@ void Ctx<T>::gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<
       default: break;
     }
   }
-  gen_x(F, t3, true, nullptr, slices);
+  gen_x(F, t3, true, nullptr, slices, false, true);
   gen_x_deriv(A_, gx, tmp, lx, slices);
 }
 
@@ -220,6 +226,7 @@ void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, 
   a.in = T3; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx; a.scale = s3;
   a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
   a.yy = 3; a.yy_nout = Nyh; a.yy_out2 = W2a; a.yy_out3 = W2b;
+  hand_in<1>(a);
   slices = gen_window(a, slices);
   a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S<T>());
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);

@@ -153,22 +153,20 @@ template <typename T, int CH> struct CtRegs { cx<T> u[CH], w[CH]; T r[7][CH]; };
 // slice) + ONE 32-bit element offset shared by all arrays of the element (at32, kernels_fft.hpp): no 64-bit vector arithmetic, one
 // address register per element in flight.
 template <typename T, int KIND, bool FLAG /*H: lmul_in given; P: p(t) from the cache*/, int CH>
-__device__ __forceinline__ void ct_load(CtRegs<T, CH>& g, int i, const GenDft<T>& a, size_t sl, int seq, int n) {
+__device__ __forceinline__ void ct_load(CtRegs<T, CH>& g, int i, const GenDft<T>& a, size_t sl, int n, unsigned o /*offset of (seq, n)*/, unsigned Fs, unsigned mn) {
   const size_t sb = sl * a.in_slice;
-  if constexpr (KIND == CT_C) g.u[i] = at32(reinterpret_cast<const cx<T>*>(a.in) + sb, (unsigned)seq * (unsigned)a.in_seq + (unsigned)n * (unsigned)a.in_elem);
+  if constexpr (KIND == CT_C) g.u[i] = at32(reinterpret_cast<const cx<T>*>(a.in) + sb, o);
   else if constexpr (KIND == CT_R1 || KIND == CT_R2) {
-    const unsigned o = (unsigned)seq * (unsigned)a.in_seq + (unsigned)n * (unsigned)a.in_elem;
     g.r[0][i] = at32(reinterpret_cast<const T*>(a.in) + sb, o);
     if constexpr (KIND == CT_R2) g.r[1][i] = at32(reinterpret_cast<const T*>(a.in2) + sb, o);
   } else if constexpr (KIND == CT_H1 || KIND == CT_H2) {
     const int m = n < a.nin ? n : a.N - n;
-    const unsigned o = (unsigned)seq * (unsigned)a.in_seq + (unsigned)m * (unsigned)a.in_elem;
-    g.u[i] = at32(reinterpret_cast<const cx<T>*>(a.in) + sb, o);
-    if constexpr (KIND == CT_H2) g.w[i] = at32(reinterpret_cast<const cx<T>*>(a.in2) + sb, o);
+    const unsigned oh = Fs + (unsigned)m * mn;                            // (half spectra are fetched along ky: never the tiled x index, G is linear)
+    g.u[i] = at32(reinterpret_cast<const cx<T>*>(a.in) + sb, oh);
+    if constexpr (KIND == CT_H2) g.w[i] = at32(reinterpret_cast<const cx<T>*>(a.in2) + sb, oh);
     if constexpr (FLAG) g.r[0][i] = at32(a.lmul_in, (unsigned)m);
   } else {
     const GenPro<T>& e = a.pro;                                          // real maps [slice][npix]: in_slice == npix
-    const unsigned o = (unsigned)seq * (unsigned)a.in_seq + (unsigned)n * (unsigned)a.in_elem;
     const size_t pb = (size_t)(e.ph.Bphi == 1 ? 0 : sl / e.P) * e.npix;
     if constexpr (FLAG) { g.r[0][i] = at32(e.ph.pcx + pb, o); g.r[1][i] = at32(e.ph.pcy + pb, o); }
     else {
@@ -240,11 +238,41 @@ constexpr int ct_chunk(int E, int kind, bool flag) {
   const int nch = (E + ch - 1) / ch;
   return (E + nch - 1) / nch;
 }
+// thread -> (sequence sq of the workgroup, first element nb); its j-th element is nb + 64 j in every mode.  mode 0: a wavefront walks its own
+// sequence; 1: consecutive threads walk the S sequences at one element (transposed side: S elements = one 64-byte piece, or -- tiled arrays --
+// whole contiguous blocks); 2: tiled ROWS (x kernels on tiled arrays): consecutive threads walk the 4 x of a block row, then the S rows, then the
+// blocks -- 4 rows x 4 x = one 128-byte line
+template <int S> __device__ __forceinline__ void ct_map0(int mode, int tid, int& sq, int& nb) {
+  constexpr int LGS = ilog2c(S);
+  const int sh = mode == 2 ? 2 : 0, mk = mode == 2 ? 3 : 0;              // (uniform selects; modes 1 and 2 share one form)
+  sq = mode ? ((tid >> sh) & (S - 1)) : (tid >> 6);
+  nb = mode ? (((tid >> (sh + LGS)) << sh) + (tid & mk)) : (tid & 63);
+}
+// One side's addressing (gen_off, kernels_generic.hpp) as scalars: off(seq, n) = F(seq) + G(n), and G(n + 64 j) = G(n) + j step -- a thread's
+// elements are ONE offset + multiples of a scalar (the index arithmetic of a general (seq, n) per element cost the fused stages 5 % of their time)
+struct CtSide {
+  unsigned sh_s, mk_s, ms, sh_n, mk_n, mn, step;
+  __device__ __forceinline__ CtSide(int tiled, int np, long sseq, long selem) {
+    const bool t1 = tiled == 1, t2 = tiled == 2;
+    sh_s = t1 ? 2u : 0u; mk_s = t1 ? 3u : 0u; ms = t1 ? 4u * (unsigned)np : (t2 ? 4u : (unsigned)sseq);
+    sh_n = t2 ? 2u : 0u; mk_n = t2 ? 3u : 0u; mn = t2 ? 4u * (unsigned)np : (t1 ? 4u : (unsigned)selem);
+    step = t2 ? 16u * mn : 64u * mn;
+  }
+  __device__ __forceinline__ unsigned F(int seq) const { return ((unsigned)seq >> sh_s) * ms + ((unsigned)seq & mk_s); }
+  __device__ __forceinline__ unsigned G(int n) const { return ((unsigned)n >> sh_n) * mn + ((unsigned)n & mk_n); }
+};
 template <typename T, int N, int KIND, bool FLAG, int S = ct_S<T>()>
-__device__ __forceinline__ void ct_fetch(const GenDft<T>& a, cx<T>* __restrict__ s, size_t sl, int seq0, bool by_seq, int tid = threadIdx.x) {
-  constexpr int LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), E = (N + 63) / 64, CH = ct_chunk(E, KIND, FLAG), NCH = (E + CH - 1) / CH;
+__device__ __forceinline__ void ct_fetch(const GenDft<T>& a, cx<T>* __restrict__ s, size_t sl, int seq0, int by_seq, int tid = threadIdx.x) {
+  constexpr int LD = ct_ld(N), E = (N + 63) / 64, CH = ct_chunk(E, KIND, FLAG), NCH = (E + CH - 1) / CH;
   constexpr bool WB = KIND == CT_P1 || KIND == CT_P2;                    // kinds that write back to memory
   constexpr int WBN = E <= 16 ? NCH : 1;                                 // chunks whose write-backs are held back (all of them up to 16 elements per thread)
+  int sq, nb;
+  ct_map0<S>(by_seq, tid, sq, nb);
+  const int seq = min(seq0 + sq, a.nseq - 1);
+  const CtSide sd(a.in_tiled, a.tile_np, a.in_seq, a.in_elem);
+  const unsigned Fs = sd.F(seq), base = Fs + sd.G(nb);
+  // element j of the thread: n0 = nb + 64 j; only the last one can lie beyond the sequence (clamped: the general form)
+  auto off = [&](int j, int n) { return (N % 64 == 0 || j < E - 1) ? base + (unsigned)j * sd.step : Fs + sd.G(n); };
   T so[WB ? WBN * CH : 1][3];
   auto write_back = [&](int j0, int cnt_base) {                          // elements j0 .. j0 + WBN * CH - 1 of the thread
     if constexpr (WB) {
@@ -253,9 +281,9 @@ __device__ __forceinline__ void ct_fetch(const GenDft<T>& a, cx<T>* __restrict__
       T* const dst = (e.rk.stage == 4 ? e.y0 : e.acc) + sb;
 #pragma unroll
       for (int jj = 0; jj < WBN * CH; ++jj) {
-        const int j = j0 + jj, q = tid + j * NT, sq = by_seq ? (q & (S - 1)) : (tid >> 6), n0 = by_seq ? (q >> LGS) : ((tid & 63) + 64 * j);
+        const int j = j0 + jj, n0 = nb + 64 * j;
         if (n0 < N && j < E && seq0 + sq < a.nseq) {                     // the element exists: only then anything is written
-          const unsigned o = (unsigned)(seq0 + sq) * (unsigned)a.in_seq + (unsigned)n0 * (unsigned)a.in_elem;
+          const unsigned o = base + (unsigned)j * sd.step;
           if constexpr (KIND == CT_P2) { at32(e.w1p + sb, o) = so[jj][0]; at32(e.w2p + sb, o) = so[jj][1]; }
           at32(dst, o) = so[jj][2];
         }
@@ -268,17 +296,14 @@ __device__ __forceinline__ void ct_fetch(const GenDft<T>& a, cx<T>* __restrict__
     CtRegs<T, CH> g;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      // transposed side: consecutive threads walk the S sequences at one n (S elements = 64 contiguous bytes); else a wavefront walks its own sequence
-      const int q = tid + (c * CH + i) * NT, sq = by_seq ? (q & (S - 1)) : (tid >> 6), n0 = by_seq ? (q >> LGS) : ((tid & 63) + 64 * (c * CH + i));
-      const int n = n0 < N ? n0 : N - 1, seq = min(seq0 + sq, a.nseq - 1);
-      ct_load<T, KIND, FLAG, CH>(g, i, a, sl, seq, n);
+      const int j = c * CH + i, n0 = nb + 64 * j, n = n0 < N ? n0 : N - 1;
+      ct_load<T, KIND, FLAG, CH>(g, i, a, sl, n, off(j, n), Fs, sd.mn);
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int q = tid + (c * CH + i) * NT, sq = by_seq ? (q & (S - 1)) : (tid >> 6), n0 = by_seq ? (q >> LGS) : ((tid & 63) + 64 * (c * CH + i));
-      const int n = n0 < N ? n0 : N - 1;
+      const int j = c * CH + i, n0 = nb + 64 * j, n = n0 < N ? n0 : N - 1;
       const cx<T> v = ct_value<T, KIND, FLAG, CH>(g, i, a, n, so[WB ? (WBN > 1 ? c * CH + i : i) : 0]);
-      if (n0 < N && (c * CH + i) < E) s[sq * LD + pad(n0)] = v;
+      if (n0 < N && j < E) s[sq * LD + pad(n0)] = v;
     }
     if constexpr (WB && WBN == 1) write_back(c * CH, 0);
   }
@@ -302,10 +327,9 @@ template <int BYTES> __device__ __forceinline__ void ct_store(void* sbase, unsig
   else *reinterpret_cast<float*>(q) = *reinterpret_cast<const float*>(v);
 }
 template <typename T>
-__device__ __forceinline__ void ct_put(const GenDft<T>& a, size_t sl, int seq, int k, cx<T> y, cx<T> yr) {
+__device__ __forceinline__ void ct_put(const GenDft<T>& a, size_t sl, unsigned o /*offset of (seq, k)*/, int k, cx<T> y, cx<T> yr) {
   if (a.inverse) y = conj(y);
   const size_t sb = sl * a.out_slice;
-  const unsigned o = (unsigned)seq * (unsigned)a.out_seq + (unsigned)k * (unsigned)a.out_elem;
   const bool wt = wt_line<T>(a.N);
   if (a.out_real) {
     const T v1 = a.scale * y.x;
@@ -328,27 +352,32 @@ __device__ __forceinline__ void ct_put(const GenDft<T>& a, size_t sl, int seq, i
 
 // Stores: all LDS reads of the thread first, then the global stores (a read-store loop waits for LDS once per element)
 template <typename T, int N, int S = ct_S<T>()>
-__device__ __forceinline__ void ct_store_rows(const GenDft<T>& a, const cx<T>* __restrict__ s, size_t sl, int seq0, bool out_by_seq, int wave, int lane, bool mid, int tid = threadIdx.x) {
-  constexpr int LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N);
+__device__ __forceinline__ void ct_store_rows(const GenDft<T>& a, const cx<T>* __restrict__ s, size_t sl, int seq0, int out_by_seq, int wave, int lane, bool mid, int tid = threadIdx.x) {
+  constexpr int LD = ct_ld(N);
   const bool split = a.in_real && a.in2;
   constexpr int E = (N + 63) / 64, NPC = (E + 11) / 12, PCH = (E + NPC - 1) / NPC;
+  int sq, kb;
+  ct_map0<S>(out_by_seq, tid, sq, kb);
+  const int seq = seq0 + sq;
+  const CtSide sd(a.out_tiled, a.tile_np, a.out_seq, a.out_elem);          // (real maps are never tiled: out_tiled == 0 with out_real)
+  const unsigned base = sd.F(seq) + sd.G(kb);
+  const cx<T>* p = s + sq * LD;
 #pragma unroll
   for (int c = 0; c < NPC; ++c) {
     cx<T> y[PCH], yr[PCH];
 #pragma unroll
     for (int ii = 0; ii < PCH; ++ii) {
-      const int i = c * PCH + ii, k0 = out_by_seq ? ((tid + i * NT) >> LGS) : (lane + 64 * i), k = min(k0, a.nout - 1);
-      const cx<T>* p = s + (out_by_seq ? ((tid + i * NT) & (S - 1)) : wave) * LD;
+      const int k = min(kb + 64 * (c * PCH + ii), a.nout - 1);
       y[ii] = p[pad(k)];
       yr[ii] = p[pad(split && k ? N - k : 0)];                           // Z[N - k]: only the pair split reads it
     }
 #pragma unroll
     for (int ii = 0; ii < PCH; ++ii) {
-      const int i = c * PCH + ii, k = out_by_seq ? ((tid + i * NT) >> LGS) : (lane + 64 * i);
-      const int seq = seq0 + (out_by_seq ? ((tid + i * NT) & (S - 1)) : wave);
-      if (i < E && k < a.nout && seq < a.nseq) ct_put(a, sl, seq, k, mid ? conj(y[ii]) : y[ii], yr[ii]);
+      const int i = c * PCH + ii, k = kb + 64 * i;
+      if (i < E && k < a.nout && seq < a.nseq) ct_put(a, sl, base + (unsigned)i * sd.step, k, mid ? conj(y[ii]) : y[ii], yr[ii]);
     }
   }
+  (void)wave; (void)lane;
 }
 
 // Fused y passes of a forward flow stage, on the wavefront's own column `seq` (row = its LDS row, holding the fetched pair
@@ -425,6 +454,9 @@ __device__ __forceinline__ void ct_flow_stage(const GenDft<T>& a, cx<T>* __restr
 #define CMBL_CT_STAMP(i) do {} while (0)
 #endif
 
+#ifndef CMBL_DY_PROBE
+#define CMBL_DY_PROBE 0      // timing-only probes of k_ct_delta_y (results wrong): 1 no transforms, 2 no product stores, 4 no operand loads, 8 no final stores
+#endif
 template <typename T> constexpr int ct_min_waves() { return sizeof(T) == 4 ? 4 : 2; }       // two workgroups per CU
 // ... of the x-pass kernels: two workgroups of S wavefronts per CU, and ONE from 1000 points on -- 16-24 elements per lane under the 128-register
 // cap spilled 80-170 registers (1000 = 8 5 5 5: 300 bytes of scratch per lane in the d/dx pass), while a launch of <= 256 row groups has one
@@ -435,13 +467,18 @@ template <typename T, int N, int S> constexpr int ct_min_waves_x() {
 }
 
 template <typename T, int N, bool CONLY = false /*complex in, complex out only (x passes): no other fetch variant is compiled in*/, int S = ct_S<T>()>
-__device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsigned ysl) {
+__device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsigned ysl, int ngroups = 0) {
   constexpr int LGS = ilog2c(S), NT = 64 * S, LD = ct_ld(N), NTW = N / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
-  const bool in_by_seq = a.in_elem != 1, out_by_seq = a.out_elem != 1;
-  const int seq0 = ((in_by_seq || out_by_seq) ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * S;
+  const int in_by_seq = a.in_tiled == 2 ? 2 : (a.in_elem != 1 ? 1 : 0), out_by_seq = a.out_tiled == 2 ? 2 : (a.out_elem != 1 ? 1 : 0);   // ct_map modes
+  // (a transposed or tiled side: neighbouring groups share lines -- the same XCD's L2 should see both; the host rounds the grid of the tiled x
+  //  launches up to a multiple of 8 for it, hence the exit)
+  // (ngroups: the groups of THIS transform where the launch has more -- the second part of k_ct_adj_x_dx: the XCD ranges are those of its own count)
+  if (ngroups && (int)blockIdx.x >= ngroups) return;
+  const int seq0 = ((in_by_seq || out_by_seq) ? xcd_tile(blockIdx.x, ngroups ? ngroups : (int)gridDim.x) : (int)blockIdx.x) * S;
+  if (seq0 >= a.nseq) return;
   const size_t sl = gen_slice(a, ysl);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef CMBL_STAMPS_CT
@@ -529,7 +566,7 @@ __global__ __launch_bounds__(64 * S, 1) void k_ct_flow_y(GenDft<T> a) {
   __syncthreads();
   GenDft<T> b{};                                                         // the store side: rfft_y(f_next) as a half spectrum, [ky][x]
   b.out = a.yy_out; b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1);
-  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
+  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice; b.out_tiled = a.in_tiled; b.tile_np = a.tile_np;
   ct_store_rows<T, N, S>(b, s, sl, seq0, true, wave, lane, false);
 }
 
@@ -571,6 +608,7 @@ __global__ __launch_bounds__(128 * S) void k_ct_delta_y(GenDft<T> a) {
 #pragma unroll
   for (int j = 0; j < EH; ++j) {
     const unsigned o = (unsigned)seqc * (unsigned)N + (unsigned)min(lane + 64 * (2 * j + set), N - 1);
+    if (CMBL_DY_PROBE & 4) { y0v[j] = T(o); acv[j] = T(1); px[j] = T(2); py[j] = T(3); continue; }
     y0v[j] = at32(e.y0 + mb, o); acv[j] = at32(e.acc + mb, o);
     if (pc) { px[j] = at32(e.ph.pcx + pb, o); py[j] = at32(e.ph.pcy + pb, o); }
     else {
@@ -579,7 +617,7 @@ __global__ __launch_bounds__(128 * S) void k_ct_delta_y(GenDft<T> a) {
     }
   }
   __syncthreads();
-  if (live) ct_transform<T, N>(set ? r2 : r1, tw, lane);
+  if (live && !(CMBL_DY_PROBE & 1)) ct_transform<T, N>(set ? r2 : r1, tw, lane);
   __syncthreads();
   if (live) {
 #pragma unroll
@@ -592,7 +630,7 @@ __global__ __launch_bounds__(128 * S) void k_ct_delta_y(GenDft<T> a) {
         const T k = px[j] * gx + py[j] * gy;
         T y = y0v[j], ac = e.rk.stage == 1 ? T(0) : acv[j];
         const T nxt = rk_update(e.rk, k, y, ac);
-        at32(e.w1p + mb, o) = l * gx; at32(e.w2p + mb, o) = l * gy;
+        if (!(CMBL_DY_PROBE & 2)) { at32(e.w1p + mb, o) = l * gx; at32(e.w2p + mb, o) = l * gy; }
         if (e.rk.stage == 4) at32(e.y0 + mb, o) = y; else at32(e.acc + mb, o) = ac;
         r1[pad(n)] = mk<T>(nxt, T(0));
         r2[pad(n)] = mk<T>(px[j] * l, py[j] * l);
@@ -600,11 +638,12 @@ __global__ __launch_bounds__(128 * S) void k_ct_delta_y(GenDft<T> a) {
     }
   }
   __syncthreads();
-  if (live && !(set == 0 && a.yy_last)) ct_transform<T, N>(set ? r2 : r1, tw, lane);
+  if (live && !(set == 0 && a.yy_last) && !(CMBL_DY_PROBE & 1)) ct_transform<T, N>(set ? r2 : r1, tw, lane);
   __syncthreads();
   GenDft<T> b{};                                                         // store side, [ky][x] like the inputs
   b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1); b.scale2 = T(1);
-  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
+  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice; b.out_tiled = a.in_tiled; b.tile_np = a.tile_np;
+  if (CMBL_DY_PROBE & 8) return;
   if (set == 0) {
     if (!a.yy_last) { b.out = a.yy_out; ct_store_rows<T, N, S>(b, s, sl, seq0, true, wave, lane, false, tid); }
   } else {
@@ -664,7 +703,7 @@ __global__ __launch_bounds__(64 * S, 1) void k_ct_adj_y(GenDft<T> a) {
   __syncthreads();
   GenDft<T> b{};
   b.N = N; b.nout = a.yy_nout; b.nseq = a.nseq; b.in_real = 1; b.scale = T(1); b.scale2 = T(1);
-  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice;
+  b.out_seq = a.in_seq; b.out_elem = a.in_elem; b.out_slice = a.in_slice; b.out_tiled = a.in_tiled; b.tile_np = a.tile_np;
   b.out = a.yy_out2; b.out2 = a.yy_out3; b.in2 = a.yy_out3;              // in2 != nullptr marks the pair split (ct_put)
   ct_store_rows<T, N, S>(b, s, sl, seq0, true, wave, lane, false);
 }
@@ -678,24 +717,36 @@ __global__ __launch_bounds__(64 * S, 1) void k_ct_adj_y(GenDft<T> a) {
 // Ys back from memory (k_ct_dft2's first half / gen_x); a.out (Ys) may then be nullptr.  Same wavefront arithmetic: bit-identical.
 template <typename T, int N, int S>
 __device__ __forceinline__ void ct_adj_x_body(const GenDft<T>& a, unsigned ysl) {
-  constexpr int R = S / 2, NT = 64 * S, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64, EH = (E + 1) / 2;
+  constexpr int R = S / 2, LGR = ilog2c(R), NT = 64 * S, LD = ct_ld(N), NTW = N / 2, E = (N + 63) / 64, EH = (E + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* tw = reinterpret_cast<cx<T>*>(smem);
   cx<T>* s = tw + NTW;
-  const size_t sl = gen_slice(a, ysl), sb = sl * a.in_slice;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = wave / R, r = wave % R, ky = blockIdx.x * R + r;
+  const size_t sl = gen_slice(a, ysl), sb = sl * a.in_slice, sbs = sl * a.out_slice;   // slice of the hand-off arrays (pair, T3) / of the Fourier state (Y0, acc, Ys)
+  const int grp = a.in_tiled ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // (tiled: two groups share each 128-byte line of the pair and of T3)
+  if (grp * R >= a.nseq) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = wave / R, r = wave % R, ky = grp * R + r;
   const bool live = ky < a.nseq;
   const int kyc = live ? ky : a.nseq - 1;
   TwStage<T, NT, NTW> twr;
   twr.issue(a.tw);
   const RKCoef<T> rk = a.pro.rk;
-  const cx<T>* Y0 = reinterpret_cast<const cx<T>*>(a.yy_out) + sb;
-  const cx<T>* Ac = reinterpret_cast<const cx<T>*>(a.out2) + sb;
+  // tiled arrays: thread (r, lane) of a member -> row trr of the member's R rows, x = txb + 64 i (consecutive lanes: the 4 x of a block row, then the rows)
+  const int tq = r * 64 + lane, trr = (tq >> 2) & (R - 1), txb = ((tq >> (2 + LGR)) << 2) + (lane & 3);
+  const unsigned tG = (unsigned)(txb >> 2) * 4u * (unsigned)a.tile_np + (unsigned)(lane & 3);
+  const cx<T>* Y0 = reinterpret_cast<const cx<T>*>(a.yy_out) + sbs;
+  const cx<T>* Ac = reinterpret_cast<const cx<T>*>(a.out2) + sbs;
   cx<T> v[E] = {}, y0v[EH] = {}, acv[EH] = {};
   {
     const cx<T>* src = reinterpret_cast<const cx<T>*>(m ? a.in2 : a.in) + sb;
+    if (a.in_tiled) {                                                    // tiled pair: the R wavefronts of the member walk (4 x, R rows) blocks of its R rows
+      const unsigned Fs = 4u * (unsigned)min(grp * R + trr, a.nseq - 1), stp = 64u * (unsigned)a.tile_np;   // element i of the thread: x = txb + 64 i
 #pragma unroll
-    for (int i = 0; i < E; ++i) v[i] = at32(src, (unsigned)kyc * (unsigned)N + (unsigned)min(lane + 64 * i, N - 1));
+      for (int i = 0; i < E; ++i)
+        v[i] = at32(src, (N % 64 == 0 || i < E - 1) ? Fs + tG + (unsigned)i * stp : Fs + (unsigned)(min(txb + 64 * i, N - 1) >> 2) * 4u * (unsigned)a.tile_np + (unsigned)(lane & 3));
+    } else {
+#pragma unroll
+      for (int i = 0; i < E; ++i) v[i] = at32(src, (unsigned)kyc * (unsigned)N + (unsigned)min(lane + 64 * i, N - 1));
+    }
 #pragma unroll
     for (int j = 0; j < EH; ++j) {                                       // the RK operands of this wavefront's share, requested up front
       const unsigned o = (unsigned)kyc * (unsigned)N + (unsigned)min(lane + 64 * (2 * j + m), N - 1);
@@ -703,8 +754,13 @@ __device__ __forceinline__ void ct_adj_x_body(const GenDft<T>& a, unsigned ysl) 
     }
   }
   cx<T>* row = s + wave * LD;
+  if (a.in_tiled) {
 #pragma unroll
-  for (int i = 0; i < E; ++i) { const int n = lane + 64 * i; if (N % 64 == 0 || n < N) row[pad(n)] = v[i]; }
+    for (int i = 0; i < E; ++i) { const int x = txb + 64 * i; if (N % 64 == 0 || x < N) s[(m * R + trr) * LD + pad(x)] = v[i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < E; ++i) { const int n = lane + 64 * i; if (N % 64 == 0 || n < N) row[pad(n)] = v[i]; }
+  }
   twr.commit(tw);
   __syncthreads();
   if (live) ct_transform<T, N>(row, tw, lane);
@@ -712,8 +768,8 @@ __device__ __forceinline__ void ct_adj_x_body(const GenDft<T>& a, unsigned ysl) 
   cx<T>* const T3 = a.yy_out2 ? reinterpret_cast<cx<T>*>(a.yy_out2) + sb : nullptr;       // (uniform)
   if (live) {
     const T l_y = a.lmul_in[ky];
-    cx<T>* Ys = a.out ? reinterpret_cast<cx<T>*>(a.out) + sb : nullptr;
-    cx<T>* dst = (rk.stage == 4 ? reinterpret_cast<cx<T>*>(a.yy_out) : reinterpret_cast<cx<T>*>(a.out2)) + sb;
+    cx<T>* Ys = a.out ? reinterpret_cast<cx<T>*>(a.out) + sbs : nullptr;
+    cx<T>* dst = (rk.stage == 4 ? reinterpret_cast<cx<T>*>(a.yy_out) : reinterpret_cast<cx<T>*>(a.out2)) + sbs;
 #pragma unroll
     for (int j = 0; j < EH; ++j) {
       const int k = lane + 64 * (2 * j + m);
@@ -733,8 +789,19 @@ __device__ __forceinline__ void ct_adj_x_body(const GenDft<T>& a, unsigned ysl) 
   __syncthreads();
   if (live && m == 0) ct_transform<T, N>(row, tw, lane);                  // (member 0's wavefront owns row r)
   __syncthreads();
-  if (live) {
-    const bool wt = wt_line<T>(N);
+  const bool wt = wt_line<T>(N);
+  if (a.out_tiled) {                                                     // tiled T3: the whole workgroup walks (4 x, R rows) blocks of its R rows
+    const int q0 = (int)threadIdx.x, rr = (q0 >> 2) & (R - 1), xb = ((q0 >> (2 + LGR)) << 2) + (q0 & 3), kyr = grp * R + rr;   // x = xb + 128 j
+    const unsigned o0 = ((unsigned)(xb >> 2) * (unsigned)a.tile_np + (unsigned)kyr) * 4u + (unsigned)(q0 & 3), stp = (unsigned)(NT / R) * (unsigned)a.tile_np;
+#pragma unroll
+    for (int j = 0; j < EH; ++j) {
+      const int x = xb + j * (NT / R);
+      if (x < N && kyr < a.nseq) {
+        const cx<T> y = conj(s[rr * LD + pad(x)]);
+        ct_store<(int)sizeof(cx<T>)>(T3, (o0 + (unsigned)j * stp) * (unsigned)sizeof(cx<T>), &y, wt);
+      }
+    }
+  } else if (live) {
 #pragma unroll
     for (int j = 0; j < EH; ++j) {
       const int k = lane + 64 * (2 * j + m);
@@ -751,8 +818,8 @@ __global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_adj_
 // workgroups of the same launch: grid.y = ny_adj slices of row updates + the slices of a1; grid.x covers the larger of the two parts
 template <typename T, int N, int S = ct_S<T>()>
 __global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_adj_x_dx(GenDft<T> a, int ny_adj, GenDft<T> a1) {
-  if ((int)blockIdx.y < ny_adj) { if ((int)blockIdx.x * (S / 2) < a.nseq) ct_adj_x_body<T, N, S>(a, blockIdx.y); }
-  else if ((int)blockIdx.x * S < a1.nseq) ct_dft_body<T, N, true, S>(a1, CT_C, blockIdx.y - (unsigned)ny_adj);
+  if ((int)blockIdx.y < ny_adj) ct_adj_x_body<T, N, S>(a, blockIdx.y);       // (either part leaves by itself where the grid is larger than it needs)
+  else ct_dft_body<T, N, true, S>(a1, CT_C, blockIdx.y - (unsigned)ny_adj, a1.in_tiled ? (((a1.nseq + S - 1) / S + 7) & ~7) : (a1.nseq + S - 1) / S);
 }
 
 }  // namespace cmbl

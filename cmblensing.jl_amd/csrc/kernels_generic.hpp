@@ -92,6 +92,12 @@ template <typename T> struct GenDft {
   void* yy_out;
   const void* yy_in3; void* yy_out2; void* yy_out3;
   T yy_scale3;
+  // TILED hand-off arrays (round 6; compile-time-plan kernels only): the half planes the column and row launches of the fused any-size stages pass
+  // to each other as [slice][x / 4][ky (tile_np rows)][x % 4] -- the tiled mixed layout of the power-of-two path (kernels_fft.hpp mix_idx) -- instead
+  // of [slice][ky][x].  A column workgroup's 4 (8) columns are then ONE (two) contiguous block(s) instead of 32-byte pieces a row apart, a row
+  // workgroup of 4 adjacent ky gathers whole 128-byte lines.  in_tiled / out_tiled: 0 = strided (in_seq / in_elem), 1 = the sequence index is x (y
+  // kernels), 2 = the element index is x (x kernels); in2, yy_in3 follow in_tiled, out2 / yy_out* follow out_tiled (addressing: CtSide, kernels_ct.hpp).
+  int in_tiled, out_tiled, tile_np;
 };
 template <typename T> __device__ __forceinline__ size_t gen_slice(const GenDft<T>& a, unsigned y = blockIdx.y) {
   return a.sln ? (size_t)a.sl0 + (y % (unsigned)a.sln) + (size_t)(y / (unsigned)a.sln) * (unsigned)a.slstride : (size_t)y;
