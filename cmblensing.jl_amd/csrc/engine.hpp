@@ -96,7 +96,7 @@ struct CtxBase {
     int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 1 << 19);   //   ... from this many pixels on (a quarter of it for >= 3 slices)
     int gen_yy = env_int("CMBL_GEN_YY", 1) != 0;                          //   the y passes of a forward stage in one launch (GenDft::yy; needs gen_ct)
     int gen_xmerge = env_int("CMBL_GEN_XMERGE", 1) != 0;                  //   the row update of an adjoint-type stage also opens the next stage (gen_x_adj_next): one launch less per stage
-    int gen_tiled = env_int("CMBL_GEN_TILED", 7);                    //   the half planes the fused any-size stages hand between their column and row launches are TILED ([x / 4][ky][x % 4], GenDft::in_tiled) instead of [ky][x]
+    int gen_tiled = env_int("CMBL_GEN_TILED", 7);                     //   the half planes the fused any-size stages hand between their column and row launches are TILED ([x / 4][ky][x % 4], GenDft::in_tiled) instead of [ky][x]
     int gen_ct_cols = env_int("CMBL_GEN_CT_COLS", 1);                     //   half-width column groups in the fused y passes: 0 never, 1 for small launches (Ctx::ct_cols_per_group), 2 always
     int gen_ct_rows = env_int("CMBL_GEN_CT_ROWS", 1) != 0;                //   shorter row groups in x-pass launches with fewer groups than CUs (Ctx::ct_rows_per_group)
     int gen_ct = env_int("CMBL_GEN_CT", 1) != 0;                          //   compile-time plans for the lengths of CMBL_CT_LIST (kernels_ct.hpp)
@@ -325,27 +325,39 @@ struct Ctx : CtxBase {
   }
   bool gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   void gen_dft(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
+  // (the mixed scratch between the two launches of a 2-D transform is a hand-off array like those of the flows: tiled under bit 8 of gen_tiled)
+  struct HandOff2D {
+    Ctx<T>* c; int keep;
+    explicit HandOff2D(Ctx<T>* c_) : c(c_), keep(c_->htile) { c->htile = (c->opts.gen_tiled & 8) ? c->gen_tile() : 0; }
+    ~HandOff2D() { c->htile = keep; }
+  };
   void gen_rfft2(const T* map, cx<T>* F, long slices) {
     cx<T>* tmp = mixed_scratch(slices);
+    HandOff2D ho(this);
     GenDft<T> a{};                                                          // y: map [x][y] -> tmp [ky][x]
     a.in = map; a.out = tmp; a.in_real = 1; a.nin = Ny; a.nout = Nyh; a.nseq = Nx; a.scale = 1;
     a.in_seq = Ny; a.in_elem = 1; a.in_slice = npix(); a.out_seq = 1; a.out_elem = Nx; a.out_slice = plane();
+    hand_out<1>(a);
     gen_dft(genY, a, slices);
     GenDft<T> b{};                                                          // x: tmp [ky][x] -> F [ky][kx]
     b.in = tmp; b.out = F; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1;
     b.in_seq = Nx; b.in_elem = 1; b.in_slice = plane(); b.out_seq = Nx; b.out_elem = 1; b.out_slice = plane();
+    hand_in<2>(b);
     gen_dft(genX, b, slices);
   }
   void gen_irfft2(const cx<T>* F, T* map, long slices) {
     cx<T>* tmp = mixed_scratch(slices);
+    HandOff2D ho(this);
     GenDft<T> b{};                                                          // x (inverse): F [ky][kx] -> tmp [ky][x]
     b.in = F; b.out = tmp; b.nin = Nx; b.nout = Nx; b.nseq = Nyh; b.scale = 1; b.inverse = 1;
     b.in_seq = Nx; b.in_elem = 1; b.in_slice = plane(); b.out_seq = Nx; b.out_elem = 1; b.out_slice = plane();
+    hand_out<2>(b);
     gen_dft(genX, b, slices);
     GenDft<T> a{};                                                          // y (c2r): tmp [ky][x] -> map [x][y]
     a.in = tmp; a.out = map; a.herm = 1; a.out_real = 1; a.inverse = 1; a.nin = Nyh; a.nout = Ny; a.nseq = Nx;
     a.scale = (T)(1.0 / ((double)Ny * Nx));
     a.in_seq = 1; a.in_elem = Nx; a.in_slice = plane(); a.out_seq = Ny; a.out_elem = 1; a.out_slice = npix();
+    hand_in<1>(a);
     gen_dft(genY, a, slices);
   }
   // Separable pieces of the any-size path (mixed layout [slice][ky][x], like the fused kernels use between their column and row passes):

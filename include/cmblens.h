@@ -94,7 +94,7 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *                                                                   next stage (CMBL_GEN_XMERGE, 1: 2 instead of 3 launches per stage; results bit-identical either way)
  *        "gen_tiled"                                                any-size flows (both axes with a compile-time plan): the half planes the fused stages hand between their
  *                                                                   column and row launches are stored as [x/4][ky][x%4] blocks instead of [ky][x]; bit mask 1 = map flows,
- *                                                                   2 = adjoint flows, 4 = delta flows (CMBL_GEN_TILED, 7; results bit-identical to 0)
+ *                                                                   2 = adjoint flows, 4 = delta flows, 8 = the scratch of the 2-D basis transforms (CMBL_GEN_TILED, 7: bit 8 measured neutral; results bit-identical to 0)
  *        "gen_yy"                                                   any-size flows: the passes of a stage that can share a launch do, where the axes have
  *                                                                   compile-time plans (CMBL_GEN_YY, 1; results bit-identical either way)
  *        "gen_slice_streams", "gen_streams_min_pix"                 any-size flows: one launch chain per group of slices from this many pixels

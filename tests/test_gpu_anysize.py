@@ -244,13 +244,15 @@ def test_anysize_tiled_hand_off_changes_no_result(camb, prec, Ny, Nx, P, B):
         p.set_option("gen_ct_cols", 2 * groups)
         res = {}
         for on in (0, 1):
-            p.set_option("gen_tiled", 7 * on)
+            p.set_option("gen_tiled", 15 * on)                              # 1 map flows + 2 adjoint flows + 4 delta flows + 8 the 2-D basis transforms
             L = C.LenseFlow(p, 7)(C.Field(p, p.tensor(phi), C.MAP))
             ft = L * C.Field(p, p.tensor(f), C.MAP)
             g = C.Field(p, p.tensor(delta), C.FOURIER)
             dphi, df, f0 = L.gradient(C.FLOW_FWD, ft, g)
-            res[on] = [ft.arr.clone(), L.ldiv(ft).arr.clone(), (L.adjoint * g).arr.clone(), L.adjoint.ldiv(g).arr.clone(), dphi.arr.clone(), df.arr.clone(), f0.arr.clone()]
-        for name, a, b in zip(("L*f", "L\\f", "L'g", "L'\\g", "dphi", "df", "f0"), res[1], res[0]):
+            Fk = p.rfft(ft.arr)
+            res[on] = [ft.arr.clone(), L.ldiv(ft).arr.clone(), (L.adjoint * g).arr.clone(), L.adjoint.ldiv(g).arr.clone(), dphi.arr.clone(), df.arr.clone(), f0.arr.clone(),
+                       Fk.clone(), p.irfft(Fk).clone()]
+        for name, a, b in zip(("L*f", "L\\f", "L'g", "L'\\g", "dphi", "df", "f0", "rfft2", "irfft2"), res[1], res[0]):
             assert torch.equal(a, b), (groups, name)
 
 
