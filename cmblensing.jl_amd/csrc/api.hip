@@ -29,6 +29,13 @@ static int guard(F&& f) {
 #define POLB_OK(P, B) CMBL_REQUIRE((P) >= 1 && (P) <= 3 && (B) >= 1, ERR_SHAPE, "npol must be 1..3 and nbatch >= 1")
 #define BY_DTYPE(ctx, expr32, expr64) do { if ((ctx)->p->dtype == CMBL_F32) { expr32; } else { expr64; } } while (0)
 
+#ifdef CMBL_STAMPS
+namespace cmbl {
+#define CMBL_X(unit) int stamps_read_##unit(unsigned long long* out_host, int n);
+CMBL_X(main_f32) CMBL_X(main_f64) CMBL_X(gen_f32) CMBL_X(gen_f64) CMBL_X(genx_f32) CMBL_X(genx_f64) CMBL_X(small_f32) CMBL_X(small_f64)
+#undef CMBL_X
+}
+#endif
 extern "C" {
 
 const char* cmbl_last_error(void) { return g_last_error.c_str(); }
@@ -362,8 +369,18 @@ int cmbl_quadratic_estimate(cmbl_dataset* ds, int which, const double* Cf_host, 
 }
 
 #ifdef CMBL_STAMPS
-int cmbl_debug_stamps(unsigned long long* out_host, int n) {   // phase timestamps of the last k_delta_y launch (tools/gpu_stamps.py)
-  return guard([&] { CMBL_HIP(hipDeviceSynchronize()); CMBL_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(cmbl::g_stamps), sizeof(unsigned long long) * n)); });
+// phase timestamps of the last stamped launch (tools/gpu_stamps*.py) of the translation unit CMBL_STAMPS_TU (kernels_fft.hpp CMBL_STAMPS_READER)
+int cmbl_debug_stamps(unsigned long long* out_host, int n) {
+  return guard([&] {
+    CMBL_HIP(hipDeviceSynchronize());
+    const char* e = std::getenv("CMBL_STAMPS_TU");
+    const std::string u = e ? e : "main_f32";
+    int rc = -1;
+#define CMBL_X(unit) if (u == #unit) rc = cmbl::stamps_read_##unit(out_host, n);
+    CMBL_X(main_f32) CMBL_X(main_f64) CMBL_X(gen_f32) CMBL_X(gen_f64) CMBL_X(genx_f32) CMBL_X(genx_f64) CMBL_X(small_f32) CMBL_X(small_f64)
+#undef CMBL_X
+    CMBL_REQUIRE(rc == 0, ERR_ARG, "CMBL_STAMPS_TU: main_f32 | main_f64 | gen_f32 | gen_f64 | genx_f32 | genx_f64 | small_f32 | small_f64");
+  });
 }
 #endif
 

@@ -15,15 +15,15 @@ bool Ctx<T>::gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
   static const int stamp_kind = env_int("CMBL_CT_STAMP_KIND", -1);
   if (kind + (a.lmul_mid ? 8 : 0) == stamp_kind) kind |= 256;
 #endif
-  if (kind == CT_C && a.in_elem == 1 && a.out_elem == 1) {                 // contiguous rows: groups of 8 / 4 / 2 (ct_rows_per_group)
+  if ((kind & 255) == CT_C && a.in_elem == 1 && a.out_elem == 1) {                 // contiguous rows: groups of 8 / 4 / 2 (ct_rows_per_group)
     const int Sx = ct_rows_per_group((long)a.nseq * slices, 1);
     a.S = Sx;
     const dim3 gx((unsigned)xgroups((a.nseq + Sx - 1) / Sx, a.in_tiled || a.out_tiled), (unsigned)slices);
     switch (ax.N) {
 #define CMBL_X(n) case n: \
-        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>()>), gx, ct_lds<T>(n), stream, a); \
-        else if (Sx == ct_S<T>() / 2) CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>() / 2>), gx, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
-        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 16 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>() / 4>), gx, (ct_lds<T>(n, 1, ct_S<T>() / 4)), stream, a); \
+        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>()>), gx, ct_lds<T>(n), stream, a, kind); \
+        else if (Sx == ct_S<T>() / 2) CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>() / 2>), gx, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a, kind); \
+        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 16 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>() / 4>), gx, (ct_lds<T>(n, 1, ct_S<T>() / 4)), stream, a, kind); \
         return true;
       CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X

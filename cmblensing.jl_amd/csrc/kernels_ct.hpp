@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_dft2
 }
 // one complex -> complex transform launch on contiguous rows (the x transforms and the one-launch d/dx pass)
 template <typename T, int N, int S>
-__global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_dftx(GenDft<T> a) { ct_dft_body<T, N, true, S>(a, CT_C, blockIdx.y); }
+__global__ __launch_bounds__(64 * S, (ct_min_waves_x<T, N, S>())) void k_ct_dftx(GenDft<T> a, int kind /*CT_C (+ the debug builds' stamp flag)*/) { ct_dft_body<T, N, true, S>(a, kind, blockIdx.y); }
 
 // The y passes of a forward flow stage in one launch (GenDft::yy; Ctx::gen_y_flow_stage): pair-c2r fetch, ct_flow_stage on every column,
 // rfft_y(f_next) stored as a half spectrum in the layout of the inputs.  A kernel of its own: its register needs are not k_ct_dft's.

@@ -30,8 +30,14 @@ namespace cmbl {
 __host__ __device__ constexpr int ilog2c(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
 // debug builds (-DCMBL_STAMPS): per-workgroup phase timestamps, read back with cmbl_debug_stamps (tools/gpu_stamps.py)
+// (the buffer is per translation unit -- device symbols are not shared without relocatable device code -- so each unit exports a reader,
+//  CMBL_STAMPS_READER below, and cmbl_debug_stamps picks the unit: CMBL_STAMPS_TU = main_f32 (default) | main_f64 | gen_f32 | genx_f32 | ...)
 #ifdef CMBL_STAMPS
 __device__ unsigned long long g_stamps[8192 * 16];
+#define CMBL_STAMPS_READER(unit) namespace cmbl { int stamps_read_##unit(unsigned long long* out_host, int n) { \
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n); } }
+#else
+#define CMBL_STAMPS_READER(unit)
 #endif
 #if defined(CMBL_STAMPS) && !defined(CMBL_STAMPS_ROWS)      // CMBL_STAMPS_ROWS: only k_delta_rows writes (its own slots 14 / 15)
 #define CMBL_STAMP(i) do { if (threadIdx.x == 0) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = clock64(); } while (0)

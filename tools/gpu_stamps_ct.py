@@ -1,5 +1,5 @@
 """Phase timestamps inside k_ct_dft (debug build: tools/devbuild.sh stampsct -DCMBL_STAMPS -DCMBL_STAMPS_ROWS -DCMBL_STAMPS_CT):
-   CMBL_CT_STAMP_KIND=<kind, +8 for the d/dx pass> CMBL_LIB=cmblensing.jl_amd/_dev/lib_stampsct.so python tools/gpu_stamps_ct.py [N]
+   CMBL_CT_STAMP_KIND=<kind, +8 for the d/dx pass> CMBL_STAMPS_TU=gen_f32 [OP=Lf] [NB=blocks] CMBL_LIB=cmblensing.jl_amd/_dev/lib_stampsct.so python tools/gpu_stamps_ct.py [N]
 kinds: 0 complex, 1 real, 2 real pair, 3 c2r, 4 pair c2r, 5 / 6 / 7 real with the stage's pointwise work in the fetch"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,8 @@ s = C.load_sim(2.0, N, "P", synthetic_cls(), T=torch.float32, pixel_mask=dict(pa
 ds, f, phi = s["ds"], s["f"], s["phi"]
 fm = f.to(C.MAP); L = ds.L(phi); gl = fm.to(C.FOURIER); ft = L * fm
 for _ in range(3):
-    L.gradient(C.FLOW_FWD, ft, gl)
+    if os.environ.get("OP", "gradL") == "Lf": L * fm                      # OP=Lf: the forward flow (its d/dx pass is a k_ct_dftx launch: kind 8)
+    else: L.gradient(C.FLOW_FWD, ft, gl)
 torch.cuda.synchronize()
 lib = C.load_library()
 nb = int(os.environ.get("NB", 96))
