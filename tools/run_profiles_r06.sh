@@ -21,9 +21,11 @@ timeout 600 python tools/gpu_configs.py > $out/configs_table.txt 2>&1
 # any-size path: the times table, the kernel statistics and SQ counters of the 768^2 step
 timeout 1500 bash tools/run_anysize_times.sh > $out/anysize_times.txt 2>&1
 { echo "## 1920^2 (15 * 2^7, in CMBL_CT_LIST since round 6) and 960 x 1920 with / without the compile-time plans"; python tools/gpu_time.py 1920 P f32 2>&1 | grep -v amdgpu; NT=5 ROUNDS=1 python tools/gpu_opt_ab.py gen_ct 0,1 960x1920 P f32 7 2>&1 | grep MIN; } >> $out/anysize_times.txt 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $out/kt768 -o p -- python tools/gpu_step_loop.py 768 P f32 20 > $out/kt768.log 2>&1
-f=$(find $out/kt768 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_768QU_f32_anysize.csv
-rm -rf $out/kt768
+for n in 768 1000 1536; do
+  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $out/kt$n -o p -- python tools/gpu_step_loop.py $n P f32 20 > $out/kt$n.log 2>&1
+  f=$(find $out/kt$n -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_${n}QU_f32_anysize.csv
+  rm -rf $out/kt$n
+done
 timeout 900 bash tools/run_pmc_sq_anysize.sh ${tag}any > $out/pmc_sq_anysize_768.txt 2>&1
 rm -rf gpurun_out/${tag}any/pmc_sq1 gpurun_out/${tag}any/pmc_sq2
 # small maps
