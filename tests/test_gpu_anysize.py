@@ -230,11 +230,12 @@ def test_anysize_row_group_height_changes_no_result(camb, prec, Ny, Nx, P):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("Ny,Nx,P,B", [(96, 160, 2, 1), (160, 96, 2, 3), (384, 192, 1, 1), (360, 320, 3, 2)])
+@pytest.mark.parametrize("Ny,Nx,P,B", [(96, 160, 2, 1), (160, 96, 2, 3), (384, 192, 1, 1), (360, 320, 3, 2), (480, 720, 2, 1), (720, 960, 1, 1), (1280, 96, 2, 1), (96, 1536, 2, 1)])
 def test_anysize_tiled_hand_off_changes_no_result(camb, prec, Ny, Nx, P, B):
     """the half planes the fused any-size stages hand between their column and row launches are tiled ([x / 4][ky][x % 4], option gen_tiled,
     GenDft::in_tiled) instead of [ky][x]: a layout of scratch arrays only -- every sequence goes through the same wavefront arithmetic, bit for
-    bit; with the full and the half-height / half-width groups, batches, and Nyh = 81, 181, 193 (not multiples of 4: padded block columns)"""
+    bit; with the full and the half-height / half-width groups, batches, Nyh = 81, 181, 193 (not multiples of 4: padded block columns), and the
+    lengths of the compile-time-plan list that no oracle comparison of the flows visits (480, 720, 960, 1280; 1536 on the row side)"""
     C = _pkg()
     tT, nT = DT[prec]
     oproj, simf, simp = sims(camb, Ny, Nx, P, B)
