@@ -13,7 +13,10 @@
 //     memory latency per workgroup instead of one per element.  The fetch variants are separate straight-line instantiations (KIND)
 //     selected by one uniform switch at the top of the kernel;
 //   * padded LDS rows (fft_lds.hpp pad()), row stride = 8 (mod 32) slots so that the transposed side of a y pass spreads over the banks;
-//   * workgroups that are neighbours in the strided direction share 128-byte lines: they are mapped to the same XCD (xcd_tile).
+//   * workgroups that are neighbours in the strided direction share 128-byte lines: they are mapped to the same XCD (xcd_tile);
+//   * (late round 6) the half planes the column and row launches of the fused flow stages hand to each other can be TILED, [x / 4][ky][x % 4]
+//     (GenDft::in_tiled / out_tiled, CtSide below): a column workgroup reads and writes contiguous blocks, a row workgroup whole or half
+//     128-byte lines; every fetch / store loop runs on one offset per thread + a scalar step per element (ct_map0, CtSide).
 #pragma once
 #include "kernels_generic.hpp"
 
@@ -248,8 +251,9 @@ template <int S> __device__ __forceinline__ void ct_map0(int mode, int tid, int&
   sq = mode ? ((tid >> sh) & (S - 1)) : (tid >> 6);
   nb = mode ? (((tid >> (sh + LGS)) << sh) + (tid & mk)) : (tid & 63);
 }
-// One side's addressing (gen_off, kernels_generic.hpp) as scalars: off(seq, n) = F(seq) + G(n), and G(n + 64 j) = G(n) + j step -- a thread's
-// elements are ONE offset + multiples of a scalar (the index arithmetic of a general (seq, n) per element cost the fused stages 5 % of their time)
+// One side's addressing as scalars.  Strided arrays: off(seq, n) = seq sseq + n selem; tiled arrays (GenDft::in_tiled): ((x >> 2) np + ky) 4 + (x & 3)
+// with x the sequence (1) or the element (2) index.  Either way off(seq, n) = F(seq) + G(n) and G(n + 64 j) = G(n) + j step -- a thread's elements
+// are ONE offset + multiples of a scalar (the index arithmetic of a general (seq, n) per element cost the fused stages 5 % of their time)
 struct CtSide {
   unsigned sh_s, mk_s, ms, sh_n, mk_n, mn, step;
   __device__ __forceinline__ CtSide(int tiled, int np, long sseq, long selem) {
