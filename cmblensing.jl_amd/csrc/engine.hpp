@@ -93,7 +93,7 @@ struct CtxBase {
     int gen_prologue = env_int("CMBL_GEN_PROLOGUE", 1) != 0;              //   pointwise work in the fetch of the consuming transform
     int gen_xderiv_fused = env_int("CMBL_GEN_XDERIV_FUSED", 1) != 0;      //   d/dx pass as one launch
     int gen_slice_streams = env_int("CMBL_GEN_SLICE_STREAMS", 1) != 0;    //   one launch chain per group of slices (Flow::gen_groups)
-    int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 1 << 19);   //   ... from this many pixels on (a quarter of it for >= 3 slices)
+    int gen_streams_min_pix = env_int("CMBL_GEN_STREAMS_MIN_PIX", 300000);   //   ... whose chains carry at least this many 4-byte pixels each (Flow::gen_groups)
     int gen_yy = env_int("CMBL_GEN_YY", 1) != 0;                          //   the y passes of a forward stage in one launch (GenDft::yy; needs gen_ct)
     int gen_xmerge = env_int("CMBL_GEN_XMERGE", 1) != 0;                  //   the row update of an adjoint-type stage also opens the next stage (gen_x_adj_next): one launch less per stage
     int gen_tiled = env_int("CMBL_GEN_TILED", 7);                     //   the half planes the fused any-size stages hand between their column and row launches are TILED ([x / 4][ky][x % 4], GenDft::in_tiled) instead of [ky][x]
@@ -321,6 +321,10 @@ struct Ctx : CtxBase {
   int ct_cols_per_group(long cols, long slices, int S) const {
     if (!opts.gen_ct_rows || S != ct_S<T>() || opts.gen_ct_cols == 0) return S;
     if (opts.gen_ct_cols == 2) return S / 2;
+    // tiled hand-off arrays (htile), 8-byte elements: 4 columns are ONE block -- contiguous at either width -- and the half-width group won at every
+    // size and batch measured (1000^2 QU grad lnP -3.7 %, 1536^2 -4.7 %, 1000^2 T+QU -9 %, 768^2 QU at B = 4 -14.5 %; never slower:
+    // profiles/r06_ab_anysize_tiled_cols.txt).  16-byte elements: the full group IS one block (half of it: +1...+3 % at 768^2 / 1000^2)
+    if (htile && sizeof(T) == 4) return S / 2;
     return ((cols + S - 1) / S) * slices * 5 < 2L * num_cus ? S / 2 : S;
   }
   bool gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
@@ -1022,9 +1026,19 @@ struct Flow {
   // Measured (profiles/r05_anysize_times.txt): 1536^2 QU -17 %, 768^2 and 1000^2 T+QU -5 .. -7 %, 1000^2 QU +2 %, 768^2 QU +5 %, 360^2 +4 %,
   // 96 x 160 +20 % -- below ~2^21 pixels per launch the kernels last 6 - 9 us and the host (~5 us per launch) cannot feed two chains, so the
   // chains are split from 2^21 pixels on, three or more slices from 2^19.
+  // Launch chains of an any-size flow: the largest divisor K of the slice count (up to max_groups / option slice_streams) whose chains each carry at
+  // least gen_streams_min_pix pixels (in units of 4-byte pixels: a double-precision map counts twice), a third more for three or more chains.
+  // Measured with the tiled kernels (profiles/r06_ab_anysize_streams_retuned.txt; grad lnP with / without chains): QU 480^2 (230 k pixels per chain)
+  // +1.5 %, 480 x 640 (307 k) -3...-8 %, 640^2 -12 %, 720^2 -12 %; T+QU (three chains) 360^2 +7 %, 384^2 +9 %, 480 x 640 (307 k) +9.5 %, 640^2
+  // (410 k) -7 %; QU at B = 8 (four chains of four slices) 192^2 (147 k per chain) +68 %, 360^2 (518 k) -15 %, 480^2 -9 %; double precision 480^2
+  // -1.5 %, 640^2 -21 %.  (Round 5's rule -- pixels of ONE slice, x 4 from three slices on -- switched the chains on for T+QU from 131 k pixels.)
   int gen_groups(long slices) const {
-    if (!c->opts.gen_slice_streams || !gen_sep() || c->npix() * (slices >= 3 ? 4 : 1) < c->opts.gen_streams_min_pix) return 1;
-    for (int k = (int)std::min<long>(std::min(max_groups, c->opts.slice_streams), slices); k > 1; --k) if (slices % k == 0) return k;
+    if (!c->opts.gen_slice_streams || !gen_sep()) return 1;
+    for (int k = (int)std::min<long>(std::min(max_groups, c->opts.slice_streams), slices); k > 1; --k) {
+      if (slices % k) continue;
+      const long per_chain = c->npix() * (slices / k) * (long)(sizeof(T) / 4), need = (long)c->opts.gen_streams_min_pix * (k >= 3 ? 4 : 3) / 3;
+      if (per_chain >= need) return k;
+    }
     return 1;
   }
   struct GenWindow {                                                    // RAII: the launches of group g of K go to its stream

@@ -97,8 +97,8 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
  *                                                                   2 = adjoint flows, 4 = delta flows, 8 = the scratch of the 2-D basis transforms (CMBL_GEN_TILED, 7: bit 8 measured neutral; results bit-identical to 0)
  *        "gen_yy"                                                   any-size flows: the passes of a stage that can share a launch do, where the axes have
  *                                                                   compile-time plans (CMBL_GEN_YY, 1; results bit-identical either way)
- *        "gen_slice_streams", "gen_streams_min_pix"                 any-size flows: one launch chain per group of slices from this many pixels
- *                                                                   on (CMBL_GEN_SLICE_STREAMS 1, CMBL_GEN_STREAMS_MIN_PIX 2^21)
+ *        "gen_slice_streams", "gen_streams_min_pix"                 any-size flows: launch chains over groups of slices when every chain carries at least this many
+ *                                                                   4-byte pixels, a third more from three chains on (CMBL_GEN_SLICE_STREAMS 1, CMBL_GEN_STREAMS_MIN_PIX 300000)
  *        "occupancy_tiles"       CMBL_OCCUPANCY_TILES (3)          small maps: bit 0 = two-column tiles when four-column tiles leave CUs idle or unevenly loaded, bit 1 = shorter row groups
  *        "fill_target"           CMBL_FILL_TARGET (0)              > 0: narrow the column tiles below that many tiles per launch instead of the built-in rule
  *        "row_fill_target"       CMBL_ROW_FILL_TARGET (0 = CUs/2)  shorten the row groups below that many groups per launch
