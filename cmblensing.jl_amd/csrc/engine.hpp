@@ -85,7 +85,7 @@ struct CtxBase {
   // language, and a switch that flips between two launches of one flow would mix code paths).
   struct Opts {
     int slice_streams = env_int("CMBL_SLICE_STREAMS", 4);                 // launch chains per flow (1 = one launch over all slices)
-    int slice_streams_min_pix = env_int("CMBL_SLICE_STREAMS_MIN_PIX", 1 << 20);
+    int slice_streams_min_pix = env_int("CMBL_SLICE_STREAMS_MIN_PIX", 1 << 19);   //   ... whose chains carry at least this many pixels each (Flow::groups)
     int pcache = env_int("CMBL_NO_PCACHE", 0) == 0;                       // p(t_k) cache per phi (read when phi is set)
     int pcache_max_mb = env_int("CMBL_PCACHE_MAX_MB", 16384);
     int fused_harm = env_int("CMBL_NO_FUSED_HARM", 0) == 0;               // harmonic-space work on the row carrier (kernels_harm.hpp)
@@ -900,12 +900,19 @@ struct Flow {
   // ~4 us, and at 512^2 the kernels last 7 us, so splitting there makes the flow host-bound (measured: 512^2 L*f 0.41 -> 0.52 ms).
   // B = 1: one pol slice per group.  B > 1: groups of whole batch slots (K = the largest divisor of B that fits), so that a group's
   // phi slots are contiguous (phi_off) -- fewer, larger launches per chain, still several chains in flight.
-  int groups(int P, int B) const {
-    if (c->npix() < c->opts.slice_streams_min_pix) return 1;
+  // A chain must carry 2 x slice_streams_min_pix pixels (2^20: 1024^2 QU / T+QU as before), the two chains of a delta flow half of that -- round 6:
+  // counted per CHAIN, not per slice, so that
+  // batches of small maps and wide patches get their chains too.  grad lnP with / without (profiles/r06_ab_pow2_streams_retuned.txt): B = 1 512 x 1024
+  // QU (524 k per chain) -7 %, 512^2 QU (262 k) +6 %, 512^2 T+QU (three chains of 262 k) +26 %; two chains of batch slots: 256^2 QU B = 8 (524 k)
+  // -12 %, 512^2 QU B = 4 -13 %, B = 8 -8 %, 512^2 T+QU B = 2 -9 %, 512^2 QU B = 2 (524 k) -0.5 %, 128^2 QU B = 16 (262 k) +5 %.
+  // The launches of a delta flow last ~1.6 x those of a map or adjoint flow, and the host has to keep every chain fed (~4 us per launch): the map
+  // and adjoint flows need twice the pixels (512^2 QU B = 2, 524 k per chain: (grad L)' -6 %, L*f +13 %; 512 x 1024: -6 %, L*f -4...+13 % by box).
+  int groups(int P, int B, bool delta = false) const {
     const int cap = std::min(max_groups, c->opts.slice_streams);
-    if (B == 1) { if (Bphi == 1) for (int k = std::min(P, cap); k > 1; --k) if (P % k == 0) return k; return 1; }
+    auto pays = [&](long slices_per_chain, int k) { return c->npix() * slices_per_chain >= (long)c->opts.slice_streams_min_pix * ((delta && k < 3) ? 1 : 2); };
+    if (B == 1) { if (Bphi == 1) for (int k = std::min(P, cap); k > 1; --k) if (P % k == 0 && pays(P / k, k)) return k; return 1; }
     // measured at 1024^2 QU: B = 2 -> 2 chains +6 %; B = 4: 2 chains 262 evaluations/s, 4 chains 240, 1 chain 247; B = 8: 266 vs 258
-    for (int k = std::min(cap, B >= 4 ? 2 : B); k > 1; --k) if (B % k == 0) return k;
+    for (int k = std::min(cap, B >= 4 ? 2 : B); k > 1; --k) if (B % k == 0 && pays((long)P * (B / k), k)) return k;
     return 1;
   }
   // batch-slot offset of group g's phi maps (0 when one phi is shared by all slots)
@@ -1032,6 +1039,8 @@ struct Flow {
   // +1.5 %, 480 x 640 (307 k) -3...-8 %, 640^2 -12 %, 720^2 -12 %; T+QU (three chains) 360^2 +7 %, 384^2 +9 %, 480 x 640 (307 k) +9.5 %, 640^2
   // (410 k) -7 %; QU at B = 8 (four chains of four slices) 192^2 (147 k per chain) +68 %, 360^2 (518 k) -15 %, 480^2 -9 %; double precision 480^2
   // -1.5 %, 640^2 -21 %.  (Round 5's rule -- pixels of ONE slice, x 4 from three slices on -- switched the chains on for T+QU from 131 k pixels.)
+  // (One rule for all flows: chains in the delta flows alone -- their launches are longer -- make (grad L)' faster from 200 k pixels per chain, 480^2 QU
+  //  -2.4 %, 480 x 640 T+QU -9 %, but the grad lnP around it SLOWER, +3.4 % / +7 %: profiles/r06_ab_anysize_streams_retuned.txt, last block.)
   int gen_groups(long slices) const {
     if (!c->opts.gen_slice_streams || !gen_sep()) return 1;
     for (int k = (int)std::min<long>(std::min(max_groups, c->opts.slice_streams), slices); k > 1; --k) {
@@ -1403,7 +1412,7 @@ struct Flow {
     cx<T>* a_cur = Ab.template as<cx<T>>(); cx<T>* a_nxt = A2.as<cx<T>>();
     if (!a_ready) c->y_r2c(f, a_cur, slices);
     if (!h_ready) c->template x_pass<1>(df, H.as<cx<T>>(), slices);
-    const int K = groups(P, B);
+    const int K = groups(P, B, true);
     const long gs = slices / K;
     const auto tile = c->tileY_delta(slices);
     const double t0 = forward_primal ? 1.0 : 0.0, h = (forward_primal ? -1.0 : 1.0) / n;

@@ -78,7 +78,7 @@ int cmbl_ctx_geometry_host(cmbl_ctx* ctx, int which, double* out_host, size_t n)
 /* ---- behaviour switches of a context (A/B and profiling aids; none changes results beyond rounding).  Each starts from the
  *      environment variable named below, read ONCE when the context is created, and afterwards changes only through this call:
  *        "slice_streams"         CMBL_SLICE_STREAMS (4)            launch chains per flow: pol slices / batch-slot groups on their own streams; 1 = one launch over all slices
- *        "slice_streams_min_pix" CMBL_SLICE_STREAMS_MIN_PIX (2^20) smallest map that is split
+ *        "slice_streams_min_pix" CMBL_SLICE_STREAMS_MIN_PIX (2^19) pixels a launch chain of a delta flow must carry (all its slices together); map and adjoint flows, and three or more chains: twice that
  *        "pcache"                !CMBL_NO_PCACHE (1)               cache p(t_k) at the 2n+1 stage times per phi (src/lenseflow.jl:45-46,131-142); read by cmbl_lenseflow_set_phi
  *        "pcache_max_mb"         CMBL_PCACHE_MAX_MB (16384)
  *        "fused_harm"            !CMBL_NO_FUSED_HARM (1)           harmonic-space operator chains inside one row pass
