@@ -32,7 +32,8 @@ static int guard(F&& f) {
 #ifdef CMBL_STAMPS
 namespace cmbl {
 #define CMBL_X(unit) int stamps_read_##unit(unsigned long long* out_host, int n);
-CMBL_X(main_f32) CMBL_X(main_f64) CMBL_X(gen_f32) CMBL_X(gen_f64) CMBL_X(genx_f32) CMBL_X(genx_f64) CMBL_X(small_f32) CMBL_X(small_f64)
+CMBL_X(main_f32) CMBL_X(main_f64) CMBL_X(gen_f32) CMBL_X(gen_f64) CMBL_X(small_f32) CMBL_X(small_f64) CMBL_X(cty_f32_a) CMBL_X(cty_f32_b) CMBL_X(cty_f64_a) CMBL_X(cty_f64_b) \
+    CMBL_X(ctx_f32_a) CMBL_X(ctx_f32_b) CMBL_X(ctx_f64_a) CMBL_X(ctx_f64_b)
 #undef CMBL_X
 }
 #endif
@@ -377,9 +378,10 @@ int cmbl_debug_stamps(unsigned long long* out_host, int n) {
     const std::string u = e ? e : "main_f32";
     int rc = -1;
 #define CMBL_X(unit) if (u == #unit) rc = cmbl::stamps_read_##unit(out_host, n);
-    CMBL_X(main_f32) CMBL_X(main_f64) CMBL_X(gen_f32) CMBL_X(gen_f64) CMBL_X(genx_f32) CMBL_X(genx_f64) CMBL_X(small_f32) CMBL_X(small_f64)
+    CMBL_X(main_f32) CMBL_X(main_f64) CMBL_X(gen_f32) CMBL_X(gen_f64) CMBL_X(small_f32) CMBL_X(small_f64) CMBL_X(cty_f32_a) CMBL_X(cty_f32_b) CMBL_X(cty_f64_a) CMBL_X(cty_f64_b) \
+    CMBL_X(ctx_f32_a) CMBL_X(ctx_f32_b) CMBL_X(ctx_f64_a) CMBL_X(ctx_f64_b)
 #undef CMBL_X
-    CMBL_REQUIRE(rc == 0, ERR_ARG, "CMBL_STAMPS_TU: main_f32 | main_f64 | gen_f32 | gen_f64 | genx_f32 | genx_f64 | small_f32 | small_f64");
+    CMBL_REQUIRE(rc == 0, ERR_ARG, "CMBL_STAMPS_TU: main_{f32,f64} | gen_{f32,f64} | small_{f32,f64} | cty_{f32,f64}_{a,b} | ctx_{f32,f64}_{a,b}");
   });
 }
 #endif

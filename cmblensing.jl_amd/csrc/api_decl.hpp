@@ -2,8 +2,10 @@
 // bodies behind the entry points.  The build is split by explicit instantiation (lib.py builds the objects in parallel):
 //   api.hip                 extern "C" entry points, argument checks, error plumbing -- instantiates NO kernel
 //   tu_main_{f32,f64}.hip   every do_*<T> below (api_body.hpp) and with them Ctx<T>, Flow<T>, Dataset<T>, Drivers<T> and their kernels
-//   tu_gen_{f32,f64}.hip    the any-size transform launches (engine_gen.hpp: k_ct_dft*, k_ct_*_y, k_gen_dft*)
-//   tu_genx_{f32,f64}.hip   ... and their x-side stage launches (k_ct_dft2, k_ct_adj_x, k_ct_adj_x_dx)
+//   tu_gen_{f32,f64}.hip    the host side of the any-size transform launches (engine_gen.hpp) and the run-time-plan kernels k_gen_dft*
+//   tu_cty_{f32,f64}_{a,b}.hip   the compile-time-plan kernels of the column side and the plain transforms (engine_ct.hpp CtLaunchY: k_ct_dft,
+//                           k_ct_dftx, k_ct_flow_y, k_ct_delta_y, k_ct_adj_y), lengths of CMBL_CT_LIST_A / _B (kernels_ct.hpp)
+//   tu_ctx_{f32,f64}_{a,b}.hip   ... and of the row side of the fused stages (CtLaunchX: k_ct_adj_x, k_ct_adj_x_dx, k_ct_dft2)
 //   tu_small_{f32,f64}.hip  the one-launch flows of small maps (engine_small.hpp: k_small_flow, k_small_adj)
 // Rule that keeps api.hip free of kernels: it must not ODR-use a member function that launches (members defined in class are inline, and
 // an explicit instantiation DECLARATION does not stop inline functions from being instantiated -- [temp.explicit]/10); it calls do_*<T>

@@ -174,6 +174,23 @@ struct CtxBase {
   long npix() const { return (long)Ny * Nx; }
 };
 
+// The launches of the compile-time-plan kernels (kernels_ct.hpp) of ONE length N: declared here, defined in engine_ct.hpp and instantiated per
+// length by tu_cty_* (column side + the plain transforms) and tu_ctx_* (row side of the fused stages), so that no other translation unit
+// compiles those kernels and the build splits the list of lengths over several units.  Sx / S: wavefronts per workgroup of the launch.
+template <typename T> struct Ctx;
+template <typename T, int N> struct CtLaunchY {
+  static void dftx(Ctx<T>* c, const GenDft<T>& a, dim3 grid, int Sx, int kind);
+  static void dft(Ctx<T>* c, const GenDft<T>& a, dim3 grid, int kind);
+  static void flow_y(Ctx<T>* c, const GenDft<T>& a, dim3 grid);
+  static bool delta_y(Ctx<T>* c, const GenDft<T>& a, dim3 grid);       // false: two LDS row sets of this length do not fit
+  static void adj_y(Ctx<T>* c, const GenDft<T>& a, dim3 grid);
+};
+template <typename T, int N> struct CtLaunchX {
+  static void adj_x(Ctx<T>* c, const GenDft<T>& a, dim3 grid, int Sx);
+  static void adj_x_dx(Ctx<T>* c, const GenDft<T>& a, dim3 grid, int Sx, int ws, const GenDft<T>& a1);
+  static void dft2(Ctx<T>* c, const GenDft<T>& a0, int kind0, dim3 grid, int Sx, int ws, const GenDft<T>& a1, int kind1);
+};
+
 template <typename T>
 struct Ctx : CtxBase {
   DevBuf twY, twX, lx_r, ly, lam, cos2F, sin2F, red_part, red_out;

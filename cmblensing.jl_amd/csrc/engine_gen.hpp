@@ -1,6 +1,6 @@
-// The any-size transform LAUNCHES of Ctx<T> (declared in engine.hpp): the members that reference k_ct_* / k_gen_dft* -- half of the
-// library's device code.  Defined out of class (hence not inline) and instantiated explicitly by tu_gen_{f32,f64}.hip, so that no other
-// translation unit compiles those kernels (api_decl.hpp has the map of the build).
+// The any-size transform LAUNCHES of Ctx<T> (declared in engine.hpp): the members that set up a GenDft argument block and launch k_gen_dft* or, by
+// length, the compile-time-plan kernels through CtLaunchY / CtLaunchX (engine_ct.hpp).  Defined out of class (hence not inline) and instantiated
+// explicitly by tu_gen_{f32,f64}.hip, so that no other translation unit compiles the run-time-plan kernels (api_decl.hpp has the map of the build).
 #pragma once
 #include "engine.hpp"
 
@@ -20,18 +20,14 @@ bool Ctx<T>::gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
     a.S = Sx;
     const dim3 gx((unsigned)xgroups((a.nseq + Sx - 1) / Sx, a.in_tiled || a.out_tiled), (unsigned)slices);
     switch (ax.N) {
-#define CMBL_X(n) case n: \
-        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>()>), gx, ct_lds<T>(n), stream, a, kind); \
-        else if (Sx == ct_S<T>() / 2) CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>() / 2>), gx, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a, kind); \
-        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 16 * ct_S<T>(), (k_ct_dftx<T, n, ct_S<T>() / 4>), gx, (ct_lds<T>(n, 1, ct_S<T>() / 4)), stream, a, kind); \
-        return true;
+#define CMBL_X(n) case n: CtLaunchY<T, n>::dftx(this, a, gx, Sx, kind); return true;
       CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
       default: return false;
     }
   }
   switch (ax.N) {
-#define CMBL_X(n) case n: CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft<T, n>), grid, ct_lds<T>(n), stream, a, kind); return true;
+#define CMBL_X(n) case n: CtLaunchY<T, n>::dft(this, a, grid, kind); return true;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: return false;
@@ -88,10 +84,7 @@ void Ctx<T>::gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, 
   a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S<T>());
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   switch (Ny) {
-#define CMBL_X(n) case n: \
-      if (a.S == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_flow_y<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
-      else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_flow_y<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
-      return;
+#define CMBL_X(n) case n: CtLaunchY<T, n>::flow_y(this, a, grid); return;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
@@ -111,10 +104,7 @@ void Ctx<T>::gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<
   a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S2<T>(Ny));
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   switch (Ny) {
-#define CMBL_X(n) case n: if constexpr (ct_lds<T>(n, 2, ct_S2<T>(n)) <= 160 * 1024) { \
-      if (a.S == ct_S2<T>(n)) CMBL_LAUNCH_NT(this, K_GEN_DFT, 128 * ct_S2<T>(n), (k_ct_delta_y<T, n, ct_S2<T>(n)>), grid, ct_lds<T>(n, 2, ct_S2<T>(n)), stream, a); \
-      else if constexpr (ct_S2<T>(n) == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_delta_y<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 2, ct_S<T>() / 2)), stream, a); \
-      return; } break;
+#define CMBL_X(n) case n: if (CtLaunchY<T, n>::delta_y(this, a, grid)) return; break;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: break;
@@ -137,10 +127,7 @@ bool Ctx<T>::gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<
   const int R = Sx / 2;
   const dim3 grid((unsigned)xgroups((a.nseq + R - 1) / R, a.in_tiled != 0), (unsigned)slices);
   switch (Nx) {
-#define CMBL_X(n) case n: \
-      if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
-      else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
-      return true;
+#define CMBL_X(n) case n: CtLaunchX<T, n>::adj_x(this, a, grid, Sx); return true;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: return false;
@@ -175,15 +162,7 @@ void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>
   const int R = Sx / 2;
   const dim3 grid((unsigned)xgroups((a.nseq + R - 1) / R, a.in_tiled != 0), (unsigned)((A_next ? 2 : 1) * ws));
   switch (Nx) {
-#define CMBL_X(n) case n: \
-      if (A_next) { \
-        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x_dx<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a, (int)ws, a1); \
-        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_adj_x_dx<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a, (int)ws, a1); \
-      } else { \
-        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
-        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_adj_x<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
-      } \
-      return;
+#define CMBL_X(n) case n: if (A_next) CtLaunchX<T, n>::adj_x_dx(this, a, grid, Sx, (int)ws, a1); else CtLaunchX<T, n>::adj_x(this, a, grid, Sx); return;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: fail(ERR_STATE, "merged x passes need a compile-time plan for Nx");
@@ -206,10 +185,7 @@ void Ctx<T>::gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<
     a0.S = a1.S = Sx;
     const dim3 grid((unsigned)xgroups((a0.nseq + a0.S - 1) / a0.S, a0.out_tiled != 0), (unsigned)(2 * ws));
     switch (Nx) {
-#define CMBL_X(n) case n: \
-        if (Sx == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_dft2<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a0, ct_kind(a0), (int)ws, a1, ct_kind(a1)); \
-        else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_dft2<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a0, ct_kind(a0), (int)ws, a1, ct_kind(a1)); \
-        return;
+#define CMBL_X(n) case n: CtLaunchX<T, n>::dft2(this, a0, ct_kind(a0), grid, Sx, (int)ws, a1, ct_kind(a1)); return;
       CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
       default: break;
@@ -231,10 +207,7 @@ void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, 
   a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S<T>());
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   switch (Ny) {
-#define CMBL_X(n) case n: \
-      if (a.S == ct_S<T>()) CMBL_LAUNCH_NT(this, K_GEN_DFT, 64 * ct_S<T>(), (k_ct_adj_y<T, n, ct_S<T>()>), grid, ct_lds<T>(n), stream, a); \
-      else CMBL_LAUNCH_NT(this, K_GEN_DFT, 32 * ct_S<T>(), (k_ct_adj_y<T, n, ct_S<T>() / 2>), grid, (ct_lds<T>(n, 1, ct_S<T>() / 2)), stream, a); \
-      return;
+#define CMBL_X(n) case n: CtLaunchY<T, n>::adj_y(this, a, grid); return;
     CMBL_CT_LIST(CMBL_X)
 #undef CMBL_X
     default: fail(ERR_STATE, "fused y passes need a compile-time plan for Ny");
@@ -247,7 +220,7 @@ void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, 
   template void Ctx<T>::gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, bool last, long slices); \
   template void Ctx<T>::gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<T>* G2, const T* lmul2, T s1, T s2, const GenPro<T>& pro, cx<T>* Anext, cx<T>* W2a, cx<T>* W2b, bool last, long slices); \
   template void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, int P, cx<T>* W2a, cx<T>* W2b, long slices);
-// (the x-side launches are compiled by a translation unit of their own, tu_genx_*.hip: the build is as long as its longest unit)
+// (the x-side launches: instantiated by the same units since the kernels moved behind CtLaunchX, engine_ct.hpp)
 #define CMBL_INSTANTIATE_GENX(T) \
   template bool Ctx<T>::gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices); \
   template void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, const RKCoef<T>& rk, cx<T>* t3, const cx<T>* A_next, cx<T>* gx, long slices); \

@@ -20,9 +20,16 @@
 #pragma once
 #include "kernels_generic.hpp"
 
-#ifndef CMBL_CT_LIST
-#define CMBL_CT_LIST(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(640) X(720) X(768) X(960) X(1000) X(1280) X(1536) X(1920)
+// (two halves: the launches of a length are compiled by the translation units tu_cty*_{a,b} / tu_ctx*_{a,b} -- engine_ct.hpp -- so that the build is as
+//  long as half of the list; 1152 = 9 * 2^7 since late round 6.  2304 and 3072 compile without spills, but 8 rows of them exceed the LDS: they
+//  need the half-size groups in every launch, k_ct_dft included -- not done)
+#ifndef CMBL_CT_LIST_A
+#define CMBL_CT_LIST_A(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(640) X(720) X(768) X(960) X(1000)
 #endif
+#ifndef CMBL_CT_LIST_B
+#define CMBL_CT_LIST_B(X) X(1152) X(1280) X(1536) X(1920)
+#endif
+#define CMBL_CT_LIST(X) CMBL_CT_LIST_A(X) CMBL_CT_LIST_B(X)
 
 namespace cmbl {
 

@@ -31,7 +31,7 @@ __host__ __device__ constexpr int ilog2c(int n) { int l = 0; while ((1 << l) < n
 
 // debug builds (-DCMBL_STAMPS): per-workgroup phase timestamps, read back with cmbl_debug_stamps (tools/gpu_stamps.py)
 // (the buffer is per translation unit -- device symbols are not shared without relocatable device code -- so each unit exports a reader,
-//  CMBL_STAMPS_READER below, and cmbl_debug_stamps picks the unit: CMBL_STAMPS_TU = main_f32 (default) | main_f64 | gen_f32 | genx_f32 | ...)
+//  CMBL_STAMPS_READER below, and cmbl_debug_stamps picks the unit: CMBL_STAMPS_TU = main_f32 (default) | main_f64 | gen_f32 | cty_f32_a | ctx_f32_b | ...)
 #ifdef CMBL_STAMPS
 __device__ unsigned long long g_stamps[8192 * 16];
 #define CMBL_STAMPS_READER(unit) namespace cmbl { int stamps_read_##unit(unsigned long long* out_host, int n) { \

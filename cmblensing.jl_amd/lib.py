@@ -2,6 +2,7 @@
 import ctypes
 import os
 import subprocess
+import time
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -34,16 +35,18 @@ def library_path():
 
 
 # translation units of the library (csrc/api_decl.hpp has the map): the entry points, and per precision the typed bodies with the
-# power-of-two kernels and the any-size transform launches.  Built in parallel, one object each, then linked.
-UNITS = ["tu_gen_f32", "tu_gen_f64", "tu_genx_f32", "tu_genx_f64", "tu_main_f32", "tu_main_f64", "tu_small_f32", "tu_small_f64", "api"]
+# power-of-two kernels, the any-size transform launches and (tu_cty / tu_ctx, two halves of the list of lengths) their compile-time-plan kernels.
+# One object each, then linked.
+# (longest first: the build is a pool of as many compilers as the host has cores)
+UNITS = ["tu_cty_f32_b", "tu_cty_f64_b", "tu_ctx_f32_b", "tu_ctx_f64_b", "tu_cty_f32_a", "tu_cty_f64_a", "tu_main_f32", "tu_main_f64",
+         "tu_ctx_f32_a", "tu_ctx_f64_a", "tu_small_f32", "tu_small_f64", "tu_gen_f32", "tu_gen_f64", "api"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def build(force=False, verbose=False, jobs=None, extra_flags=(), out=None, objdir=None):
     """hipcc cross-compiles for gfx950 without a GPU.  In-tree output: cmblensing.jl_amd/libcmblens_hip.so
 
-    One object per translation unit under build/obj (git-ignored), compiled `jobs` at a time (default: all of them, they are fewer than the
-    cores of any box this runs on), re-compiled only when a source it includes (-MMD dependency file) or the flags changed.  `extra_flags`
+    One object per translation unit under build/obj (git-ignored), compiled `jobs` at a time (default: one per core, the longest units first), re-compiled only when a source it includes (-MMD dependency file) or the flags changed.  `extra_flags`
     / `out` / `objdir`: variant builds of the same sources (tools/devbuild.py)."""
     csrc = os.path.join(_HERE, "csrc")
     out = out or library_path()
@@ -63,22 +66,22 @@ def build(force=False, verbose=False, jobs=None, extra_flags=(), out=None, objdi
 
     todo = [u for u in UNITS if stale(u)]
     procs, failed = [], []
-    jobs = jobs or int(os.environ.get("CMBL_BUILD_JOBS", "0")) or len(UNITS)
+    jobs = jobs or int(os.environ.get("CMBL_BUILD_JOBS", "0")) or min(len(UNITS), os.cpu_count() or 8)
 
     def reap(block):
-        for item in list(procs):
-            unit, p, log = item
-            if block or p.poll() is not None:
-                rc = p.wait()
+        """collect the compilers that have finished; block: wait until at least one has"""
+        while True:
+            done = [item for item in procs if item[1].poll() is not None]
+            for unit, p, log in done:
                 log.close()
-                procs.remove(item)
-                if rc != 0:
+                procs.remove((unit, p, log))
+                if p.returncode != 0:
                     failed.append(unit)
                 else:
                     open(os.path.join(objdir, unit + ".flags"), "w").write(stamp)
-                if not block:
-                    continue
+            if done or not block or not procs:
                 return
+            time.sleep(0.2)
 
     for unit in todo:
         while len(procs) >= jobs:

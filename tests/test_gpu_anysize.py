@@ -67,9 +67,10 @@ TOL32_PATCH = dict(fft=1.5e-6, flow=6e-5, adj=3.6e-4, grad=1.2e-3, cg=1e-3)
 
 # (double precision: the 1536- and 768-point plans on the column / row side of thin patches -- the float64 oracle of a 1536 x 768 patch took 80 s of
 #  the GPU suite's 500; the full-size double-precision flows are tests/test_gpu_headline_parity.py's)
-@pytest.mark.parametrize("prec,Ny,Nx,P", [("f32", 768, 768, 2), ("f64", 1536, 192, 2), ("f64", 192, 768, 2), ("f32", 640, 1280, 1), ("f32", 1000, 1000, 2)])
+@pytest.mark.parametrize("prec,Ny,Nx,P", [("f32", 768, 768, 2), ("f64", 1536, 192, 2), ("f64", 192, 768, 2), ("f32", 640, 1280, 1), ("f32", 1000, 1000, 2),
+                                            ("f32", 1152, 192, 2), ("f64", 192, 1152, 1)])
 def test_compile_time_plans_flows_and_gradient(camb, prec, Ny, Nx, P, monkeypatch):
-    """the lengths with compile-time plans (csrc/kernels_ct.hpp: 3 * 2^k, 5 * 2^k, 1000 = 8 * 5^3) at survey patch sizes, radix-16 stages
+    """the lengths with compile-time plans (csrc/kernels_ct.hpp: 3 * 2^k, 5 * 2^k, 9 * 2^7 = 1152, 1000 = 8 * 5^3) at survey patch sizes, radix-16 stages
     included: flows, adjoints and the delta-flow gradient against the oracle"""
     monkeypatch.setitem(TP.TOL, "f32", TOL32_PATCH)
     TP.test_lenseflow_ops(camb, prec, Ny, Nx, P, 1, 1, 7)
@@ -82,7 +83,7 @@ def test_compile_time_plans_posterior_gradient_768():
     TP.test_logpdf_mixed_and_gradient("f32", "P", (768, 768), scale32=10.0)
 
 
-CT_LIST = (96, 160, 192, 320, 360, 384, 480, 640, 720, 768, 960, 1000, 1280, 1536, 1920)     # CMBL_CT_LIST of csrc/kernels_ct.hpp
+CT_LIST = (96, 160, 192, 320, 360, 384, 480, 640, 720, 768, 960, 1000, 1152, 1280, 1536, 1920)     # CMBL_CT_LIST of csrc/kernels_ct.hpp
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -230,7 +231,7 @@ def test_anysize_row_group_height_changes_no_result(camb, prec, Ny, Nx, P):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("Ny,Nx,P,B", [(96, 160, 2, 1), (160, 96, 2, 3), (384, 192, 1, 1), (360, 320, 3, 2), (480, 720, 2, 1), (720, 960, 1, 1), (1280, 96, 2, 1), (96, 1536, 2, 1)])
+@pytest.mark.parametrize("Ny,Nx,P,B", [(96, 160, 2, 1), (160, 96, 2, 3), (384, 192, 1, 1), (360, 320, 3, 2), (480, 720, 2, 1), (720, 960, 1, 1), (1280, 96, 2, 1), (96, 1536, 2, 1), (1152, 192, 2, 1), (192, 1152, 2, 1)])
 def test_anysize_tiled_hand_off_changes_no_result(camb, prec, Ny, Nx, P, B):
     """the half planes the fused any-size stages hand between their column and row launches are tiled ([x / 4][ky][x % 4], option gen_tiled,
     GenDft::in_tiled) instead of [ky][x]: a layout of scratch arrays only -- every sequence goes through the same wavefront arithmetic, bit for

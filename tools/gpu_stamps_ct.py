@@ -1,5 +1,5 @@
 """Phase timestamps inside k_ct_dft (debug build: tools/devbuild.sh stampsct -DCMBL_STAMPS -DCMBL_STAMPS_ROWS -DCMBL_STAMPS_CT):
-   CMBL_CT_STAMP_KIND=<kind, +8 for the d/dx pass> CMBL_STAMPS_TU=gen_f32 [OP=Lf] [NB=blocks] CMBL_LIB=cmblensing.jl_amd/_dev/lib_stampsct.so python tools/gpu_stamps_ct.py [N]
+   CMBL_CT_STAMP_KIND=<kind, +8 for the d/dx pass> CMBL_STAMPS_TU=cty_f32_a [OP=Lf] [NB=blocks] CMBL_LIB=cmblensing.jl_amd/_dev/lib_stampsct.so python tools/gpu_stamps_ct.py [N]
 kinds: 0 complex, 1 real, 2 real pair, 3 c2r, 4 pair c2r, 5 / 6 / 7 real with the stage's pointwise work in the fetch"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
