@@ -423,7 +423,7 @@ struct Ctx : CtxBase {
   bool gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices);   // defined in engine_gen.hpp (tu_gen_*.hip)
   // the x axis has a compile-time plan: the row update of an adjoint-type stage can open the next stage in the same launch (gen_x_adj_next)
   bool gen_ct_x() const {
-    if (!opts.gen_ct || !opts.gen_yy || !opts.gen_xmerge || genX.plan.nf == 0) return false;
+    if (!opts.gen_ct || !opts.gen_yy || !opts.gen_xmerge || genX.plan.nf == 0 || !ct_rowfuse_ok<T>(Nx)) return false;
     switch (Nx) {
 #define CMBL_X(n) case n: return true;
       CMBL_CT_LIST(CMBL_X)

@@ -8,7 +8,7 @@ namespace cmbl {
 
 template <typename T>
 bool Ctx<T>::gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
-  a.N = ax.N; a.tw = ax.twN.template as<cx<T>>(); a.S = ct_S<T>();
+  a.N = ax.N; a.tw = ax.twN.template as<cx<T>>(); a.S = ct_Smax<T>(ax.N);   // (the groups of k_ct_dft: as many sequences as fit the LDS)
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   int kind = ct_kind(a);
 #ifdef CMBL_STAMPS_CT
@@ -16,7 +16,7 @@ bool Ctx<T>::gen_dft_ct(const GenAxis& ax, GenDft<T> a, long slices) {
   if (kind + (a.lmul_mid ? 8 : 0) == stamp_kind) kind |= 256;
 #endif
   if ((kind & 255) == CT_C && a.in_elem == 1 && a.out_elem == 1) {                 // contiguous rows: groups of 8 / 4 / 2 (ct_rows_per_group)
-    const int Sx = ct_rows_per_group((long)a.nseq * slices, 1);
+    const int Sx = std::min(ct_rows_per_group((long)a.nseq * slices, 1), ct_Smax<T>(ax.N));
     a.S = Sx;
     const dim3 gx((unsigned)xgroups((a.nseq + Sx - 1) / Sx, a.in_tiled || a.out_tiled), (unsigned)slices);
     switch (ax.N) {
@@ -81,7 +81,7 @@ void Ctx<T>::gen_y_flow_stage(const cx<T>* G1, const cx<T>* G2, const T* lmul2, 
   a.yy = 1; a.yy_last = last ? 1 : 0; a.yy_nout = Nyh; a.yy_out = Anext;
   hand_in<1>(a);
   slices = gen_window(a, slices);
-  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S<T>());
+  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = std::min(ct_cols_per_group((long)a.nseq, slices, ct_S<T>()), ct_Smax<T>(Ny));
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   switch (Ny) {
 #define CMBL_X(n) case n: CtLaunchY<T, n>::flow_y(this, a, grid); return;
@@ -114,7 +114,7 @@ void Ctx<T>::gen_y_delta_stage(const cx<T>* T3, T s3, const cx<T>* G1, const cx<
 
 template <typename T>
 bool Ctx<T>::gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>* acc_, cx<T>* Ys, const RKCoef<T>& rk, long slices) {
-  if (!opts.gen_ct || !opts.gen_yy || genX.plan.nf == 0) return false;
+  if (!opts.gen_ct || !opts.gen_yy || genX.plan.nf == 0 || !ct_rowfuse_ok<T>(Nx)) return false;
   GenDft<T> a{};
   a.in = W2a; a.in2 = W2b; a.nin = Nx; a.nout = Nx; a.nseq = Nyh; a.scale = 1;
   a.in_seq = Nx; a.in_elem = 1; a.in_slice = plane(); a.out_seq = Nx; a.out_elem = 1; a.out_slice = plane();
@@ -122,7 +122,7 @@ bool Ctx<T>::gen_x_adj_update(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<
   hand_in<2>(a);
   slices = gen_window(a, slices);
   a.N = Nx; a.tw = genX.twN.template as<cx<T>>();
-  const int Sx = std::max(ct_S<T>() / 2, ct_rows_per_group((long)a.nseq * slices, 2));   // S wavefronts = S / 2 rows x the two members of the pair
+  const int Sx = std::min(std::max(ct_S<T>() / 2, ct_rows_per_group((long)a.nseq * slices, 2)), ct_Smax<T>(Nx));   // S wavefronts = S / 2 rows x the two members of the pair
   a.S = Sx;
   const int R = Sx / 2;
   const dim3 grid((unsigned)xgroups((a.nseq + R - 1) / R, a.in_tiled != 0), (unsigned)slices);
@@ -157,7 +157,7 @@ void Ctx<T>::gen_x_adj_next(const cx<T>* W2a, const cx<T>* W2b, cx<T>* Y0, cx<T>
   // group height: the row-update part has Nyh / (S / 2) workgroups per slice, the d/dx part Nyh / S
   // (half-height groups while the launch has fewer than 1.5 full-height groups per CU: measured at 768^2 / 1000^2 QU -3.5 %, 768^2 T+QU +1.4 %,
   //  profiles/r06_ab_anysize_xmerge.txt)
-  const int Sx = (opts.gen_ct_rows && ((A_next ? 3L : 2L) * a.nseq * ws + ct_S<T>() - 1) / ct_S<T>() < 3L * num_cus / 2) ? ct_S<T>() / 2 : ct_S<T>();
+  const int Sx = std::min((opts.gen_ct_rows && ((A_next ? 3L : 2L) * a.nseq * ws + ct_S<T>() - 1) / ct_S<T>() < 3L * num_cus / 2) ? ct_S<T>() / 2 : ct_S<T>(), ct_Smax<T>(Nx));
   a.S = a1.S = Sx;
   const int R = Sx / 2;
   const dim3 grid((unsigned)xgroups((a.nseq + R - 1) / R, a.in_tiled != 0), (unsigned)((A_next ? 2 : 1) * ws));
@@ -181,7 +181,7 @@ void Ctx<T>::gen_x_inv_and_deriv(const cx<T>* F, cx<T>* t3, const cx<T>* A_, cx<
     const long ws = gen_window(a0, slices);
     (void)gen_window(a1, slices);
     a0.N = a1.N = Nx; a0.tw = a1.tw = genX.twN.template as<cx<T>>();
-    const int Sx = std::max(ct_S<T>() / 2, ct_rows_per_group(2L * a0.nseq * ws, 1));
+    const int Sx = std::min(std::max(ct_S<T>() / 2, ct_rows_per_group(2L * a0.nseq * ws, 1)), ct_Smax<T>(Nx));
     a0.S = a1.S = Sx;
     const dim3 grid((unsigned)xgroups((a0.nseq + a0.S - 1) / a0.S, a0.out_tiled != 0), (unsigned)(2 * ws));
     switch (Nx) {
@@ -204,7 +204,7 @@ void Ctx<T>::gen_y_adj_stage(const cx<T>* T3, T s3, const PhiMaps<T>& phm, T t, 
   a.yy = 3; a.yy_nout = Nyh; a.yy_out2 = W2a; a.yy_out3 = W2b;
   hand_in<1>(a);
   slices = gen_window(a, slices);
-  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = ct_cols_per_group((long)a.nseq, slices, ct_S<T>());
+  a.N = Ny; a.tw = genY.twN.template as<cx<T>>(); a.S = std::min(ct_cols_per_group((long)a.nseq, slices, ct_S<T>()), ct_Smax<T>(Ny));
   const dim3 grid((unsigned)((a.nseq + a.S - 1) / a.S), (unsigned)slices);
   switch (Ny) {
 #define CMBL_X(n) case n: CtLaunchY<T, n>::adj_y(this, a, grid); return;

@@ -21,13 +21,13 @@
 #include "kernels_generic.hpp"
 
 // (two halves: the launches of a length are compiled by the translation units tu_cty*_{a,b} / tu_ctx*_{a,b} -- engine_ct.hpp -- so that the build is as
-//  long as half of the list; 1152 = 9 * 2^7 since late round 6.  2304 and 3072 compile without spills, but 8 rows of them exceed the LDS: they
-//  need the half-size groups in every launch, k_ct_dft included -- not done)
+//  long as half of the list; 1152 = 9 * 2^7, 2304 = 9 * 2^8 and 3072 = 3 * 2^10 since late round 6 -- the last two in half-size groups, ct_Smax: 8
+//  rows of them exceed the LDS; their delta stages run unfused: two row sets do not fit either)
 #ifndef CMBL_CT_LIST_A
 #define CMBL_CT_LIST_A(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(640) X(720) X(768) X(960) X(1000)
 #endif
 #ifndef CMBL_CT_LIST_B
-#define CMBL_CT_LIST_B(X) X(1152) X(1280) X(1536) X(1920)
+#define CMBL_CT_LIST_B(X) X(1152) X(1280) X(1536) X(1920) X(2304) X(3072)
 #endif
 #define CMBL_CT_LIST(X) CMBL_CT_LIST_A(X) CMBL_CT_LIST_B(X)
 
@@ -44,6 +44,11 @@ constexpr int ct_ns(int N, int i) { int ns = 1; for (int k = 0; k < i; ++k) ns *
 constexpr int ct_ld(int N) { return pad(N) + ((8 - pad(N) % 32) + 32) % 32; }                        // row stride, 8 (mod 32) slots
 template <typename T> constexpr int ct_S() { return 64 / (int)sizeof(cx<T>); }                       // sequences (= wavefronts) per workgroup
 template <typename T> constexpr size_t ct_lds(int N, int rowsets = 1, int S = ct_S<T>()) { return ((size_t)(N / 2) + (size_t)rowsets * S * ct_ld(N)) * sizeof(cx<T>); }
+// the most sequences per workgroup whose rows fit the LDS: ct_S up to 1920 points; 2304 and 3072 take half groups in every launch
+template <typename T> constexpr int ct_Smax(int N) { return ct_lds<T>(N) <= 160 * 1024 ? ct_S<T>() : ct_S<T>() / 2; }
+// the fused row update (k_ct_adj_x: a whole row AND its RK operands in registers) spills 600-800 bytes per lane in double precision beyond 1920 points:
+// those shapes run the x transform and the RK update as launches of their own (Ctx::gen_ct_x)
+template <typename T> constexpr bool ct_rowfuse_ok(int N) { return !(sizeof(T) == 8 && N > 1920); }
 // columns per workgroup of the delta-stage kernel (two LDS rows per column): the usual count, or half of it where that does not fit (Ny > ~1150;
 // the transposed side then moves 32-byte pieces)
 #ifndef CMBL_CT_S2_HALF
@@ -501,14 +506,14 @@ __device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsign
   twr.issue(a.tw);
   if constexpr (CONLY) ct_fetch<T, N, CT_C, false, S>(a, s, sl, seq0, in_by_seq);
   else switch (kind) {                                                   // uniform: one straight-line fetch per variant
-    case CT_C: ct_fetch<T, N, CT_C, false>(a, s, sl, seq0, in_by_seq); break;
-    case CT_R1: ct_fetch<T, N, CT_R1, false>(a, s, sl, seq0, in_by_seq); break;
-    case CT_R2: ct_fetch<T, N, CT_R2, false>(a, s, sl, seq0, in_by_seq); break;
-    case CT_H1: if (a.lmul_in) ct_fetch<T, N, CT_H1, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_H1, false>(a, s, sl, seq0, in_by_seq); break;
-    case CT_H2: if (a.lmul_in) ct_fetch<T, N, CT_H2, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_H2, false>(a, s, sl, seq0, in_by_seq); break;
-    case CT_P1: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P1, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P1, false>(a, s, sl, seq0, in_by_seq); break;
-    case CT_P2: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P2, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P2, false>(a, s, sl, seq0, in_by_seq); break;
-    default: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P3, true>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P3, false>(a, s, sl, seq0, in_by_seq); break;
+    case CT_C: ct_fetch<T, N, CT_C, false, S>(a, s, sl, seq0, in_by_seq); break;
+    case CT_R1: ct_fetch<T, N, CT_R1, false, S>(a, s, sl, seq0, in_by_seq); break;
+    case CT_R2: ct_fetch<T, N, CT_R2, false, S>(a, s, sl, seq0, in_by_seq); break;
+    case CT_H1: if (a.lmul_in) ct_fetch<T, N, CT_H1, true, S>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_H1, false, S>(a, s, sl, seq0, in_by_seq); break;
+    case CT_H2: if (a.lmul_in) ct_fetch<T, N, CT_H2, true, S>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_H2, false, S>(a, s, sl, seq0, in_by_seq); break;
+    case CT_P1: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P1, true, S>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P1, false, S>(a, s, sl, seq0, in_by_seq); break;
+    case CT_P2: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P2, true, S>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P2, false, S>(a, s, sl, seq0, in_by_seq); break;
+    default: if (a.pro.ph.pcx) ct_fetch<T, N, CT_P3, true, S>(a, s, sl, seq0, in_by_seq); else ct_fetch<T, N, CT_P3, false, S>(a, s, sl, seq0, in_by_seq); break;
   }
   twr.commit(tw);
   CMBL_CT_STAMP(1);
@@ -537,7 +542,7 @@ __device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsign
   CMBL_CT_STAMP(6); CMBL_CT_STAMP(15);
 }
 template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_S<T>(), (ct_min_waves_x<T, N, ct_S<T>()>())) void k_ct_dft(GenDft<T> a, int kind) { ct_dft_body<T, N>(a, kind, blockIdx.y); }
+__global__ __launch_bounds__(64 * ct_Smax<T>(N), (ct_min_waves_x<T, N, ct_Smax<T>(N)>())) void k_ct_dft(GenDft<T> a, int kind) { ct_dft_body<T, N, false, ct_Smax<T>(N)>(a, kind, blockIdx.y); }
 // Two independent transform launches of the same length as one (grid.y = ny0 + the second's): the two x passes that open a delta-flow
 // stage -- ifft_x(delta f) and the d/dx pass of rfft_y(f) -- have no dependence on each other.
 // S: sequences (= wavefronts) per workgroup.  The x passes read and write contiguous rows, so nothing ties them to the 64-byte pieces of the
