@@ -22,7 +22,7 @@
 
 // (two halves: the launches of a length are compiled by the translation units tu_cty*_{a,b} / tu_ctx*_{a,b} -- engine_ct.hpp -- so that the build is as
 //  long as half of the list; 1152 = 9 * 2^7, 2304 = 9 * 2^8 and 3072 = 3 * 2^10 since late round 6 -- the last two in half-size groups, ct_Smax: 8
-//  rows of them exceed the LDS; their delta stages run unfused: two row sets do not fit either)
+//  rows of them exceed the LDS; their delta stages run in quarter-width column groups, ct_S2)
 #ifndef CMBL_CT_LIST_A
 #define CMBL_CT_LIST_A(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(640) X(720) X(768) X(960) X(1000)
 #endif
@@ -54,7 +54,10 @@ template <typename T> constexpr bool ct_rowfuse_ok(int N) { return !(sizeof(T) =
 #ifndef CMBL_CT_S2_HALF
 #define CMBL_CT_S2_HALF 0      // 1: always half (A/B: shorter transform phases, 32-byte pieces on the transposed side)
 #endif
-template <typename T> constexpr int ct_S2(int N) { return (!CMBL_CT_S2_HALF && ct_lds<T>(N, 2) <= 160 * 1024) ? ct_S<T>() : ct_S<T>() / 2; }
+// (a quarter from 2304 points on: 2 columns in single, 1 in double precision)
+template <typename T> constexpr int ct_S2(int N) {
+  return (!CMBL_CT_S2_HALF && ct_lds<T>(N, 2) <= 160 * 1024) ? ct_S<T>() : ct_lds<T>(N, 2, ct_S<T>() / 2) <= 160 * 1024 ? ct_S<T>() / 2 : ct_S<T>() / 4;
+}
 
 // fetch variants
 enum { CT_C = 0, CT_R1, CT_R2, CT_H1, CT_H2, CT_P1, CT_P2, CT_P3 };

@@ -112,7 +112,7 @@ def test_every_compile_time_plan_against_numpy_and_the_run_time_plans(prec, N):
 def test_longest_compile_time_plan_in_the_flows(camb, prec, monkeypatch):
     """1920 points (30 elements per lane: chunked operand loads, one workgroup per CU) on the column side and on the row side of the fused any-size
     stage kernels: flows and the delta-flow gradient against the oracle at 1920 x 96 and 96 x 1920; and the two lengths that run in half-size groups
-    (their rows exceed the LDS eight at a time; delta stages unfused; no fused row update in double precision): 3072 x 96 and 96 x 2304"""
+    (their rows exceed the LDS eight at a time; delta stages in quarter-width column groups; no fused row update in double precision): 3072 x 96 and 96 x 2304"""
     monkeypatch.setitem(TP.TOL, "f32", TOL32_PATCH)
     C = _pkg()
     tT, nT = DT[prec]
