@@ -21,13 +21,13 @@
 #include "kernels_generic.hpp"
 
 // (two halves: the launches of a length are compiled by the translation units tu_cty*_{a,b} / tu_ctx*_{a,b} -- engine_ct.hpp -- so that the build is as
-//  long as half of the list; 1152 = 9 * 2^7, 2304 = 9 * 2^8 and 3072 = 3 * 2^10 since late round 6 -- the last two in half-size groups, ct_Smax: 8
+//  long as half of the list; 576 = 9 * 2^6, 1152, 2304, 2560 = 5 * 2^9 and 3072 = 3 * 2^10 since late round 6 -- the last three in half-size groups, ct_Smax: 8
 //  rows of them exceed the LDS; their delta stages run in quarter-width column groups, ct_S2)
 #ifndef CMBL_CT_LIST_A
-#define CMBL_CT_LIST_A(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(640) X(720) X(768) X(960) X(1000)
+#define CMBL_CT_LIST_A(X) X(96) X(160) X(192) X(320) X(360) X(384) X(480) X(576) X(640) X(720) X(768) X(960) X(1000)
 #endif
 #ifndef CMBL_CT_LIST_B
-#define CMBL_CT_LIST_B(X) X(1152) X(1280) X(1536) X(1920) X(2304) X(3072)
+#define CMBL_CT_LIST_B(X) X(1152) X(1280) X(1536) X(1920) X(2304) X(2560) X(3072)
 #endif
 #define CMBL_CT_LIST(X) CMBL_CT_LIST_A(X) CMBL_CT_LIST_B(X)
 
@@ -545,7 +545,8 @@ __device__ __forceinline__ void ct_dft_body(const GenDft<T>& a, int kind, unsign
   CMBL_CT_STAMP(6); CMBL_CT_STAMP(15);
 }
 template <typename T, int N>
-__global__ __launch_bounds__(64 * ct_Smax<T>(N), (ct_min_waves_x<T, N, ct_Smax<T>(N)>())) void k_ct_dft(GenDft<T> a, int kind) { ct_dft_body<T, N, false, ct_Smax<T>(N)>(a, kind, blockIdx.y); }
+// (the all-kinds kernel at 960 points, 15 elements per lane: 17 registers over the 128-register cap -- it takes the budget of the 1000-point kernels)
+__global__ __launch_bounds__(64 * ct_Smax<T>(N), (ct_min_waves_x<T, (N == 960 ? 1000 : N), ct_Smax<T>(N)>())) void k_ct_dft(GenDft<T> a, int kind) { ct_dft_body<T, N, false, ct_Smax<T>(N)>(a, kind, blockIdx.y); }
 // Two independent transform launches of the same length as one (grid.y = ny0 + the second's): the two x passes that open a delta-flow
 // stage -- ifft_x(delta f) and the d/dx pass of rfft_y(f) -- have no dependence on each other.
 // S: sequences (= wavefronts) per workgroup.  The x passes read and write contiguous rows, so nothing ties them to the 64-byte pieces of the
@@ -757,14 +758,20 @@ __device__ __forceinline__ void ct_adj_x_body(const GenDft<T>& a, unsigned ysl) 
   cx<T> v[E] = {}, y0v[EH] = {}, acv[EH] = {};
   {
     const cx<T>* src = reinterpret_cast<const cx<T>*>(m ? a.in2 : a.in) + sb;
-    if (a.in_tiled) {                                                    // tiled pair: the R wavefronts of the member walk (4 x, R rows) blocks of its R rows
-      const unsigned Fs = 4u * (unsigned)min(grp * R + trr, a.nseq - 1), stp = 64u * (unsigned)a.tile_np;   // element i of the thread: x = txb + 64 i
+    // ONE load statement for both layouts (the two as branches around the loop put the aggregate v[] into scratch memory in double precision):
+    // tiled pair: the R wavefronts of the member walk (4 x, R rows) blocks of its R rows, element i of the thread at x = txb + 64 i;
+    // [ky][x]: a wavefront walks its own row.  Offset = o0 + i * stp, only the last element can lie beyond the row (clamped)
+    const bool tl = a.in_tiled != 0;
+    const unsigned Fs = 4u * (unsigned)min(grp * R + trr, a.nseq - 1);
+    const unsigned o0 = tl ? Fs + tG : (unsigned)kyc * (unsigned)N + (unsigned)lane, stp = tl ? 64u * (unsigned)a.tile_np : 64u;
 #pragma unroll
-      for (int i = 0; i < E; ++i)
-        v[i] = at32(src, (N % 64 == 0 || i < E - 1) ? Fs + tG + (unsigned)i * stp : Fs + (unsigned)(min(txb + 64 * i, N - 1) >> 2) * 4u * (unsigned)a.tile_np + (unsigned)(lane & 3));
-    } else {
-#pragma unroll
-      for (int i = 0; i < E; ++i) v[i] = at32(src, (unsigned)kyc * (unsigned)N + (unsigned)min(lane + 64 * i, N - 1));
+    for (int i = 0; i < E; ++i) {
+      unsigned o = o0 + (unsigned)i * stp;
+      if (!(N % 64 == 0 || i < E - 1)) {
+        const unsigned xc = (unsigned)min((tl ? txb : lane) + 64 * i, N - 1);
+        o = tl ? Fs + (xc >> 2) * 4u * (unsigned)a.tile_np + (xc & 3u) : (unsigned)kyc * (unsigned)N + xc;
+      }
+      v[i] = at32(src, o);
     }
 #pragma unroll
     for (int j = 0; j < EH; ++j) {                                       // the RK operands of this wavefront's share, requested up front
@@ -773,12 +780,12 @@ __device__ __forceinline__ void ct_adj_x_body(const GenDft<T>& a, unsigned ysl) 
     }
   }
   cx<T>* row = s + wave * LD;
-  if (a.in_tiled) {
+  {
+    const bool tl = a.in_tiled != 0;
+    cx<T>* const dstrow = tl ? s + (m * R + trr) * LD : row;
+    const int x0 = tl ? txb : lane;
 #pragma unroll
-    for (int i = 0; i < E; ++i) { const int x = txb + 64 * i; if (N % 64 == 0 || x < N) s[(m * R + trr) * LD + pad(x)] = v[i]; }
-  } else {
-#pragma unroll
-    for (int i = 0; i < E; ++i) { const int n = lane + 64 * i; if (N % 64 == 0 || n < N) row[pad(n)] = v[i]; }
+    for (int i = 0; i < E; ++i) { const int x = x0 + 64 * i; if (N % 64 == 0 || x < N) dstrow[pad(x)] = v[i]; }
   }
   twr.commit(tw);
   __syncthreads();

@@ -83,7 +83,7 @@ def test_compile_time_plans_posterior_gradient_768():
     TP.test_logpdf_mixed_and_gradient("f32", "P", (768, 768), scale32=10.0)
 
 
-CT_LIST = (96, 160, 192, 320, 360, 384, 480, 640, 720, 768, 960, 1000, 1152, 1280, 1536, 1920, 2304, 3072)     # CMBL_CT_LIST of csrc/kernels_ct.hpp
+CT_LIST = (96, 160, 192, 320, 360, 384, 480, 576, 640, 720, 768, 960, 1000, 1152, 1280, 1536, 1920, 2304, 2560, 3072)     # CMBL_CT_LIST of csrc/kernels_ct.hpp
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -237,7 +237,7 @@ def test_anysize_row_group_height_changes_no_result(camb, prec, Ny, Nx, P):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("Ny,Nx,P,B", [(96, 160, 2, 1), (160, 96, 2, 3), (384, 192, 1, 1), (360, 320, 3, 2), (480, 720, 2, 1), (720, 960, 1, 1), (1280, 96, 2, 1), (96, 1536, 2, 1), (1152, 192, 2, 1), (192, 1152, 2, 1), (2304, 96, 2, 1), (96, 3072, 2, 2), (3072, 160, 1, 1)])
+@pytest.mark.parametrize("Ny,Nx,P,B", [(96, 160, 2, 1), (160, 96, 2, 3), (384, 192, 1, 1), (360, 320, 3, 2), (480, 720, 2, 1), (720, 960, 1, 1), (1280, 96, 2, 1), (96, 1536, 2, 1), (1152, 192, 2, 1), (192, 1152, 2, 1), (2304, 96, 2, 1), (96, 3072, 2, 2), (3072, 160, 1, 1), (576, 576, 2, 1), (2560, 96, 2, 1), (96, 2560, 1, 2)])
 def test_anysize_tiled_hand_off_changes_no_result(camb, prec, Ny, Nx, P, B):
     """the half planes the fused any-size stages hand between their column and row launches are tiled ([x / 4][ky][x % 4], option gen_tiled,
     GenDft::in_tiled) instead of [ky][x]: a layout of scratch arrays only -- every sequence goes through the same wavefront arithmetic, bit for
