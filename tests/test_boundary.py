@@ -99,3 +99,25 @@ def test_every_context_option_is_documented_in_the_header():
     assert len(names) >= 20
     missing = [n for n in names if f'"{n}"' not in hdr]
     assert not missing, missing
+
+def test_plan_length_list_of_the_gpu_tests_is_the_header_s():
+    """tests/test_gpu_anysize.py::CT_LIST (every length against NumPy and the run-time plans) and tools/gpu_ct_sweep.py::CT are the compile-time-plan
+    list of csrc/kernels_ct.hpp (CMBL_CT_LIST_A + _B): a length added to the header without its tests fails here"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "cmblensing.jl_amd", "csrc", "kernels_ct.hpp")).read()
+    lens = []
+    for half in ("A", "B"):
+        m = re.search(r"#define CMBL_CT_LIST_%s\(X\)(.*)" % half, hdr)
+        lens += [int(v) for v in re.findall(r"X\((\d+)\)", m.group(1))]
+    assert len(lens) == len(set(lens)) and len(lens) >= 20
+    for path, name in (("tests/test_gpu_anysize.py", "CT_LIST"), ("tools/gpu_ct_sweep.py", "CT")):
+        src = open(os.path.join(root, path)).read()
+        m = re.search(r"^%s = \(([0-9, ]+)\)" % name, src, re.M)
+        assert m, path
+        assert sorted(int(v) for v in m.group(1).split(",")) == sorted(lens), path
+    for n in lens:                                                       # what the kernels assume: 4 | N (tiled blocks), factors 2, 3, 5 only
+        k = n
+        for pr in (2, 3, 5):
+            while k % pr == 0: k //= pr
+        assert k == 1 and n % 4 == 0, n
